@@ -1,0 +1,251 @@
+#!/usr/bin/env python3
+"""bench.py -- MinHash signatures/sec on MI355X (BASELINE.json metric), one process per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): 1M sets x 256 tokens, num_perm=128 per GPU, synthetic
+pre-hashed tokens ``RandomState(42+rank).randint(0, 2**32, (N, T), uint64)``, seed=1.  A "step"
+is one pass of the hot path (``mhx_minhash_bulk_dev``) over the whole resident corpus, producing
+the [N, K] uint64 signature matrix in HBM.  Inputs are in HBM before the timed region starts.
+Weak scaling: every rank hashes its own 1M-set shard; there is no collective in the data path
+(``--allgather`` adds the RCCL all-gather of the shards after every step, the config-3 shape).
+
+Prints ONE JSON line on rank 0.  ``roofline.achieved`` = algorithmic bytes (8*T + 8*K per
+signature) / average launch duration measured with HIP events on the
+kernel's own stream.  ``cpu_baseline`` = the numpy restatement of the reference's CPU path
+(oracle/, kind "port") timed on a bounded sample on this host, rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--sets", type=int, default=1_000_000, help="sets per GPU")
+    ap.add_argument("--tokens", type=int, default=256)
+    ap.add_argument("--num-perm", type=int, default=128)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--allgather", action="store_true", help="RCCL all-gather of the shards inside every step")
+    ap.add_argument("--check-rows", type=int, default=4096, help="rows verified against the oracle")
+    ap.add_argument("--cpu-sample", type=int, default=40_000, help="sets timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive host->host measurement")
+    ap.add_argument("--u32", action="store_true", help="compact variant: uint32 tokens in, uint32 signatures out")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N`")
+
+    # libmhx (system ROCm runtime) is loaded before torch so that both share one HIP runtime.
+    from datasketch_amd import _native
+    from datasketch_amd.minhash import MinHash
+
+    ctx = _native.Context(local_rank)
+
+    dist = None
+    torch = None
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        import torch  # noqa: F811  (plumbing only: rendezvous, barrier, max-over-ranks)
+        import torch.distributed as dist  # noqa: F811
+
+        backend = "nccl" if args.allgather else os.environ.get("MHX_BENCH_BACKEND", "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+
+    def barrier():
+        if dist is not None:
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
+
+    def sync():
+        ctx.synchronize()
+        if torch is not None and torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+
+    n, t, k = args.sets, args.tokens, args.num_perm
+    proto = MinHash(num_perm=k, seed=args.seed, hashfunc=lambda x: x)
+    perms = proto.permutations
+
+    # ---- synthetic corpus, resident in HBM before timing
+    rng = np.random.RandomState(42 + rank)
+    tokens = rng.randint(0, 2**32, size=(n, t), dtype=np.uint64)
+    if args.u32:
+        d_tok = ctx.to_device(tokens.astype(np.uint32))
+        tok_dtype, out_dtype, out_np, tok_bytes, out_bytes = _native.MHX_U32, _native.MHX_U32, np.uint32, 4, 4
+    else:
+        d_tok = ctx.to_device(tokens)
+        tok_dtype, out_dtype, out_np, tok_bytes, out_bytes = _native.MHX_U64, _native.MHX_U64, np.uint64, 8, 8
+    d_out = ctx.alloc(n * k * out_bytes)
+    ctx.perm_handle(perms)
+
+    gather = None
+    if args.allgather:
+        gather = setup_allgather(ctx, dist, torch, d_out, n * k * out_bytes, world, rank)
+
+    def step():
+        ctx.minhash_bulk_dev(perms, d_tok.ptr, tok_dtype, None, t, n, n * t, None, 0, d_out.ptr, out_dtype)
+        if gather is not None:
+            gather()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+
+    # ---- timed region: exactly K steps, barrier + sync on both sides, max over ranks
+    evs = [ctx.event() for _ in range(args.steps + 1)]
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(args.steps):
+        step()
+        evs[i + 1].record()
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    launch_ms = [evs[i].elapsed_ms(evs[i + 1]) for i in range(args.steps)]
+    kernel_ms = float(np.mean(launch_ms))
+
+    # ---- parity: rows spread over the whole matrix against the C oracle (bit-exact or fail)
+    from oracle import oracle as O
+
+    a, b = perms
+    check = max(0, min(args.check_rows, n))
+    if check:
+        rows = np.unique(np.linspace(0, n - 1, check).astype(np.int64))
+        sig = d_out.download((n, k), out_np)
+        want = O.c_minhash_bulk_dense(tokens[rows], a, b)
+        if not np.array_equal(sig[rows].astype(np.uint64), want):
+            raise SystemExit("PARITY FAILURE: GPU signatures differ from the oracle")
+        del sig
+
+    out = {
+        "metric": "MinHash signatures/sec (1M sets x 256 tokens, num_perm=128)",
+        "value": world * n * args.steps / elapsed,
+        "unit": "signatures/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32" if args.u32 else "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"MinHash.bulk {n} sets x {t} tokens, num_perm={k}, per GPU (BASELINE.json configs[1])",
+            "sets_per_gpu": n,
+            "tokens_per_set": t,
+            "num_perm": k,
+            "token_dtype": "uint32" if args.u32 else "uint64",
+            "signature_dtype": "uint32" if args.u32 else "uint64",
+            "parallelism": f"shard{world}" + ("+allgather" if args.allgather else ""),
+            "parity_rows_checked": int(check),
+        },
+    }
+    alg_bytes = n * (tok_bytes * t + out_bytes * k)  # 8*T + 8*K per signature
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    pair_rate = n * t * k / (kernel_ms * 1e-3)
+    out["roofline"] = {
+        "bound": "hbm",
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS,
+        "traffic": None,
+        "kernel": "minhash_bulk_kernel",
+        "kernel_ms": kernel_ms,
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "note": "integer-VALU-bound kernel: (token,perm) pair evaluations/s = %.3e" % pair_rate,
+    }
+
+    if rank == 0 and world == 1:
+        if not args.no_e2e:
+            t1 = time.perf_counter()
+            ctx.minhash_bulk(perms, tokens.reshape(-1), None, t, n, None)
+            out["pcie_inclusive_value"] = n / (time.perf_counter() - t1)
+        if args.cpu_sample > 0:
+            out["cpu_baseline"] = cpu_baseline(O, tokens, a, b, min(args.cpu_sample, n), k, t)
+    if dist is not None:
+        barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(O, tokens, a, b, sample, k, t):
+    """The reference's CPU path (numpy restatement, oracle/oracle.py:np_minhash_bulk), one core."""
+    sets = list(tokens[:sample])
+    t0 = time.perf_counter()
+    got = O.np_minhash_bulk(sets, a, b)
+    dt = time.perf_counter() - t0
+    c0 = time.perf_counter()
+    want = O.c_minhash_bulk_dense(tokens[:sample], a, b)
+    cdt = time.perf_counter() - c0
+    assert np.array_equal(got, want)
+    return {
+        "value": sample / dt,
+        "unit": "signatures/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"first {sample} sets of the same corpus ({t} tokens, num_perm={k}), numpy per-set loop as MinHash.bulk; {dt:.1f} s",
+        "host_cpus": os.cpu_count(),
+        "c_oracle_value": sample / cdt,
+    }
+
+
+def setup_allgather(ctx, dist, torch, d_out, shard_bytes, world, rank):
+    """All-gather of the signature shards with RCCL (torch.distributed 'nccl' backend as plumbing):
+    device buffers owned by libmhx are wrapped zero-copy through __cuda_array_interface__."""
+    if dist is None:
+        raise SystemExit("--allgather needs a torch.distributed launch (torchrun), also for 1 GPU")
+
+    class _Wrap:
+        def __init__(self, ptr, nbytes):
+            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+    d_all = ctx.alloc(shard_bytes * world)
+    send = torch.as_tensor(_Wrap(d_out.ptr, shard_bytes), device=f"cuda:{torch.cuda.current_device()}")
+    recv = torch.as_tensor(_Wrap(d_all.ptr, shard_bytes * world), device=f"cuda:{torch.cuda.current_device()}")
+
+    def gather():
+        ctx.synchronize()  # shard complete on libmhx's stream before RCCL reads it
+        dist.all_gather_into_tensor(recv, send)
+
+    gather.keepalive = (d_all, send, recv)
+    return gather
+
+
+if __name__ == "__main__":
+    main()

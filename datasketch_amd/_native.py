@@ -1,0 +1,422 @@
+"""ctypes binding of libmhx.so (include/mhx.h) -- the only door from Python to the HIP kernels.
+
+No PyTorch, no CuPy: numpy arrays in, numpy arrays out, raw pointers across the C ABI.
+Product code: this module never imports anything from ``oracle/``; when the shared library or
+a device is missing it raises, it does not fall back to a CPU implementation.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmhx.so")
+
+MHX_OK, MHX_ERR_NO_DEVICE, MHX_ERR_INVALID, MHX_ERR_HIP, MHX_ERR_OOM, MHX_ERR_UNSUPPORTED, MHX_ERR_COMM = range(7)
+MHX_U64, MHX_U32 = 0, 1
+COMM_ID_BYTES = 128
+
+_vp = ctypes.c_void_p
+_i64 = ctypes.c_int64
+_i32 = ctypes.c_int32
+_int = ctypes.c_int
+_sz = ctypes.c_size_t
+
+# name -> argtypes; every function returns int unless listed in _RESTYPE
+_PROTOTYPES = {
+    "mhx_device_count": [ctypes.POINTER(_int)],
+    "mhx_ctx_create": [_int, ctypes.POINTER(_vp)],
+    "mhx_ctx_destroy": [_vp],
+    "mhx_ctx_synchronize": [_vp],
+    "mhx_ctx_device_info": [_vp, ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_i64)],
+    "mhx_ctx_set_option": [_vp, ctypes.c_char_p, _i64],
+    "mhx_dev_alloc": [_vp, _sz, ctypes.POINTER(_vp)],
+    "mhx_dev_free": [_vp, _vp],
+    "mhx_memcpy_h2d": [_vp, _vp, _vp, _sz],
+    "mhx_memcpy_d2h": [_vp, _vp, _vp, _sz],
+    "mhx_memset_dev": [_vp, _vp, _int, _sz],
+    "mhx_event_create": [_vp, ctypes.POINTER(_vp)],
+    "mhx_event_record": [_vp],
+    "mhx_event_synchronize": [_vp],
+    "mhx_event_elapsed_ms": [_vp, _vp, ctypes.POINTER(ctypes.c_float)],
+    "mhx_event_destroy": [_vp],
+    "mhx_perm_create": [_vp, _vp, _vp, _i32, ctypes.POINTER(_vp)],
+    "mhx_perm_destroy": [_vp],
+    "mhx_minhash_bulk_dev": [_vp, _vp, _int, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _int],
+    "mhx_minhash_bulk": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp],
+    "mhx_minhash_update_batch": [_vp, _vp, _i64, _vp],
+    "mhx_minhash_merge_dev": [_vp, _vp, _vp, _i64, _vp],
+    "mhx_minhash_merge": [_vp, _vp, _vp, _i64, _vp],
+    "mhx_wgen_create": [_vp, _vp, _vp, _vp, _i32, _i32, ctypes.POINTER(_vp)],
+    "mhx_wgen_destroy": [_vp],
+    "mhx_weighted_minhash_many": [_vp, _vp, _vp, _vp, _int, _i64, _vp, _vp],
+    "mhx_weighted_minhash_many_dev": [_vp, _vp, _vp, _vp, _int, _i64, _i64, _vp, _vp],
+    "mhx_bbit_num_blocks": [_i32, _i32, ctypes.POINTER(_i32)],
+    "mhx_bbit_pack_dev": [_vp, _vp, _i64, _i32, _i32, _vp],
+    "mhx_bbit_pack": [_vp, _vp, _i64, _i32, _i32, _vp],
+    "mhx_band_keys_dev": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "mhx_band_keys": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "mhx_lean_serialize_dev": [_vp, _vp, _i64, _i32, _i64, _vp],
+    "mhx_lean_serialize": [_vp, _vp, _i64, _i32, _i64, _vp],
+    "mhx_comm_unique_id": [_vp],
+    "mhx_comm_create": [_vp, _vp, _int, _int, ctypes.POINTER(_vp)],
+    "mhx_comm_destroy": [_vp],
+    "mhx_comm_allgather_dev": [_vp, _vp, _vp, _sz],
+}
+_RESTYPE = {"mhx_last_error": ctypes.c_char_p, "mhx_version": ctypes.c_char_p}
+
+EXPORTED_SYMBOLS = sorted(list(_PROTOTYPES) + list(_RESTYPE))
+
+
+class MhxError(RuntimeError):
+    """A libmhx call failed (HIP / RCCL / allocation)."""
+
+
+_lib = None
+_lib_error: Optional[str] = None
+_lock = threading.Lock()
+
+
+def gpu_node_present() -> bool:
+    """True when this host exposes an AMD GPU compute node (so a missing library is a bug, not a CPU box)."""
+    return os.path.exists("/dev/kfd")
+
+
+def load():
+    """Load libmhx.so (built in-tree by datasketch_amd/csrc/build.sh).  Raises if it is missing."""
+    global _lib, _lib_error
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if _lib_error is not None:
+            raise MhxError(_lib_error)
+        try:
+            lib = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            _lib_error = (
+                f"libmhx.so could not be loaded from {LIB_PATH}: {e}. "
+                "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or datasketch_amd/csrc/build.sh"
+            )
+            raise MhxError(_lib_error) from e
+        for name, argtypes in _PROTOTYPES.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = _int
+        for name, restype in _RESTYPE.items():
+            fn = getattr(lib, name)
+            fn.argtypes = []
+            fn.restype = restype
+        _lib = lib
+        return lib
+
+
+def last_error() -> str:
+    return load().mhx_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int) -> None:
+    """Map a libmhx status to the exception the reference's API would raise."""
+    if rc == MHX_OK:
+        return
+    msg = last_error()
+    if rc == MHX_ERR_INVALID:
+        raise ValueError(msg)
+    if rc == MHX_ERR_OOM:
+        raise MemoryError(msg)
+    if rc == MHX_ERR_NO_DEVICE:
+        raise RuntimeError(msg)
+    raise MhxError(f"libmhx error {rc}: {msg}")
+
+
+_device_count: Optional[int] = None
+
+
+def device_count() -> int:
+    global _device_count
+    if _device_count is None:
+        n = _int(0)
+        check(load().mhx_device_count(ctypes.byref(n)))
+        _device_count = n.value
+    return _device_count
+
+
+def gpu_available() -> bool:
+    """Counterpart of the reference's ``_gpu_available`` (datasketch/minhash.py:38-48).
+
+    False on a host without an AMD GPU.  On a GPU host a missing/unloadable libmhx.so raises:
+    the HIP path must never be skipped silently where it could have run.
+    """
+    try:
+        return device_count() > 0
+    except MhxError:
+        if gpu_node_present():
+            raise
+        return False
+
+
+def _ptr(arr: Optional[np.ndarray]):
+    return None if arr is None else arr.ctypes.data
+
+
+class DeviceBuffer:
+    """A device allocation owned by a Context (freed on close() / garbage collection)."""
+
+    def __init__(self, ctx: "Context", nbytes: int):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = _vp()
+        check(ctx.lib.mhx_dev_alloc(ctx.handle, self.nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr: np.ndarray, offset: int = 0) -> "DeviceBuffer":
+        arr = np.ascontiguousarray(arr)
+        if offset + arr.nbytes > self.nbytes:
+            raise ValueError("upload exceeds the device buffer")
+        check(self.ctx.lib.mhx_memcpy_h2d(self.ctx.handle, self.ptr + offset, arr.ctypes.data, arr.nbytes))
+        return self
+
+    def download(self, shape, dtype, offset: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        if offset + out.nbytes > self.nbytes:
+            raise ValueError("download exceeds the device buffer")
+        check(self.ctx.lib.mhx_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr + offset, out.nbytes))
+        return out
+
+    def free(self) -> None:
+        if self.ptr is not None and self.ctx.handle is not None:
+            self.ctx.lib.mhx_dev_free(self.ctx.handle, self.ptr)
+        self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Event:
+    def __init__(self, ctx: "Context"):
+        self.ctx = ctx
+        p = _vp()
+        check(ctx.lib.mhx_event_create(ctx.handle, ctypes.byref(p)))
+        self.handle = p.value
+
+    def record(self) -> "Event":
+        check(self.ctx.lib.mhx_event_record(self.handle))
+        return self
+
+    def synchronize(self) -> None:
+        check(self.ctx.lib.mhx_event_synchronize(self.handle))
+
+    def elapsed_ms(self, stop: "Event") -> float:
+        ms = ctypes.c_float(0)
+        check(self.ctx.lib.mhx_event_elapsed_ms(self.handle, stop.handle, ctypes.byref(ms)))
+        return float(ms.value)
+
+    def __del__(self):
+        try:
+            if self.handle is not None and self.ctx.handle is not None:
+                self.ctx.lib.mhx_event_destroy(self.handle)
+        except Exception:
+            pass
+        self.handle = None
+
+
+class Context:
+    """One device + one HIP stream (mhx_ctx).  Not thread-safe; use one per thread/GPU."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load()
+        p = _vp()
+        check(self.lib.mhx_ctx_create(int(device), ctypes.byref(p)))
+        self.handle = p.value
+        self.device = int(device)
+        self._perms = {}  # (K, digest) -> perm handle
+        self._wgens = {}
+
+    # -- info / knobs
+    def info(self) -> dict:
+        name = ctypes.create_string_buffer(128)
+        cus = _int(0)
+        hbm = _i64(0)
+        check(self.lib.mhx_ctx_device_info(self.handle, name, 128, ctypes.byref(cus), ctypes.byref(hbm)))
+        return {"name": name.value.decode(), "compute_units": cus.value, "hbm_bytes": hbm.value, "device": self.device}
+
+    def set_option(self, key: str, value: int) -> None:
+        check(self.lib.mhx_ctx_set_option(self.handle, key.encode(), int(value)))
+
+    def synchronize(self) -> None:
+        check(self.lib.mhx_ctx_synchronize(self.handle))
+
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def to_device(self, arr: np.ndarray) -> DeviceBuffer:
+        arr = np.ascontiguousarray(arr)
+        return DeviceBuffer(self, max(arr.nbytes, 1)).upload(arr)
+
+    def event(self) -> Event:
+        return Event(self)
+
+    # -- MinHash permutations (replaces the reference's _ensure_gpu_caches)
+    def perm_handle(self, permutations) -> int:
+        a = np.ascontiguousarray(permutations[0], dtype=np.uint64)
+        b = np.ascontiguousarray(permutations[1], dtype=np.uint64)
+        if a.ndim != 1 or a.shape != b.shape or a.size == 0:
+            raise ValueError("permutations must be two equally long 1-D arrays")
+        key = (a.size, hash(a.tobytes()), hash(b.tobytes()))
+        h = self._perms.get(key)
+        if h is None:
+            if len(self._perms) >= 64:  # bounded cache of uploaded permutation sets
+                _, old = self._perms.popitem()
+                self.lib.mhx_perm_destroy(old)
+            p = _vp()
+            check(self.lib.mhx_perm_create(self.handle, a.ctypes.data, b.ctypes.data, a.size, ctypes.byref(p)))
+            h = p.value
+            self._perms[key] = h
+        return h
+
+    def wgen_create(self, rs, ln_cs, betas) -> int:
+        """Upload WeightedMinHashGenerator tables (float32 [sample_size, dim]); returns an mhx_wgen handle."""
+        rs = np.ascontiguousarray(rs, dtype=np.float32)
+        ln_cs = np.ascontiguousarray(ln_cs, dtype=np.float32)
+        betas = np.ascontiguousarray(betas, dtype=np.float32)
+        if rs.ndim != 2 or rs.shape != ln_cs.shape or rs.shape != betas.shape:
+            raise ValueError("rs, ln_cs, betas must share one 2-D shape")
+        p = _vp()
+        check(self.lib.mhx_wgen_create(self.handle, rs.ctypes.data, ln_cs.ctypes.data, betas.ctypes.data, rs.shape[0], rs.shape[1], ctypes.byref(p)))
+        self._wgens[p.value] = True
+        return p.value
+
+    def wgen_destroy(self, handle: int) -> None:
+        if self.handle is not None and self._wgens.pop(handle, None):
+            self.lib.mhx_wgen_destroy(handle)
+
+    # -- host-buffer entry points ------------------------------------------------------------
+    def minhash_bulk(self, permutations, hv: np.ndarray, offsets: Optional[np.ndarray], fixed_len: int, n_sets: int,
+                     init: Optional[np.ndarray] = None) -> np.ndarray:
+        """CSR / fixed-length corpus of pre-hashed tokens -> [n_sets, K] uint64 (host in, host out)."""
+        perm = self.perm_handle(permutations)
+        k = len(permutations[0])
+        hv = np.ascontiguousarray(hv, dtype=np.uint64)
+        if offsets is not None:
+            offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+            if offsets.shape != (n_sets + 1,):
+                raise ValueError("offsets must have n_sets+1 entries")
+            if n_sets and int(offsets[-1]) > hv.size:
+                raise ValueError("offsets run past the token array")
+        elif fixed_len * n_sets > hv.size:
+            raise ValueError("token array shorter than n_sets*fixed_len")
+        stride = 0
+        if init is not None:
+            init = np.ascontiguousarray(init, dtype=np.uint64)
+            if init.shape == (k,):
+                stride = 0
+            elif init.shape == (n_sets, k):
+                stride = k
+            else:
+                raise ValueError("init must have shape (K,) or (n_sets, K)")
+        out = np.empty((n_sets, k), dtype=np.uint64)
+        check(self.lib.mhx_minhash_bulk(perm, _ptr(hv), _ptr(offsets), int(fixed_len), int(n_sets), _ptr(init), stride, _ptr(out)))
+        return out
+
+    def minhash_update_batch(self, permutations, hv: np.ndarray, hashvalues: np.ndarray) -> np.ndarray:
+        perm = self.perm_handle(permutations)
+        hv = np.ascontiguousarray(hv, dtype=np.uint64)
+        state = np.array(hashvalues, dtype=np.uint64, copy=True)
+        check(self.lib.mhx_minhash_update_batch(perm, _ptr(hv), hv.size, _ptr(state)))
+        return state
+
+    def minhash_merge(self, x: np.ndarray, y: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.uint64)
+        y = np.ascontiguousarray(y, dtype=np.uint64)
+        if x.shape != y.shape:
+            raise ValueError("signature matrices must have the same shape")
+        out = np.empty_like(x)
+        check(self.lib.mhx_minhash_merge(self.handle, _ptr(x), _ptr(y), x.size, _ptr(out)))
+        return out
+
+    def weighted_minhash_many(self, h: int, sample_size: int, indptr, indices, values, values_are_logs: bool):
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        values = np.ascontiguousarray(values, dtype=np.float32)
+        n = indptr.size - 1
+        out = np.zeros((n, int(sample_size), 2), dtype=np.int64)
+        nonempty = np.zeros(n, dtype=np.uint8)
+        check(self.lib.mhx_weighted_minhash_many(h, _ptr(indptr), _ptr(indices), _ptr(values), int(bool(values_are_logs)), n, _ptr(out), _ptr(nonempty)))
+        return out, nonempty.astype(bool)
+
+    def bbit_pack(self, sig: np.ndarray, b: int) -> np.ndarray:
+        sig = np.ascontiguousarray(sig, dtype=np.uint64)
+        n, k = sig.shape
+        nb = _i32(0)
+        check(self.lib.mhx_bbit_num_blocks(k, int(b), ctypes.byref(nb)))
+        out = np.zeros((n, nb.value), dtype=np.uint64)
+        check(self.lib.mhx_bbit_pack(self.handle, _ptr(sig), n, k, int(b), _ptr(out)))
+        return out
+
+    def band_keys(self, sig: np.ndarray, bands: int, r: int) -> np.ndarray:
+        sig = np.ascontiguousarray(sig, dtype=np.uint64)
+        n, k = sig.shape
+        out = np.empty((n, bands * r), dtype=np.uint64)
+        check(self.lib.mhx_band_keys(self.handle, _ptr(sig), n, k, int(bands), int(r), _ptr(out)))
+        return out
+
+    def lean_serialize(self, sig: np.ndarray, seed: int) -> np.ndarray:
+        sig = np.ascontiguousarray(sig, dtype=np.uint64)
+        n, k = sig.shape
+        out = np.zeros((n, 12 + 4 * k), dtype=np.uint8)
+        check(self.lib.mhx_lean_serialize(self.handle, _ptr(sig), n, k, int(seed), _ptr(out)))
+        return out
+
+    # -- device-resident entry points (pointers are DeviceBuffer.ptr + byte offsets) -----------
+    def minhash_bulk_dev(self, permutations, d_hv: int, hv_dtype: int, d_offsets: Optional[int], fixed_len: int, n_sets: int,
+                         total_tokens: int, d_init: Optional[int], init_stride: int, d_out: int, out_dtype: int) -> None:
+        perm = self.perm_handle(permutations)
+        check(self.lib.mhx_minhash_bulk_dev(perm, d_hv, hv_dtype, d_offsets, int(fixed_len), int(n_sets), int(total_tokens), d_init, int(init_stride), d_out, out_dtype))
+
+    def close(self) -> None:
+        if self.handle is None:
+            return
+        for h in self._perms.values():
+            self.lib.mhx_perm_destroy(h)
+        for h in list(self._wgens):
+            self.lib.mhx_wgen_destroy(h)
+        self._perms.clear()
+        self._wgens.clear()
+        self.lib.mhx_ctx_destroy(self.handle)
+        self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_contexts = {}
+
+
+def default_device() -> int:
+    """Device for the implicit context: MHX_DEVICE, else LOCAL_RANK (one process per GPU), else 0."""
+    for var in ("MHX_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(var)
+        if v is not None and v.strip().lstrip("-").isdigit():
+            n = device_count()
+            return int(v) % n if n else 0
+    return 0
+
+
+def context(device: Optional[int] = None) -> Context:
+    """Process-wide context per device (created lazily; raises RuntimeError without a device)."""
+    dev = default_device() if device is None else int(device)
+    key = (os.getpid(), dev)
+    ctx = _contexts.get(key)
+    if ctx is None:
+        ctx = Context(dev)
+        _contexts[key] = ctx
+    return ctx

@@ -1,0 +1,123 @@
+// comm.hip -- RCCL all-gather of signature-matrix shards over xGMI (one rank per context/GPU).
+// RCCL is bound lazily with dlopen so libmhx.so loads on hosts that have no librccl.so.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+
+#include "mhx_internal.h"
+
+struct mhx_comm {
+    mhx_ctx *ctx = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0;
+    int world = 1;
+};
+
+namespace {
+
+struct Rccl {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        for (const char *n : names) {
+            r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (r.handle) break;
+        }
+        if (!r.handle) {
+            r.error = std::string("cannot load librccl.so: ") + dlerror();
+            return;
+        }
+#define MHX_SYM(field, sym)                                              \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.handle, sym)); \
+    if (!r.field) r.error = std::string("librccl.so lacks symbol ") + sym;
+        MHX_SYM(GetUniqueId, "ncclGetUniqueId")
+        MHX_SYM(CommInitRank, "ncclCommInitRank")
+        MHX_SYM(CommDestroy, "ncclCommDestroy")
+        MHX_SYM(AllGather, "ncclAllGather")
+        MHX_SYM(GetErrorString, "ncclGetErrorString")
+#undef MHX_SYM
+    });
+    return r;
+}
+
+int rccl_ready() {
+    Rccl &r = rccl();
+    if (!r.error.empty()) return mhx::fail(MHX_ERR_COMM, "%s", r.error.c_str());
+    return MHX_OK;
+}
+
+#define MHX_RCCL_CHECK(expr)                                                                          \
+    do {                                                                                              \
+        ncclResult_t _r = (expr);                                                                     \
+        if (_r != ncclSuccess)                                                                        \
+            return mhx::fail(MHX_ERR_COMM, "%s failed: %s", #expr, rccl().GetErrorString(_r));        \
+    } while (0)
+
+}  // namespace
+
+static_assert(sizeof(ncclUniqueId) == MHX_COMM_ID_BYTES, "RCCL unique id size changed");
+
+extern "C" {
+
+int mhx_comm_unique_id(uint8_t id[MHX_COMM_ID_BYTES]) {
+    if (!id) return mhx::fail(MHX_ERR_INVALID, "id is NULL");
+    if (int rc = rccl_ready()) return rc;
+    ncclUniqueId uid;
+    MHX_RCCL_CHECK(rccl().GetUniqueId(&uid));
+    memcpy(id, &uid, MHX_COMM_ID_BYTES);
+    return MHX_OK;
+}
+
+int mhx_comm_create(mhx_ctx *ctx, const uint8_t id[MHX_COMM_ID_BYTES], int rank, int world_size,
+                    mhx_comm **out) {
+    if (!ctx || !id || !out) return mhx::fail(MHX_ERR_INVALID, "NULL argument");
+    MHX_REQUIRE(world_size > 0 && rank >= 0 && rank < world_size, "bad rank %d / world_size %d", rank, world_size);
+    if (int rc = rccl_ready()) return rc;
+    if (int rc = ctx->activate()) return rc;
+    ncclUniqueId uid;
+    memcpy(&uid, id, MHX_COMM_ID_BYTES);
+    mhx_comm *c = new mhx_comm();
+    c->ctx = ctx;
+    c->rank = rank;
+    c->world = world_size;
+    ncclResult_t r = rccl().CommInitRank(&c->comm, world_size, uid, rank);
+    if (r != ncclSuccess) {
+        delete c;
+        return mhx::fail(MHX_ERR_COMM, "ncclCommInitRank failed: %s", rccl().GetErrorString(r));
+    }
+    *out = c;
+    return MHX_OK;
+}
+
+int mhx_comm_destroy(mhx_comm *comm) {
+    if (!comm) return MHX_OK;
+    (void)hipSetDevice(comm->ctx->device);
+    (void)hipStreamSynchronize(comm->ctx->stream);
+    if (comm->comm) (void)rccl().CommDestroy(comm->comm);
+    delete comm;
+    return MHX_OK;
+}
+
+int mhx_comm_allgather_dev(mhx_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank) {
+    if (!comm) return mhx::fail(MHX_ERR_INVALID, "comm is NULL");
+    if (bytes_per_rank == 0) return MHX_OK;
+    MHX_REQUIRE(d_send && d_recv, "NULL device pointer");
+    if (int rc = comm->ctx->activate()) return rc;
+    MHX_RCCL_CHECK(rccl().AllGather(d_send, d_recv, bytes_per_rank, ncclUint8, comm->comm, comm->ctx->stream));
+    return MHX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,581 @@
+// mhx_api.hip -- C ABI of libmhx (include/mhx.h): context, device memory, events and the
+// host-buffer entry points that stage through device scratch.  Product code: no oracle here.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "mhx_internal.h"
+
+namespace mhx {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+int bbit_slot_size(int b) {  // ref: datasketch/b_bit_minhash.py:147-160
+    if (b == 1) return 1;
+    if (b == 2) return 2;
+    if (b <= 4) return 4;
+    if (b <= 8) return 8;
+    if (b <= 16) return 16;
+    return 32;
+}
+
+}  // namespace mhx
+
+using mhx::fail;
+
+int mhx_ctx::activate() const {
+    MHX_HIP_CHECK(hipSetDevice(device));
+    return MHX_OK;
+}
+
+int mhx_ctx::ensure_scratch(int slot, size_t bytes) {
+    if (bytes <= scratch_bytes[slot]) return MHX_OK;
+    if (scratch[slot]) {
+        MHX_HIP_CHECK(hipStreamSynchronize(stream));
+        MHX_HIP_CHECK(hipFree(scratch[slot]));
+        scratch[slot] = nullptr;
+        scratch_bytes[slot] = 0;
+    }
+    // grow geometrically so repeated slightly larger calls do not reallocate every time
+    size_t want = std::max(bytes, scratch_bytes[slot] + scratch_bytes[slot] / 2);
+    want = (want + 255) & ~(size_t)255;
+    hipError_t e = hipMalloc(&scratch[slot], want);
+    if (e != hipSuccess && want != bytes) {
+        want = (bytes + 255) & ~(size_t)255;
+        e = hipMalloc(&scratch[slot], want);
+    }
+    if (e != hipSuccess) {
+        scratch[slot] = nullptr;
+        return fail(MHX_ERR_OOM, "device scratch allocation of %zu bytes failed: %s", want,
+                    hipGetErrorString(e));
+    }
+    scratch_bytes[slot] = want;
+    return MHX_OK;
+}
+
+extern "C" {
+
+const char *mhx_last_error(void) { return mhx::g_last_error.c_str(); }
+
+const char *mhx_version(void) { return "mhx 0.1.0 (gfx950)"; }
+
+int mhx_device_count(int *count) {
+    if (!count) return fail(MHX_ERR_INVALID, "count is NULL");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        *count = 0;
+        return MHX_OK;  // "no device" is an answer, not an error (ref: minhash.py:38-48)
+    }
+    *count = n;
+    return MHX_OK;
+}
+
+int mhx_ctx_create(int device, mhx_ctx **out) {
+    if (!out) return fail(MHX_ERR_INVALID, "ctx out pointer is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(MHX_ERR_NO_DEVICE, "no HIP device is available");
+    }
+    if (device < 0 || device >= n) return fail(MHX_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+    MHX_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MHX_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    mhx_ctx *ctx = new mhx_ctx();
+    ctx->device = device;
+    ctx->num_cus = prop.multiProcessorCount;
+    ctx->hbm_bytes = (int64_t)prop.totalGlobalMem;
+    snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(MHX_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return MHX_OK;
+}
+
+int mhx_ctx_destroy(mhx_ctx *ctx) {
+    if (!ctx) return MHX_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 4; ++i)
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MHX_OK;
+}
+
+int mhx_ctx_synchronize(mhx_ctx *ctx) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MHX_OK;
+}
+
+int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus, int64_t *hbm_bytes) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    if (name && name_len > 0) {
+        strncpy(name, ctx->name, (size_t)name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (cus) *cus = ctx->num_cus;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    return MHX_OK;
+}
+
+int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
+    if (!ctx || !key) return fail(MHX_ERR_INVALID, "ctx/key is NULL");
+    if (!strcmp(key, "minhash.path")) ctx->opt_minhash_path = value;
+    else if (!strcmp(key, "minhash.split")) ctx->opt_minhash_split = value;
+    else if (!strcmp(key, "blocks_per_cu")) ctx->opt_blocks_per_cu = value;
+    else if (!strcmp(key, "weighted.rows")) ctx->opt_weighted_rows = value;
+    else return fail(MHX_ERR_INVALID, "unknown option '%s'", key);
+    return MHX_OK;
+}
+
+// ---- device memory -------------------------------------------------------------------------
+int mhx_dev_alloc(mhx_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) return fail(MHX_ERR_INVALID, "ctx/dptr is NULL");
+    *dptr = nullptr;
+    if (int rc = ctx->activate()) return rc;
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(MHX_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    return MHX_OK;
+}
+
+int mhx_dev_free(mhx_ctx *ctx, void *dptr) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    if (!dptr) return MHX_OK;
+    if (int rc = ctx->activate()) return rc;
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    MHX_HIP_CHECK(hipFree(dptr));
+    return MHX_OK;
+}
+
+int mhx_memcpy_h2d(mhx_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    if (!bytes) return MHX_OK;
+    if (int rc = ctx->activate()) return rc;
+    MHX_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MHX_OK;
+}
+
+int mhx_memcpy_d2h(mhx_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    if (!bytes) return MHX_OK;
+    if (int rc = ctx->activate()) return rc;
+    MHX_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MHX_OK;
+}
+
+int mhx_memset_dev(mhx_ctx *ctx, void *dst, int byte_value, size_t bytes) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    if (!bytes) return MHX_OK;
+    if (int rc = ctx->activate()) return rc;
+    MHX_HIP_CHECK(hipMemsetAsync(dst, byte_value, bytes, ctx->stream));
+    return MHX_OK;
+}
+
+// ---- events --------------------------------------------------------------------------------
+int mhx_event_create(mhx_ctx *ctx, mhx_event **ev) {
+    if (!ctx || !ev) return fail(MHX_ERR_INVALID, "ctx/ev is NULL");
+    if (int rc = ctx->activate()) return rc;
+    mhx_event *e = new mhx_event();
+    e->ctx = ctx;
+    hipError_t err = hipEventCreate(&e->ev);
+    if (err != hipSuccess) {
+        delete e;
+        return fail(MHX_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(err));
+    }
+    *ev = e;
+    return MHX_OK;
+}
+
+int mhx_event_record(mhx_event *ev) {
+    if (!ev) return fail(MHX_ERR_INVALID, "event is NULL");
+    MHX_HIP_CHECK(hipEventRecord(ev->ev, ev->ctx->stream));
+    return MHX_OK;
+}
+
+int mhx_event_synchronize(mhx_event *ev) {
+    if (!ev) return fail(MHX_ERR_INVALID, "event is NULL");
+    MHX_HIP_CHECK(hipEventSynchronize(ev->ev));
+    return MHX_OK;
+}
+
+int mhx_event_elapsed_ms(mhx_event *start, mhx_event *stop, float *ms) {
+    if (!start || !stop || !ms) return fail(MHX_ERR_INVALID, "event/ms is NULL");
+    MHX_HIP_CHECK(hipEventElapsedTime(ms, start->ev, stop->ev));
+    return MHX_OK;
+}
+
+int mhx_event_destroy(mhx_event *ev) {
+    if (!ev) return MHX_OK;
+    (void)hipEventDestroy(ev->ev);
+    delete ev;
+    return MHX_OK;
+}
+
+// ---- MinHash -------------------------------------------------------------------------------
+int mhx_perm_create(mhx_ctx *ctx, const uint64_t *a, const uint64_t *b, int32_t num_perm,
+                    mhx_perm **out) {
+    if (!ctx || !a || !b || !out) return fail(MHX_ERR_INVALID, "NULL argument");
+    MHX_REQUIRE(num_perm > 0, "num_perm must be positive, got %d", num_perm);
+    if (int rc = ctx->activate()) return rc;
+    mhx_perm *p = new mhx_perm();
+    p->ctx = ctx;
+    p->num_perm = num_perm;
+    const size_t bytes = sizeof(uint64_t) * (size_t)num_perm;
+    hipError_t e = hipMalloc((void **)&p->d_a, 2 * bytes);
+    if (e != hipSuccess) {
+        delete p;
+        return fail(MHX_ERR_OOM, "hipMalloc for permutations failed: %s", hipGetErrorString(e));
+    }
+    p->d_b = p->d_a + num_perm;
+    e = hipMemcpyAsync(p->d_a, a, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(p->d_b, b, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        (void)hipFree(p->d_a);
+        delete p;
+        return fail(MHX_ERR_HIP, "uploading permutations failed: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return MHX_OK;
+}
+
+int mhx_perm_destroy(mhx_perm *perm) {
+    if (!perm) return MHX_OK;
+    (void)hipSetDevice(perm->ctx->device);
+    (void)hipStreamSynchronize(perm->ctx->stream);
+    (void)hipFree(perm->d_a);
+    delete perm;
+    return MHX_OK;
+}
+
+int mhx_minhash_bulk_dev(mhx_perm *perm, const void *d_hv, int hv_dtype, const int64_t *d_offsets,
+                         int64_t fixed_len, int64_t n_sets, int64_t total_tokens,
+                         const uint64_t *d_init, int64_t init_stride, void *d_out, int out_dtype) {
+    if (!perm) return fail(MHX_ERR_INVALID, "perm is NULL");
+    MHX_REQUIRE(n_sets >= 0, "n_sets must be >= 0");
+    MHX_REQUIRE(hv_dtype == MHX_U64 || hv_dtype == MHX_U32, "bad hv_dtype %d", hv_dtype);
+    MHX_REQUIRE(out_dtype == MHX_U64 || out_dtype == MHX_U32, "bad out_dtype %d", out_dtype);
+    MHX_REQUIRE(d_offsets || fixed_len >= 0, "fixed_len must be >= 0 when offsets is NULL");
+    MHX_REQUIRE(init_stride == 0 || init_stride >= perm->num_perm, "init_stride must be 0 or >= num_perm");
+    MHX_REQUIRE(total_tokens >= 0, "total_tokens must be >= 0");
+    if (n_sets == 0) return MHX_OK;
+    MHX_REQUIRE(d_out, "d_out is NULL");
+    MHX_REQUIRE(d_hv || total_tokens == 0, "d_hv is NULL");
+    if (int rc = perm->ctx->activate()) return rc;
+    return mhx::launch_minhash_bulk(perm, d_hv, hv_dtype, d_offsets, fixed_len, n_sets, total_tokens,
+                                    d_init, init_stride, d_out, out_dtype);
+}
+
+int mhx_minhash_bulk(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets, int64_t fixed_len,
+                     int64_t n_sets, const uint64_t *init, int64_t init_stride, uint64_t *out) {
+    if (!perm) return fail(MHX_ERR_INVALID, "perm is NULL");
+    MHX_REQUIRE(n_sets >= 0, "n_sets must be >= 0");
+    if (n_sets == 0) return MHX_OK;
+    MHX_REQUIRE(out, "out is NULL");
+    MHX_REQUIRE(offsets || fixed_len >= 0, "fixed_len must be >= 0 when offsets is NULL");
+    mhx_ctx *ctx = perm->ctx;
+    if (int rc = ctx->activate()) return rc;
+    const int64_t k = perm->num_perm;
+    int64_t total = 0;
+    if (offsets) {
+        MHX_REQUIRE(offsets[0] >= 0, "offsets[0] must be >= 0");
+        for (int64_t i = 0; i < n_sets; ++i)
+            MHX_REQUIRE(offsets[i + 1] >= offsets[i], "offsets must be non-decreasing (row %lld)", (long long)i);
+        total = offsets[n_sets];
+    } else {
+        total = n_sets * fixed_len;
+    }
+    MHX_REQUIRE(hv || total == 0, "hv is NULL");
+    const size_t hv_bytes = sizeof(uint64_t) * (size_t)total;
+    const size_t off_bytes = offsets ? sizeof(int64_t) * (size_t)(n_sets + 1) : 0;
+    const size_t out_bytes = sizeof(uint64_t) * (size_t)(n_sets * k);
+    const size_t init_bytes = init ? sizeof(uint64_t) * (size_t)(init_stride ? n_sets * init_stride : k) : 0;
+    if (int rc = ctx->ensure_scratch(0, hv_bytes + 256)) return rc;
+    if (int rc = ctx->ensure_scratch(1, off_bytes + init_bytes + 512)) return rc;
+    if (int rc = ctx->ensure_scratch(2, out_bytes)) return rc;
+    uint64_t *d_hv = (uint64_t *)ctx->scratch[0];
+    int64_t *d_off = offsets ? (int64_t *)ctx->scratch[1] : nullptr;
+    uint64_t *d_init = init ? (uint64_t *)((char *)ctx->scratch[1] + ((off_bytes + 255) & ~(size_t)255)) : nullptr;
+    uint64_t *d_out = (uint64_t *)ctx->scratch[2];
+    if (hv_bytes) MHX_HIP_CHECK(hipMemcpyAsync(d_hv, hv, hv_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (off_bytes) MHX_HIP_CHECK(hipMemcpyAsync(d_off, offsets, off_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (init_bytes) MHX_HIP_CHECK(hipMemcpyAsync(d_init, init, init_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = mhx::launch_minhash_bulk(perm, d_hv, MHX_U64, d_off, fixed_len, n_sets, total, d_init,
+                                          init_stride, d_out, MHX_U64))
+        return rc;
+    MHX_HIP_CHECK(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MHX_OK;
+}
+
+int mhx_minhash_update_batch(mhx_perm *perm, const uint64_t *hv, int64_t n, uint64_t *hashvalues) {
+    if (!perm) return fail(MHX_ERR_INVALID, "perm is NULL");
+    MHX_REQUIRE(n >= 0, "n must be >= 0");
+    if (n == 0) return MHX_OK;  // ref: minhash.py:265-266
+    MHX_REQUIRE(hv && hashvalues, "hv/hashvalues is NULL");
+    return mhx_minhash_bulk(perm, hv, nullptr, n, 1, hashvalues, 0, hashvalues);
+}
+
+int mhx_minhash_merge_dev(mhx_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y, int64_t count,
+                          uint64_t *d_out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_REQUIRE(count >= 0, "count must be >= 0");
+    if (count == 0) return MHX_OK;
+    MHX_REQUIRE(d_x && d_y && d_out, "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_minhash_merge(ctx, d_x, d_y, count, d_out);
+}
+
+int mhx_minhash_merge(mhx_ctx *ctx, const uint64_t *x, const uint64_t *y, int64_t count, uint64_t *out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_REQUIRE(count >= 0, "count must be >= 0");
+    if (count == 0) return MHX_OK;
+    MHX_REQUIRE(x && y && out, "NULL host pointer");
+    if (int rc = ctx->activate()) return rc;
+    const size_t bytes = sizeof(uint64_t) * (size_t)count;
+    if (int rc = ctx->ensure_scratch(0, bytes)) return rc;
+    if (int rc = ctx->ensure_scratch(2, bytes)) return rc;
+    uint64_t *dx = (uint64_t *)ctx->scratch[0], *dy = (uint64_t *)ctx->scratch[2];
+    MHX_HIP_CHECK(hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, ctx->stream));
+    MHX_HIP_CHECK(hipMemcpyAsync(dy, y, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = mhx::launch_minhash_merge(ctx, dx, dy, count, dx)) return rc;
+    MHX_HIP_CHECK(hipMemcpyAsync(out, dx, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MHX_OK;
+}
+
+// ---- packing -------------------------------------------------------------------------------
+int mhx_bbit_num_blocks(int32_t num_perm, int32_t b, int32_t *num_blocks) {
+    if (!num_blocks) return fail(MHX_ERR_INVALID, "num_blocks is NULL");
+    MHX_REQUIRE(b >= 0 && b <= 32, "b must be an integer in [0, 32]");
+    MHX_REQUIRE(num_perm > 0, "num_perm must be positive");
+    const int per = 64 / mhx::bbit_slot_size(b);
+    *num_blocks = (num_perm + per - 1) / per;
+    return MHX_OK;
+}
+
+int mhx_bbit_pack_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t b,
+                      uint64_t *d_out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_REQUIRE(b >= 0 && b <= 32, "b must be an integer in [0, 32]");
+    MHX_REQUIRE(k > 0 && n >= 0, "bad shape");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(d_sig && d_out, "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_bbit_pack(ctx, d_sig, n, k, b, d_out);
+}
+
+int mhx_band_keys_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands,
+                      int32_t r, uint64_t *d_out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
+    MHX_REQUIRE(n >= 0, "bad shape");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(d_sig && d_out, "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_band_keys(ctx, d_sig, n, k, bands, r, d_out);
+}
+
+int mhx_lean_serialize_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int64_t seed,
+                           uint8_t *d_out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_REQUIRE(k > 0 && n >= 0, "bad shape");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(d_sig && d_out, "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_lean_serialize(ctx, d_sig, n, k, seed, d_out);
+}
+
+// host wrappers: stage signature matrix in scratch[0], result in scratch[2]
+static int stage_sig(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, size_t out_bytes) {
+    if (int rc = ctx->activate()) return rc;
+    const size_t in_bytes = sizeof(uint64_t) * (size_t)(n * k);
+    if (int rc = ctx->ensure_scratch(0, in_bytes)) return rc;
+    if (int rc = ctx->ensure_scratch(2, out_bytes)) return rc;
+    MHX_HIP_CHECK(hipMemcpyAsync(ctx->scratch[0], sig, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    return MHX_OK;
+}
+
+static int fetch_out(mhx_ctx *ctx, void *out, size_t out_bytes) {
+    MHX_HIP_CHECK(hipMemcpyAsync(out, ctx->scratch[2], out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MHX_OK;
+}
+
+int mhx_bbit_pack(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int32_t b, uint64_t *out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    int32_t nb = 0;
+    if (int rc = mhx_bbit_num_blocks(k, b, &nb)) return rc;
+    MHX_REQUIRE(n >= 0, "bad shape");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(sig && out, "NULL host pointer");
+    const size_t out_bytes = sizeof(uint64_t) * (size_t)(n * nb);
+    if (int rc = stage_sig(ctx, sig, n, k, out_bytes)) return rc;
+    if (int rc = mhx::launch_bbit_pack(ctx, (const uint64_t *)ctx->scratch[0], n, k, b, (uint64_t *)ctx->scratch[2]))
+        return rc;
+    return fetch_out(ctx, out, out_bytes);
+}
+
+int mhx_band_keys(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int32_t bands, int32_t r,
+                  uint64_t *out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
+    MHX_REQUIRE(n >= 0, "bad shape");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(sig && out, "NULL host pointer");
+    const size_t out_bytes = sizeof(uint64_t) * (size_t)(n * bands * r);
+    if (int rc = stage_sig(ctx, sig, n, k, out_bytes)) return rc;
+    if (int rc = mhx::launch_band_keys(ctx, (const uint64_t *)ctx->scratch[0], n, k, bands, r,
+                                       (uint64_t *)ctx->scratch[2]))
+        return rc;
+    return fetch_out(ctx, out, out_bytes);
+}
+
+int mhx_lean_serialize(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int64_t seed, uint8_t *out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_REQUIRE(k > 0 && n >= 0, "bad shape");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(sig && out, "NULL host pointer");
+    const size_t out_bytes = (size_t)n * (12 + 4 * (size_t)k);
+    if (int rc = stage_sig(ctx, sig, n, k, out_bytes)) return rc;
+    if (int rc = mhx::launch_lean_serialize(ctx, (const uint64_t *)ctx->scratch[0], n, k, seed,
+                                            (uint8_t *)ctx->scratch[2]))
+        return rc;
+    return fetch_out(ctx, out, out_bytes);
+}
+
+// ---- weighted ------------------------------------------------------------------------------
+int mhx_wgen_create(mhx_ctx *ctx, const float *rs, const float *ln_cs, const float *betas,
+                    int32_t sample_size, int32_t dim, mhx_wgen **out) {
+    if (!ctx || !rs || !ln_cs || !betas || !out) return fail(MHX_ERR_INVALID, "NULL argument");
+    MHX_REQUIRE(sample_size > 0 && dim > 0, "sample_size and dim must be positive");
+    if (int rc = ctx->activate()) return rc;
+    mhx_wgen *g = new mhx_wgen();
+    g->ctx = ctx;
+    g->sample_size = sample_size;
+    g->dim = dim;
+    g->s_pad = (sample_size + 63) / 64 * 64;
+    const size_t n = (size_t)sample_size * dim;
+    const size_t t_bytes = sizeof(float) * 3 * (size_t)g->s_pad * dim;
+    hipError_t e = hipMalloc((void **)&g->d_params, t_bytes);
+    if (e != hipSuccess) {
+        delete g;
+        return fail(MHX_ERR_OOM, "hipMalloc for weighted parameters failed: %s", hipGetErrorString(e));
+    }
+    int rc = ctx->ensure_scratch(0, 3 * n * sizeof(float));
+    if (rc == MHX_OK) {
+        float *d = (float *)ctx->scratch[0];
+        e = hipMemcpyAsync(d, rs, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d + n, ln_cs, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d + 2 * n, betas, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) rc = fail(MHX_ERR_HIP, "uploading weighted parameters failed: %s", hipGetErrorString(e));
+        if (rc == MHX_OK) rc = mhx::launch_wgen_transpose(g, d, d + n, d + 2 * n);
+        if (rc == MHX_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
+            rc = fail(MHX_ERR_HIP, "weighted parameter transpose failed");
+    }
+    if (rc != MHX_OK) {
+        (void)hipFree(g->d_params);
+        delete g;
+        return rc;
+    }
+    *out = g;
+    return MHX_OK;
+}
+
+int mhx_wgen_destroy(mhx_wgen *gen) {
+    if (!gen) return MHX_OK;
+    (void)hipSetDevice(gen->ctx->device);
+    (void)hipStreamSynchronize(gen->ctx->stream);
+    (void)hipFree(gen->d_params);
+    delete gen;
+    return MHX_OK;
+}
+
+int mhx_weighted_minhash_many_dev(mhx_wgen *gen, const int64_t *d_indptr, const int32_t *d_indices,
+                                  const float *d_values, int values_are_logs, int64_t n_rows,
+                                  int64_t nnz, int64_t *d_out, uint8_t *d_nonempty) {
+    if (!gen) return fail(MHX_ERR_INVALID, "gen is NULL");
+    MHX_REQUIRE(n_rows >= 0 && nnz >= 0, "bad shape");
+    if (n_rows == 0) return MHX_OK;
+    MHX_REQUIRE(d_indptr && d_out && d_nonempty, "NULL device pointer");
+    MHX_REQUIRE((d_indices && d_values) || nnz == 0, "NULL device pointer");
+    if (int rc = gen->ctx->activate()) return rc;
+    return mhx::launch_weighted(gen, d_indptr, d_indices, d_values, values_are_logs, n_rows, nnz, d_out,
+                                d_nonempty);
+}
+
+int mhx_weighted_minhash_many(mhx_wgen *gen, const int64_t *indptr, const int32_t *indices,
+                              const float *values, int values_are_logs, int64_t n_rows, int64_t *out,
+                              uint8_t *nonempty) {
+    if (!gen) return fail(MHX_ERR_INVALID, "gen is NULL");
+    MHX_REQUIRE(n_rows >= 0, "bad shape");
+    if (n_rows == 0) return MHX_OK;
+    MHX_REQUIRE(indptr && out && nonempty, "NULL host pointer");
+    mhx_ctx *ctx = gen->ctx;
+    if (int rc = ctx->activate()) return rc;
+    for (int64_t i = 0; i < n_rows; ++i)
+        MHX_REQUIRE(indptr[i + 1] >= indptr[i], "indptr must be non-decreasing (row %lld)", (long long)i);
+    MHX_REQUIRE(indptr[0] == 0, "indptr[0] must be 0");
+    const int64_t nnz = indptr[n_rows];
+    MHX_REQUIRE((indices && values) || nnz == 0, "NULL host pointer");
+    for (int64_t j = 0; j < nnz; ++j)
+        MHX_REQUIRE(indices[j] >= 0 && indices[j] < gen->dim, "column index %d out of range [0,%d)", indices[j], gen->dim);
+    const size_t ptr_bytes = sizeof(int64_t) * (size_t)(n_rows + 1);
+    const size_t idx_bytes = ((sizeof(int32_t) * (size_t)nnz) + 255) & ~(size_t)255;
+    const size_t val_bytes = sizeof(float) * (size_t)nnz;
+    const size_t out_bytes = sizeof(int64_t) * 2 * (size_t)gen->sample_size * (size_t)n_rows;
+    const size_t ne_off = (out_bytes + 255) & ~(size_t)255;
+    if (int rc = ctx->ensure_scratch(0, idx_bytes + val_bytes + 256)) return rc;
+    if (int rc = ctx->ensure_scratch(1, ptr_bytes)) return rc;
+    if (int rc = ctx->ensure_scratch(2, ne_off + (size_t)n_rows)) return rc;
+    int32_t *d_idx = (int32_t *)ctx->scratch[0];
+    float *d_val = (float *)((char *)ctx->scratch[0] + idx_bytes);
+    int64_t *d_ptr = (int64_t *)ctx->scratch[1];
+    int64_t *d_out = (int64_t *)ctx->scratch[2];
+    uint8_t *d_ne = (uint8_t *)ctx->scratch[2] + ne_off;
+    MHX_HIP_CHECK(hipMemcpyAsync(d_ptr, indptr, ptr_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (nnz) {
+        MHX_HIP_CHECK(hipMemcpyAsync(d_idx, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice, ctx->stream));
+        MHX_HIP_CHECK(hipMemcpyAsync(d_val, values, val_bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (int rc = mhx::launch_weighted(gen, d_ptr, d_idx, d_val, values_are_logs, n_rows, nnz, d_out, d_ne))
+        return rc;
+    MHX_HIP_CHECK(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipMemcpyAsync(nonempty, d_ne, (size_t)n_rows, hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MHX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+// mhx_internal.h -- shared plumbing of libmhx (context, error reporting, launch helpers).
+// Product code: nothing here may reference oracle/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <unordered_map>
+
+#include "mhx.h"
+
+namespace mhx {
+
+// thread-local last-error string (mhx_last_error)
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+
+#define MHX_HIP_CHECK(expr)                                                                      \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            return ::mhx::fail(_e == hipErrorOutOfMemory ? MHX_ERR_OOM : MHX_ERR_HIP,            \
+                               "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                               __LINE__);                                                        \
+        }                                                                                        \
+    } while (0)
+
+#define MHX_REQUIRE(cond, ...)                                       \
+    do {                                                             \
+        if (!(cond)) return ::mhx::fail(MHX_ERR_INVALID, __VA_ARGS__); \
+    } while (0)
+
+}  // namespace mhx
+
+// Opaque handle layouts (C linkage names are declared in mhx.h).
+struct mhx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int num_cus = 0;
+    int64_t hbm_bytes = 0;
+    char name[128] = {0};
+    // grow-only scratch used by the host entry points (device staging of inputs/outputs)
+    void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    // options (mhx_ctx_set_option)
+    int64_t opt_minhash_path = 0;   // 0 auto, 1 exact fold everywhere, 2 fast fold (+exact redo)
+    int64_t opt_minhash_split = 0;  // 0 auto, 1 force wave-per-set, 2 force split-sets (atomic combine)
+    int64_t opt_blocks_per_cu = 0;  // 0 auto
+    int64_t opt_weighted_rows = 0;  // 0 auto: rows per workgroup tile in the weighted kernel
+
+    int ensure_scratch(int slot, size_t bytes);
+    int activate() const;
+};
+
+struct mhx_perm {
+    mhx_ctx *ctx = nullptr;
+    int32_t num_perm = 0;
+    uint64_t *d_a = nullptr;  // [K]
+    uint64_t *d_b = nullptr;  // [K]
+};
+
+struct mhx_wgen {
+    mhx_ctx *ctx = nullptr;
+    int32_t sample_size = 0;
+    int32_t dim = 0;
+    // parameters transposed to [dim][3][S_pad] (r, ln_c, beta) so that one column's samples are
+    // contiguous across lanes
+    float *d_params = nullptr;
+    int32_t s_pad = 0;
+};
+
+struct mhx_event {
+    mhx_ctx *ctx = nullptr;
+    hipEvent_t ev = nullptr;
+};
+
+namespace mhx {
+
+// kernels' host-side launchers (defined in the .hip files)
+int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const int64_t *d_offsets,
+                        int64_t fixed_len, int64_t n_sets, int64_t total_tokens,
+                        const uint64_t *d_init, int64_t init_stride, void *d_out, int out_dtype);
+int launch_minhash_merge(mhx_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y, int64_t count,
+                         uint64_t *d_out);
+int launch_weighted(mhx_wgen *gen, const int64_t *d_indptr, const int32_t *d_indices,
+                    const float *d_values, int values_are_logs, int64_t n_rows, int64_t nnz,
+                    int64_t *d_out, uint8_t *d_nonempty);
+int launch_wgen_transpose(mhx_wgen *gen, const float *d_rs, const float *d_lncs, const float *d_betas);
+int launch_bbit_pack(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t b,
+                     uint64_t *d_out);
+int launch_band_keys(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands,
+                     int32_t r, uint64_t *d_out);
+int launch_lean_serialize(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int64_t seed,
+                          uint8_t *d_out);
+
+int bbit_slot_size(int b);
+
+}  // namespace mhx

@@ -1,0 +1,477 @@
+// minhash_kernels.hip -- bulk MinHash signatures for gfx950 (MI355X), hand-written HIP.
+//
+// What is computed (reference: datasketch/minhash.py:293-297 inside the per-set loop of
+// :491-522):   out[i,k] = min(init[i,k], min_t fold((hv[t]*a[k] + b[k]) mod 2^64))
+// with fold(s) = (s mod (2^61-1)) & 0xFFFFFFFF.  numpy evaluates hv*a+b in uint64, so the
+// 2^64 wrap is part of the function and is reproduced here.
+//
+// Design (see DESIGN.md "MinHash kernel"):
+//   * permutations on lanes: lane l of a wave keeps (a,b) of P permutations in VGPRs for the
+//     whole kernel; one wave walks one set; the running minima stay in registers, so there is
+//     no cross-lane reduction at all and the [K] row is stored fully coalesced.
+//   * tokens are wave-uniform: they are fetched with scalar loads (s_load_dwordx16 = 8 uint64
+//     tokens) into SGPRs and feed v_mad_u64_u32 directly as the scalar operand; the next chunk
+//     is prefetched while the current one is being hashed.
+//   * per (token, permutation) pair the work is integer VALU: two 32x32 multiplies
+//     (v_mad_u64_u32 + v_mul_lo_u32) and the Mersenne fold.  The common case uses a 3-op fold
+//     whose rare failure (probability 2^-29 per pair) is detected for free from the final
+//     minima; such a set is recomputed with the exact fold, so results are always bit-exact.
+//   * sets with few, long token lists (update_batch on one MinHash) are split over many waves
+//     and combined with 64-bit atomic min.
+// The kernel is VALU-bound (about 190 integer ops per input byte), not HBM-bound.
+#include "mhx_internal.h"
+
+namespace mhx {
+namespace {
+
+constexpr uint64_t kMersenne = (1ull << 61) - 1;  // datasketch/minhash.py:30
+constexpr uint32_t kMaxHash = 0xFFFFFFFFu;        // datasketch/minhash.py:31
+constexpr int kWave = 64;
+
+struct BulkArgs {
+    const void *hv;          // tokens (uint64 or uint32)
+    const int64_t *offsets;  // CSR or nullptr
+    int64_t fixed_len;
+    int64_t n_sets;
+    const uint64_t *a;
+    const uint64_t *b;
+    int32_t num_perm;
+    int32_t force_exact;
+    const uint64_t *init;
+    int64_t init_stride;
+    void *out;
+};
+
+// ---- per-pair arithmetic ------------------------------------------------------------------
+// s = (h*a + b) mod 2^64, h < 2^32:   low 64 bits of h*a_lo + b, plus (h*a_hi mod 2^32) << 32
+__device__ __forceinline__ void mad_narrow(uint32_t h, uint32_t a_lo, uint32_t a_hi, uint64_t b,
+                                           uint32_t &s_lo, uint32_t &s_hi) {
+    const uint64_t s0 = (uint64_t)h * a_lo + b;  // v_mad_u64_u32 (wraps mod 2^64 like numpy)
+    s_lo = (uint32_t)s0;
+    s_hi = (uint32_t)(s0 >> 32) + h * a_hi;  // v_mul_lo_u32 + v_add_u32
+}
+
+// general uint64 token (sha1_hash64, identity on big ints): one more 32-bit multiply
+__device__ __forceinline__ void mad_wide(uint32_t h_lo, uint32_t h_hi, uint32_t a_lo, uint32_t a_hi,
+                                         uint64_t b, uint32_t &s_lo, uint32_t &s_hi) {
+    const uint64_t s0 = (uint64_t)h_lo * a_lo + b;
+    s_lo = (uint32_t)s0;
+    s_hi = (uint32_t)(s0 >> 32) + h_lo * a_hi + h_hi * a_lo;
+}
+
+// Exact fold: (s mod p) & 0xFFFFFFFF for p = 2^61-1.
+//   s = top*2^61 + low  ==  top + low (mod p), and top + low < 2p, so
+//   s mod p = y - p*[y >= p] with y = low + top;  -p == +1 (mod 2^32).
+__device__ __forceinline__ uint32_t fold_exact(uint32_t s_lo, uint32_t s_hi) {
+    const uint32_t top = s_hi >> 29;
+    const uint64_t y = ((((uint64_t)(s_hi & 0x1FFFFFFFu)) << 32) | s_lo) + top;
+    return (uint32_t)y + (y >= kMersenne ? 1u : 0u);
+}
+
+// Fast fold: u' = s_lo + top + 1 (mod 2^32).  Whenever u' >= 8 there was no carry out of
+// s_lo + top + 1, hence y < p and fold_exact == u' - 1.  u' in [0,7] is the only way the exact
+// result can differ (or the order of the minima can change), so a set whose final minimum of
+// u' is <= 7 for some permutation is recomputed with fold_exact.
+__device__ __forceinline__ uint32_t fold_fast(uint32_t s_lo, uint32_t s_hi) {
+    return s_lo + (s_hi >> 29) + 1u;
+}
+
+template <bool EXACT>
+__device__ __forceinline__ uint32_t fold(uint32_t s_lo, uint32_t s_hi) {
+    return EXACT ? fold_exact(s_lo, s_hi) : fold_fast(s_lo, s_hi);
+}
+
+template <int P>
+struct Perms {
+    uint32_t a_lo[P], a_hi[P];
+    uint64_t b[P];
+};
+
+// ---- token chunks in SGPRs ----------------------------------------------------------------
+// Tokens are read through the constant address space: a wave-uniform load from it is always
+// selected as a scalar load (s_load_dwordxN -> SGPRs, scalar cache), which costs no VALU issue
+// and lets the token feed v_mad_u64_u32 as its scalar operand.  The corpus is read-only for the
+// whole launch, which is what the scalar cache requires.
+#define MHX_CONST_AS __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const T MHX_CONST_AS *as_const(const T *p) {
+    return (const T MHX_CONST_AS *)p;  // NOLINT: address-space cast
+}
+
+template <typename TokT>
+struct Chunk;
+template <>
+struct Chunk<uint64_t> {
+    static constexpr int N = 8;  // 64 B = one s_load_dwordx16
+    uint64_t v[N];
+    __device__ __forceinline__ void load(const uint64_t MHX_CONST_AS *p) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = p[i];
+    }
+    __device__ __forceinline__ uint32_t or_hi() const {
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) o |= (uint32_t)(v[i] >> 32);
+        return o;
+    }
+    __device__ __forceinline__ uint32_t lo(int i) const { return (uint32_t)v[i]; }
+    __device__ __forceinline__ uint32_t hi(int i) const { return (uint32_t)(v[i] >> 32); }
+};
+template <>
+struct Chunk<uint32_t> {
+    static constexpr int N = 16;
+    uint32_t v[N];
+    __device__ __forceinline__ void load(const uint32_t MHX_CONST_AS *p) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) v[i] = p[i];
+    }
+    __device__ __forceinline__ uint32_t or_hi() const { return 0; }
+    __device__ __forceinline__ uint32_t lo(int i) const { return v[i]; }
+    __device__ __forceinline__ uint32_t hi(int) const { return 0; }
+};
+
+template <int P, bool EXACT, bool WIDE, typename TokT>
+__device__ __forceinline__ void hash_chunk(const Chunk<TokT> &c, const Perms<P> &pm,
+                                           uint32_t (&acc)[P]) {
+    constexpr int N = Chunk<TokT>::N;
+    if (!WIDE) {
+#pragma unroll
+        for (int i = 0; i < N; i += 4) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                uint32_t f[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    uint32_t lo, hi;
+                    mad_narrow(c.lo(i + j), pm.a_lo[p], pm.a_hi[p], pm.b[p], lo, hi);
+                    f[j] = fold<EXACT>(lo, hi);
+                }
+                acc[p] = min(min(acc[p], f[3]), min(min(f[0], f[1]), f[2]));  // 2 x v_min3_u32
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                uint32_t l0, h0;
+                mad_wide(c.lo(i), c.hi(i), pm.a_lo[p], pm.a_hi[p], pm.b[p], l0, h0);
+                acc[p] = min(acc[p], fold<EXACT>(l0, h0));
+            }
+        }
+    }
+}
+
+// Hash tokens [beg, end) of one set into acc (fold<EXACT> space).  All arguments wave-uniform.
+// Two loops: the narrow one (every token < 2^32: two multiplies per pair) runs until a chunk with
+// a wider token shows up, the wide one (three multiplies) finishes the set.  Keeping them apart
+// keeps the hot loop free of branches.  Each iteration issues the scalar load of the NEXT chunk
+// first and only then hashes the current one; the s_waitcnt for the prefetched SGPRs therefore
+// sits a whole chunk of VALU work (about 100 instructions) after the s_load.
+template <int P, bool EXACT, typename TokT>
+__device__ __forceinline__ void hash_range(const TokT MHX_CONST_AS *hv, int64_t beg, int64_t end,
+                                           const Perms<P> &pm, uint32_t (&acc)[P]) {
+    constexpr int N = Chunk<TokT>::N;
+    const TokT MHX_CONST_AS *p = hv + beg;
+    const int64_t n = end - beg;
+    const int nfull = (int)(n / N);  // launcher keeps per-wave ranges far below 2^31 chunks
+    if (nfull > 0) {
+        Chunk<TokT> cur;
+        cur.load(p);
+        int i = 0;
+        bool wide = false;
+        for (;;) {  // narrow loop
+            if (cur.or_hi() != 0) {
+                wide = true;
+                break;
+            }
+            const bool more = i + 1 < nfull;
+            Chunk<TokT> nxt;
+            nxt.load(p + (int64_t)(more ? i + 1 : i) * N);  // clamped: no branch around the load
+            __builtin_amdgcn_sched_barrier(0);              // keep the prefetch ahead of the math
+            hash_chunk<P, EXACT, false, TokT>(cur, pm, acc);
+            cur = nxt;
+            ++i;
+            if (!more) break;
+        }
+        if (wide) {
+            for (;;) {
+                const bool more = i + 1 < nfull;
+                Chunk<TokT> nxt;
+                nxt.load(p + (int64_t)(more ? i + 1 : i) * N);
+                __builtin_amdgcn_sched_barrier(0);
+                hash_chunk<P, EXACT, true, TokT>(cur, pm, acc);
+                cur = nxt;
+                ++i;
+                if (!more) break;
+            }
+        }
+    }
+    for (int64_t t = (int64_t)nfull * N; t < n; ++t) {  // ragged tail, one token at a time
+        const uint64_t tok = p[t];
+        const uint32_t lo = (uint32_t)tok, hi = (uint32_t)(tok >> 32);
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            uint32_t l0, h0;
+            mad_wide(lo, hi, pm.a_lo[q], pm.a_hi[q], pm.b[q], l0, h0);
+            acc[q] = min(acc[q], fold<EXACT>(l0, h0));
+        }
+    }
+}
+
+// min over tokens [beg,end) of the exact fold, for the P permutations of this lane.
+// Fast fold first; recompute exactly iff some lane's minimum lands in the ambiguous zone.
+template <int P, typename TokT>
+__device__ __forceinline__ void set_minima(const TokT MHX_CONST_AS *hv, int64_t beg, int64_t end,
+                                           const Perms<P> &pm, bool force_exact, uint32_t (&res)[P]) {
+    bool redo = force_exact;
+    if (!force_exact) {
+        uint32_t acc[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[p] = kMaxHash;
+        hash_range<P, false, TokT>(hv, beg, end, pm, acc);
+        bool suspicious = false;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            suspicious |= acc[p] <= 7u;
+            res[p] = acc[p] - 1u;
+        }
+        redo = __any(suspicious);
+    }
+    if (redo) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) res[p] = kMaxHash;
+        hash_range<P, true, TokT>(hv, beg, end, pm, res);
+    }
+}
+
+template <int P>
+__device__ __forceinline__ void load_perms(const BulkArgs &args, int kbase, int lane, Perms<P> &pm,
+                                           int (&kidx)[P]) {
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int k = kbase + p * kWave + lane;
+        kidx[p] = k < args.num_perm ? k : -1;
+        const uint64_t a = kidx[p] >= 0 ? args.a[k] : 0;
+        pm.a_lo[p] = (uint32_t)a;
+        pm.a_hi[p] = (uint32_t)(a >> 32);
+        pm.b[p] = kidx[p] >= 0 ? args.b[k] : 0;
+    }
+}
+
+// ---- kernel A: one wave per set -------------------------------------------------------------
+// grid.x strides over sets, grid.y = permutation chunk (64*P permutations each).
+template <int P, typename TokT, typename OutT>
+__global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int waves_per_block = blockDim.x >> 6;
+    Perms<P> pm;
+    int kidx[P];
+    load_perms<P>(args, blockIdx.y * (kWave * P), lane, pm, kidx);
+
+    const TokT MHX_CONST_AS *hv = as_const(static_cast<const TokT *>(args.hv));
+    const int64_t MHX_CONST_AS *offsets = as_const(args.offsets);
+    OutT *__restrict__ out = static_cast<OutT *>(args.out);
+    const int64_t stride = (int64_t)gridDim.x * waves_per_block;
+    for (int64_t set = (int64_t)blockIdx.x * waves_per_block + wave; set < args.n_sets; set += stride) {
+        int64_t beg, end;
+        if (args.offsets) {
+            beg = offsets[set];
+            end = offsets[set + 1];
+        } else {
+            beg = set * args.fixed_len;
+            end = beg + args.fixed_len;
+        }
+        uint32_t res[P];
+        if (end > beg) set_minima<P, TokT>(hv, beg, end, pm, args.force_exact != 0, res);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if (kidx[p] < 0) continue;
+            uint64_t v;
+            if (args.init) {
+                const uint64_t iv = args.init[set * args.init_stride + kidx[p]];
+                if (end > beg) {
+                    const uint32_t ic = (iv >> 32) ? kMaxHash : (uint32_t)iv;
+                    v = min(ic, res[p]);
+                } else {
+                    v = iv;  // empty set: state untouched (minhash.py:265-266)
+                }
+            } else {
+                v = end > beg ? res[p] : kMaxHash;
+            }
+            if (sizeof(OutT) == 4) v = v > kMaxHash ? kMaxHash : v;
+            out[set * args.num_perm + kidx[p]] = (OutT)v;
+        }
+    }
+}
+
+// ---- kernel B: few long sets, split over waves, combined with atomic min ---------------------
+// out must already hold the initial state (init or 2^32-1).  grid.x = token slices of `slice`
+// tokens over the flat token array; a slice may span several sets.
+template <typename OutT>
+__global__ void minhash_fill_state_kernel(const BulkArgs args) {
+    const int64_t total = args.n_sets * (int64_t)args.num_perm;
+    OutT *__restrict__ out = static_cast<OutT *>(args.out);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        uint64_t v = kMaxHash;
+        if (args.init) {
+            const int64_t set = i / args.num_perm;
+            v = args.init[set * args.init_stride + (i - set * args.num_perm)];
+        }
+        if (sizeof(OutT) == 4) v = v > kMaxHash ? kMaxHash : v;
+        out[i] = (OutT)v;
+    }
+}
+
+template <int P, typename TokT, typename OutT>
+__global__ __launch_bounds__(256) void minhash_split_kernel(const BulkArgs args, int64_t total_tokens,
+                                                            int64_t slice) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int waves_per_block = blockDim.x >> 6;
+    Perms<P> pm;
+    int kidx[P];
+    load_perms<P>(args, blockIdx.y * (kWave * P), lane, pm, kidx);
+    const TokT MHX_CONST_AS *hv = as_const(static_cast<const TokT *>(args.hv));
+    const int64_t MHX_CONST_AS *offsets = as_const(args.offsets);
+    OutT *__restrict__ out = static_cast<OutT *>(args.out);
+
+    const int64_t n_slices = (total_tokens + slice - 1) / slice;
+    const int64_t stride = (int64_t)gridDim.x * waves_per_block;
+    for (int64_t s = (int64_t)blockIdx.x * waves_per_block + wave; s < n_slices; s += stride) {
+        const int64_t s_beg = s * slice;
+        const int64_t s_end = min(s_beg + slice, total_tokens);
+        // first set whose range intersects [s_beg, s_end): largest i with start(i) <= s_beg
+        int64_t set;
+        if (args.offsets) {
+            int64_t lo = 0, hi = args.n_sets;  // invariant: offsets[lo] <= s_beg < offsets[hi]
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (offsets[mid] <= s_beg) lo = mid; else hi = mid;
+            }
+            set = lo;
+        } else {
+            set = s_beg / args.fixed_len;
+        }
+        for (; set < args.n_sets; ++set) {
+            const int64_t set_beg = args.offsets ? offsets[set] : set * args.fixed_len;
+            const int64_t set_end = args.offsets ? offsets[set + 1] : set_beg + args.fixed_len;
+            if (set_beg >= s_end) break;
+            const int64_t beg = max(set_beg, s_beg), end = min(set_end, s_end);
+            if (end <= beg) continue;
+            uint32_t res[P];
+            set_minima<P, TokT>(hv, beg, end, pm, args.force_exact != 0, res);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                if (kidx[p] < 0) continue;
+                OutT *dst = out + set * args.num_perm + kidx[p];
+                if (sizeof(OutT) == 8)
+                    atomicMin(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)res[p]);
+                else
+                    atomicMin(reinterpret_cast<unsigned int *>(dst), res[p]);
+            }
+        }
+    }
+}
+
+__global__ void minhash_merge_kernel(const uint64_t *__restrict__ x, const uint64_t *__restrict__ y,
+                                     int64_t count, uint64_t *__restrict__ out) {
+    // 16 B per lane per access; HBM-bound elementwise min (minhash.py:359)
+    const int64_t n2 = count >> 1;
+    const ulonglong2 *x2 = reinterpret_cast<const ulonglong2 *>(x);
+    const ulonglong2 *y2 = reinterpret_cast<const ulonglong2 *>(y);
+    ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(out);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const ulonglong2 xa = x2[i], ya = y2[i];
+        ulonglong2 r;
+        r.x = xa.x < ya.x ? xa.x : ya.x;
+        r.y = xa.y < ya.y ? xa.y : ya.y;
+        o2[i] = r;
+    }
+    if ((count & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+        out[count - 1] = x[count - 1] < y[count - 1] ? x[count - 1] : y[count - 1];
+}
+
+template <int P, typename TokT, typename OutT>
+int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t total_tokens, bool split) {
+    const int kchunks = (args.num_perm + kWave * P - 1) / (kWave * P);
+    const int blocks_per_cu = ctx->opt_blocks_per_cu > 0 ? (int)ctx->opt_blocks_per_cu : 8;
+    const int64_t max_blocks = (int64_t)ctx->num_cus * blocks_per_cu;
+    if (!split) {
+        const int64_t want = (args.n_sets + 3) / 4;
+        dim3 grid((unsigned)std::max<int64_t>(1, std::min(want, max_blocks)), (unsigned)kchunks);
+        hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT>), grid, dim3(256), 0, ctx->stream, args);
+    } else {
+        const int64_t total_out = args.n_sets * (int64_t)args.num_perm;
+        const int64_t fill_blocks = std::max<int64_t>(1, std::min<int64_t>((total_out + 255) / 256, max_blocks));
+        hipLaunchKernelGGL((minhash_fill_state_kernel<OutT>), dim3((unsigned)fill_blocks), dim3(256), 0,
+                           ctx->stream, args);
+        // slice length: enough slices to fill the chip, but at least 64 tokens per slice
+        const int64_t waves = max_blocks * 4;
+        int64_t slice = (total_tokens + waves - 1) / waves;
+        slice = std::max<int64_t>(64, (slice + 15) / 16 * 16);
+        const int64_t n_slices = (total_tokens + slice - 1) / slice;
+        const int64_t want = (n_slices + 3) / 4;
+        dim3 grid((unsigned)std::max<int64_t>(1, std::min(want, max_blocks)), (unsigned)kchunks);
+        hipLaunchKernelGGL((minhash_split_kernel<P, TokT, OutT>), grid, dim3(256), 0, ctx->stream, args,
+                           total_tokens, slice);
+    }
+    MHX_HIP_CHECK(hipGetLastError());
+    return MHX_OK;
+}
+
+template <typename TokT, typename OutT>
+int launch_p(mhx_ctx *ctx, const BulkArgs &args, int64_t total_tokens, bool split) {
+    const int k = args.num_perm;
+    if (k <= 64) return launch_typed<1, TokT, OutT>(ctx, args, total_tokens, split);
+    if (k <= 128) return launch_typed<2, TokT, OutT>(ctx, args, total_tokens, split);
+    if (k <= 256 || (k > 512 && k <= 768)) return launch_typed<4, TokT, OutT>(ctx, args, total_tokens, split);
+    return launch_typed<8, TokT, OutT>(ctx, args, total_tokens, split);
+}
+
+}  // namespace
+
+int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const int64_t *d_offsets,
+                        int64_t fixed_len, int64_t n_sets, int64_t total_tokens,
+                        const uint64_t *d_init, int64_t init_stride, void *d_out, int out_dtype) {
+    mhx_ctx *ctx = perm->ctx;
+    if (n_sets == 0) return MHX_OK;
+    BulkArgs args;
+    args.hv = d_hv;
+    args.offsets = d_offsets;
+    args.fixed_len = fixed_len;
+    args.n_sets = n_sets;
+    args.a = perm->d_a;
+    args.b = perm->d_b;
+    args.num_perm = perm->num_perm;
+    args.force_exact = ctx->opt_minhash_path == 1;
+    args.init = d_init;
+    args.init_stride = init_stride;
+    args.out = d_out;
+    // Few sets with long token lists: split sets over waves (atomic combine); else wave per set.
+    const int64_t waves_avail = (int64_t)ctx->num_cus * 16;
+    bool split = n_sets < waves_avail && total_tokens > n_sets * 128 && total_tokens >= 1024;
+    if (ctx->opt_minhash_split == 1) split = false;
+    if (ctx->opt_minhash_split == 2) split = total_tokens > 0;
+    if (hv_dtype == MHX_U64 && out_dtype == MHX_U64) return launch_p<uint64_t, uint64_t>(ctx, args, total_tokens, split);
+    if (hv_dtype == MHX_U64 && out_dtype == MHX_U32) return launch_p<uint64_t, uint32_t>(ctx, args, total_tokens, split);
+    if (hv_dtype == MHX_U32 && out_dtype == MHX_U64) return launch_p<uint32_t, uint64_t>(ctx, args, total_tokens, split);
+    if (hv_dtype == MHX_U32 && out_dtype == MHX_U32) return launch_p<uint32_t, uint32_t>(ctx, args, total_tokens, split);
+    return fail(MHX_ERR_INVALID, "unknown hv_dtype/out_dtype (%d, %d)", hv_dtype, out_dtype);
+}
+
+int launch_minhash_merge(mhx_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y, int64_t count,
+                         uint64_t *d_out) {
+    if (count == 0) return MHX_OK;
+    const int64_t want = ((count >> 1) + 255) / 256;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * 8));
+    hipLaunchKernelGGL(minhash_merge_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_x, d_y,
+                       count, d_out);
+    MHX_HIP_CHECK(hipGetLastError());
+    return MHX_OK;
+}
+
+}  // namespace mhx

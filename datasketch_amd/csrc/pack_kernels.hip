@@ -1,0 +1,143 @@
+// pack_kernels.hip -- HBM-bound re-packing of signature matrices for downstream consumers:
+// b-bit packing (bBitMinHash), MinHashLSH band keys (byte-swapped copy) and the LeanMinHash
+// wire format.  One wave walks whole rows; lanes read consecutive uint64 values (coalesced).
+#include "mhx_internal.h"
+
+namespace mhx {
+namespace {
+
+constexpr int kWave = 64;
+
+// ---- b-bit packing --------------------------------------------------------------------------
+// ref: datasketch/b_bit_minhash.py:37-38 (mask to b bits), :82-97 (value j of a block of
+// n = 64/slot values sits at bit (n-1-j)*slot).  Lane l of a wave handles value kk0+l of a row;
+// the `per` lanes of one block OR their shifted contributions together with a butterfly of
+// DPP/shuffle steps and the first lane of the group stores the block.
+__global__ __launch_bounds__(256) void bbit_pack_kernel(const uint64_t *__restrict__ sig, int64_t n,
+                                                        int32_t k, int32_t b, int32_t slot,
+                                                        int32_t nb, uint64_t *__restrict__ out) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    const int per = 64 / slot;                    // values per block
+    const int j = lane & (per - 1);               // position inside the block
+    const int shift = (per - 1 - j) * slot;
+    const uint64_t mask = b >= 32 ? 0xFFFFFFFFull : ((1ull << b) - 1ull);
+    const int padded = nb * per;                  // row length rounded up to whole blocks
+    const int blocks_per_iter = kWave / per;      // blocks a wave finishes per 64 values
+    for (int64_t row = (int64_t)blockIdx.x * waves_per_block + wave; row < n;
+         row += (int64_t)gridDim.x * waves_per_block) {
+        const uint64_t *src = sig + row * k;
+        uint64_t *dst = out + row * nb;
+        for (int kk0 = 0; kk0 < padded; kk0 += kWave) {
+            const int kk = kk0 + lane;
+            uint64_t v = 0;
+            if (kk < k) v = ((uint64_t)(uint32_t)(src[kk] & mask)) << shift;
+            // OR-reduce across the `per` lanes of the block
+            for (int d = 1; d < per; d <<= 1) {
+                const uint32_t lo = __shfl_xor((uint32_t)v, d);
+                const uint32_t hi = __shfl_xor((uint32_t)(v >> 32), d);
+                v |= ((uint64_t)hi << 32) | lo;
+            }
+            const int blk = kk0 / per + lane / per;
+            if (j == 0 && blk < nb && lane / per < blocks_per_iter) dst[blk] = v;
+        }
+    }
+}
+
+// ---- band keys ------------------------------------------------------------------------------
+// ref: datasketch/lsh.py:537-538 (_byteswap) over hashranges (:199): out[i, c] = bswap64(sig[i, c])
+__global__ __launch_bounds__(256) void band_keys_kernel(const uint64_t *__restrict__ sig, int64_t n,
+                                                        int32_t k, int32_t w,
+                                                        uint64_t *__restrict__ out) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    for (int64_t row = (int64_t)blockIdx.x * waves_per_block + wave; row < n;
+         row += (int64_t)gridDim.x * waves_per_block) {
+        const uint64_t *src = sig + row * k;
+        uint64_t *dst = out + row * w;
+        for (int c = lane; c < w; c += kWave) dst[c] = __builtin_bswap64(src[c]);
+    }
+}
+
+// flat variant when the whole matrix is converted (w == k): 16 B per lane
+__global__ __launch_bounds__(256) void bswap_flat_kernel(const ulonglong2 *__restrict__ in, int64_t n2,
+                                                         ulonglong2 *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        ulonglong2 v = in[i];
+        v.x = __builtin_bswap64(v.x);
+        v.y = __builtin_bswap64(v.y);
+        out[i] = v;
+    }
+}
+
+// ---- LeanMinHash wire format ----------------------------------------------------------------
+// ref: datasketch/lean_minhash.py:174-175: struct "<qi{K}I" = seed(int64) K(int32) K x uint32.
+// A record is (3 + K) 32-bit words; records are only 4-byte aligned, so stores are dword-wide.
+__global__ __launch_bounds__(256) void lean_serialize_kernel(const uint64_t *__restrict__ sig, int64_t n,
+                                                             int32_t k, int64_t seed,
+                                                             uint32_t *__restrict__ out) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    const int rec = 3 + k;
+    for (int64_t row = (int64_t)blockIdx.x * waves_per_block + wave; row < n;
+         row += (int64_t)gridDim.x * waves_per_block) {
+        const uint64_t *src = sig + row * k;
+        uint32_t *dst = out + row * rec;
+        if (lane == 0) {
+            dst[0] = (uint32_t)seed;
+            dst[1] = (uint32_t)((uint64_t)seed >> 32);
+            dst[2] = (uint32_t)k;
+        }
+        for (int c = lane; c < k; c += kWave) dst[3 + c] = (uint32_t)src[c];
+    }
+}
+
+inline dim3 row_grid(mhx_ctx *ctx, int64_t n) {
+    const int64_t want = (n + 3) / 4;
+    return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * 8)));
+}
+
+}  // namespace
+
+int launch_bbit_pack(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t b,
+                     uint64_t *d_out) {
+    const int slot = bbit_slot_size(b);
+    const int per = 64 / slot;
+    const int nb = (k + per - 1) / per;
+    hipLaunchKernelGGL(bbit_pack_kernel, row_grid(ctx, n), dim3(256), 0, ctx->stream, d_sig, n, k, b, slot,
+                       nb, d_out);
+    MHX_HIP_CHECK(hipGetLastError());
+    return MHX_OK;
+}
+
+int launch_band_keys(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
+                     uint64_t *d_out) {
+    const int w = bands * r;
+    const int64_t total = n * (int64_t)k;
+    const bool aligned = (((uintptr_t)d_sig | (uintptr_t)d_out) & 15) == 0;
+    if (w == k && (total & 1) == 0 && aligned) {
+        const int64_t n2 = total >> 1;
+        const int64_t want = (n2 + 255) / 256;
+        dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * 8)));
+        hipLaunchKernelGGL(bswap_flat_kernel, grid, dim3(256), 0, ctx->stream, (const ulonglong2 *)d_sig, n2,
+                           (ulonglong2 *)d_out);
+    } else {
+        hipLaunchKernelGGL(band_keys_kernel, row_grid(ctx, n), dim3(256), 0, ctx->stream, d_sig, n, k, w, d_out);
+    }
+    MHX_HIP_CHECK(hipGetLastError());
+    return MHX_OK;
+}
+
+int launch_lean_serialize(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int64_t seed,
+                          uint8_t *d_out) {
+    hipLaunchKernelGGL(lean_serialize_kernel, row_grid(ctx, n), dim3(256), 0, ctx->stream, d_sig, n, k, seed,
+                       (uint32_t *)d_out);
+    MHX_HIP_CHECK(hipGetLastError());
+    return MHX_OK;
+}
+
+}  // namespace mhx

@@ -1,0 +1,92 @@
+"""Multi-GPU sharding of the bulk MinHash path: one process per GPU, corpus split by rows.
+
+The path is embarrassingly parallel over sets (every rank needs only the 2*K permutation
+parameters, regenerated from the seed), so the compute phase has NO collective.  The only
+exchange step is the optional assembly of the full ``[N, K]`` signature matrix on every rank
+(an all-gather of row shards) when one consumer -- e.g. ``MinHashLSH.insert`` -- needs it whole.
+
+``torch.distributed`` is used as plumbing only (rendezvous + the collective): backend ``nccl``
+is RCCL over xGMI on MI355X, ``gloo`` is the CPU stand-in used by the tests.  libmhx also has a
+torch-free RCCL binding (``mhx_comm_*`` in include/mhx.h) for deployments without PyTorch.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+
+def shard_rows(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous row block ``[begin, end)`` of rank ``rank``; sizes differ by at most one."""
+    if not (0 <= rank < world_size):
+        raise ValueError("rank out of range")
+    base, extra = divmod(int(n_rows), int(world_size))
+    begin = rank * base + min(rank, extra)
+    return begin, begin + base + (1 if rank < extra else 0)
+
+
+def shard_by_tokens(offsets: Sequence[int], world_size: int) -> List[Tuple[int, int]]:
+    """Contiguous row blocks balanced by token count (ragged corpora): block r ends at the first
+    row boundary at or after r/world of the total tokens.  Returns ``[(begin, end)] * world``."""
+    offsets = np.asarray(offsets, dtype=np.int64)
+    n = offsets.size - 1
+    total = int(offsets[-1] - offsets[0])
+    cuts = [0]
+    for r in range(1, world_size):
+        target = offsets[0] + (total * r) // world_size
+        cut = int(np.searchsorted(offsets, target, side="left"))
+        cuts.append(min(max(cut, cuts[-1]), n))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
+
+
+def allgather_signatures(local: np.ndarray, group=None, counts: Optional[Sequence[int]] = None) -> np.ndarray:
+    """Assemble the full signature matrix from per-rank row shards (host arrays in, host array out).
+
+    ``local`` is this rank's ``[n_r, K]`` uint64 shard.  Values are < 2**32, so shards travel as
+    uint32 (half the bytes on the wire) and are widened on arrival.  Unequal shard sizes are
+    padded to the largest (``counts`` = rows per rank; gathered first when not given).
+    """
+    import torch
+    import torch.distributed as dist
+
+    if not dist.is_initialized():
+        return np.asarray(local, dtype=np.uint64)
+    world = dist.get_world_size(group)
+    local = np.ascontiguousarray(local, dtype=np.uint64)
+    k = local.shape[1]
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    if counts is None:
+        c = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
+        all_c = torch.zeros(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(all_c, c, group=group)
+        counts = [int(x) for x in all_c.cpu().tolist()]
+    if np.any(local > np.uint64(0xFFFFFFFF)):
+        raise ValueError("signature values >= 2**32 cannot use the uint32 wire format")
+    width = max(counts) if counts else 0
+    send = np.zeros((width, k), dtype=np.int32)
+    send[: local.shape[0]] = local.astype(np.uint32).view(np.int32)
+    t_send = torch.from_numpy(send).to(dev)
+    t_recv = torch.empty((world * width, k), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(t_recv, t_send, group=group)
+    recv = t_recv.cpu().numpy().view(np.uint32).reshape(world, width, k)
+    parts = [recv[r, : counts[r]] for r in range(world)]
+    return np.concatenate(parts, axis=0).astype(np.uint64)
+
+
+def bulk_signatures_sharded(tokens, *, num_perm: int, seed: int = 1, gpu_mode: str = "always", group=None) -> np.ndarray:
+    """Config-3 shape: every rank hashes its row block of ``tokens`` (a dense ``[N, T]`` array of
+    pre-hashed tokens, identical on every rank) and the shards are all-gathered; every rank
+    returns the full ``[N, K]`` matrix."""
+    import torch.distributed as dist
+
+    from datasketch_amd.hashfunc import prehashed
+    from datasketch_amd.minhash import MinHash
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    begin, end = shard_rows(tokens.shape[0], world, rank)
+    local = MinHash.bulk_signatures(tokens[begin:end], num_perm=num_perm, seed=seed, hashfunc=prehashed, gpu_mode=gpu_mode)
+    counts = [shard_rows(tokens.shape[0], world, r) for r in range(world)]
+    return allgather_signatures(local, group=group, counts=[e - b for b, e in counts])

@@ -1,0 +1,354 @@
+"""MinHash with the reference's API (ekzhu/datasketch ``datasketch.MinHash``) and a HIP back end.
+
+Mirror of datasketch/minhash.py: same constructor, attributes, methods, validation and error
+behaviour, so an object of this class can be handed to MinHashLSH & co. (they read
+``.hashvalues``, ``.seed`` and ``len()`` only).  What differs is below the ``gpu_mode`` seam:
+
+* ``gpu_mode='always'`` / ``'detect'`` run the permutation + min step on an MI355X through
+  libmhx (``datasketch_amd/csrc``), replacing the reference's CuPy branch
+  (datasketch/minhash.py:281-291).  ``'always'`` raises ``RuntimeError`` when no device (or no
+  libmhx.so) is usable; ``'detect'`` uses the device when there is one.
+* ``bulk`` / ``generator`` hand the WHOLE corpus to one fused kernel instead of one call per
+  set, and ``bulk_signatures`` returns the ``[N, K]`` matrix without building N objects.
+* ``gpu_mode='disable'`` is the reference's numpy arithmetic (kept because it is part of the
+  API contract; it is not a fallback: nothing switches to it implicitly on a GPU host).
+
+Results are bit-identical to the reference in every mode, including numpy's uint64 wrap-around
+in ``(a*hv + b) % (2**61-1) & 0xFFFFFFFF``.
+"""
+from __future__ import annotations
+
+import copy
+import warnings
+from typing import Callable, Generator, Iterable, List, Optional, Tuple
+
+import numpy as np
+
+from datasketch_amd import _native
+from datasketch_amd.hashfunc import prehashed, sha1_hash32
+
+# The size of a hash value in number of bytes (reference: datasketch/minhash.py:27)
+hashvalue_byte_size = len(bytes(np.int64(42).data))
+
+_mersenne_prime = np.uint64((1 << 61) - 1)  # reference: datasketch/minhash.py:30
+_max_hash = np.uint64((1 << 32) - 1)  # :31
+_hash_range = 1 << 32  # :32
+
+_GPU_MODES = ("disable", "detect", "always")
+
+# sets per device launch in bulk/generator (bounds host staging memory, keeps generator lazy)
+_BULK_CHUNK_SETS = 1 << 16
+_BULK_CHUNK_TOKENS = 1 << 25
+
+
+def _gpu_available() -> bool:
+    """Reference: datasketch/minhash.py:38-48, with a HIP device count instead of CuPy's."""
+    return _native.gpu_available()
+
+
+def _no_device_error() -> RuntimeError:
+    # message kept compatible with datasketch/minhash.py:274
+    return RuntimeError("GPU mode 'always' requested but no HIP device (or libmhx.so) is available.")
+
+
+def _as_hash_array(values) -> np.ndarray:
+    """Same conversion the reference applies (minhash.py:294): raises OverflowError for values
+    outside uint64, TypeError/ValueError for non-integers."""
+    return np.array(values, dtype=np.uint64)
+
+
+class MinHash:
+    """MinHash sketch for Jaccard similarity; drop-in for ``datasketch.MinHash``.
+
+    Args:
+        num_perm: number of permutation functions (ignored when ``hashvalues`` is given).
+        seed: seed of the permutation functions.
+        gpu_mode: ``'disable'`` | ``'detect'`` | ``'always'`` (see module docstring).
+        hashfunc: callable mapping a token to an unsigned integer hash value (< 2**64).
+        hashobj: deprecated, as in the reference.
+        hashvalues: optional initial state.
+        permutations: optional ``(a, b)`` permutation parameters to reuse.
+    """
+
+    def __init__(
+        self,
+        num_perm: int = 128,
+        seed: int = 1,
+        gpu_mode: str = "disable",
+        hashfunc: Callable = sha1_hash32,
+        hashobj: Optional[object] = None,
+        hashvalues=None,
+        permutations=None,
+    ) -> None:
+        if hashvalues is not None:
+            num_perm = len(hashvalues)
+        if num_perm > _hash_range:
+            # reference: datasketch/minhash.py:125-132
+            raise ValueError("Cannot have more than %d number of permutation functions" % _hash_range)
+        self.seed = seed
+        self.num_perm = num_perm
+        if not callable(hashfunc):
+            raise ValueError("The hashfunc must be a callable.")
+        self.hashfunc = hashfunc
+        if hashobj is not None:
+            warnings.warn("hashobj is deprecated, use hashfunc instead.", DeprecationWarning, stacklevel=2)
+        if hashvalues is not None:
+            self.hashvalues = self._parse_hashvalues(hashvalues)
+        else:
+            self.hashvalues = self._init_hashvalues(num_perm)
+        if permutations is not None:
+            self.permutations = permutations
+        else:
+            self.permutations = self._init_permutations(num_perm)
+        if len(self) != len(self.permutations[0]):
+            raise ValueError("Numbers of hash values and permutations mismatch")
+        self._gpu_mode = gpu_mode
+
+    # ------------------------------------------------------------------ state helpers
+    def _init_hashvalues(self, num_perm: int) -> np.ndarray:
+        return np.full(num_perm, _max_hash, dtype=np.uint64)
+
+    def _init_permutations(self, num_perm: int) -> np.ndarray:
+        """(a_i, b_i) drawn alternately from the legacy ``RandomState(seed)`` stream, a in [1, p),
+        b in [0, p); same stream as datasketch/minhash.py:170-184 (kept on the host)."""
+        gen = np.random.RandomState(self.seed)
+        ab = np.empty((2, num_perm), dtype=np.uint64)
+        for i in range(num_perm):
+            ab[0, i] = gen.randint(1, _mersenne_prime, dtype=np.uint64)
+            ab[1, i] = gen.randint(0, _mersenne_prime, dtype=np.uint64)
+        return ab
+
+    def _parse_hashvalues(self, hashvalues) -> np.ndarray:
+        return np.array(hashvalues, dtype=np.uint64)
+
+    # ------------------------------------------------------------------ back-end selection
+    def _use_gpu(self) -> bool:
+        """The seam of datasketch/minhash.py:268-279."""
+        mode = self._gpu_mode
+        if mode == "always":
+            try:
+                ok = _gpu_available()
+            except _native.MhxError as e:
+                raise _no_device_error() from e
+            if not ok:
+                raise _no_device_error()
+            return True
+        if mode == "detect":
+            return _gpu_available()
+        return False
+
+    # ------------------------------------------------------------------ updates
+    def update(self, b) -> None:
+        """Add one token.  As in the reference (minhash.py:221-224) a single token is folded in
+        on the host: one K-vector of numpy arithmetic, no device round trip."""
+        hv = self.hashfunc(b)
+        a, c = self.permutations
+        phv = np.bitwise_and((a * hv + c) % _mersenne_prime, _max_hash)
+        self.hashvalues = np.minimum(phv, self.hashvalues)
+
+    def update_batch(self, b: Iterable) -> None:
+        """Add many tokens.  Hashing runs on the host (reference contract, minhash.py:262-263);
+        permutation + min run on the device for ``gpu_mode`` 'always' / 'detect'."""
+        if self.hashfunc is prehashed and isinstance(b, np.ndarray):
+            hv_list = b
+            if b.size == 0:
+                return
+        else:
+            hv_list = [self.hashfunc(_b) for _b in b]
+            if not hv_list:  # empty batch is a no-op (minhash.py:265-266)
+                return
+        if self._use_gpu():
+            hv = _as_hash_array(hv_list).reshape(-1)
+            self.hashvalues = _native.context().minhash_update_batch(self.permutations, hv, self.hashvalues)
+            return
+        a, c = self.permutations
+        hv = np.array(hv_list, dtype=np.uint64, ndmin=2).T
+        phv = np.bitwise_and((hv * a + c) % _mersenne_prime, _max_hash)
+        self.hashvalues = np.minimum(self.hashvalues, phv.min(axis=0))
+
+    # ------------------------------------------------------------------ estimators
+    def jaccard(self, other: "MinHash") -> float:
+        if other.seed != self.seed:
+            raise ValueError("Cannot compute Jaccard given MinHash with different seeds")
+        if len(self) != len(other):
+            raise ValueError("Cannot compute Jaccard given MinHash with different numbers of permutation functions")
+        return float(np.count_nonzero(self.hashvalues == other.hashvalues)) / float(len(self))
+
+    def count(self) -> float:
+        k = len(self)
+        return float(k) / np.sum(self.hashvalues / float(_max_hash)) - 1.0
+
+    def merge(self, other: "MinHash") -> None:
+        if other.seed != self.seed:
+            raise ValueError("Cannot merge MinHash with different seeds")
+        if len(self) != len(other):
+            raise ValueError("Cannot merge MinHash with different numbers of permutation functions")
+        self.hashvalues = np.minimum(other.hashvalues, self.hashvalues)
+
+    def digest(self) -> np.ndarray:
+        return copy.copy(self.hashvalues)
+
+    def is_empty(self) -> bool:
+        return not np.any(self.hashvalues != _max_hash)
+
+    def clear(self) -> None:
+        self.hashvalues = self._init_hashvalues(len(self))
+
+    def copy(self) -> "MinHash":
+        return MinHash(
+            seed=self.seed,
+            hashfunc=self.hashfunc,
+            hashvalues=self.digest(),
+            permutations=self.permutations,
+            gpu_mode=self._gpu_mode,
+        )
+
+    def __len__(self) -> int:
+        return len(self.hashvalues)
+
+    def __eq__(self, other) -> bool:
+        return type(self) is type(other) and self.seed == other.seed and np.array_equal(self.hashvalues, other.hashvalues)
+
+    __hash__ = None  # mutable, like the reference (defines __eq__ without __hash__)
+
+    @classmethod
+    def union(cls, *mhs: "MinHash") -> "MinHash":
+        if len(mhs) < 2:
+            raise ValueError("Cannot union less than 2 MinHash")
+        num_perm = len(mhs[0])
+        seed = mhs[0].seed
+        if any((seed != m.seed or num_perm != len(m)) for m in mhs):
+            raise ValueError("The unioning MinHash must have the same seed and number of permutation functions")
+        hashvalues = np.minimum.reduce([m.hashvalues for m in mhs])
+        return cls(
+            num_perm=num_perm,
+            seed=seed,
+            hashfunc=mhs[0].hashfunc,
+            hashvalues=hashvalues,
+            permutations=mhs[0].permutations,
+            gpu_mode=mhs[0]._gpu_mode,
+        )
+
+    # ------------------------------------------------------------------ bulk
+    def _spawn(self, hashvalues: np.ndarray) -> "MinHash":
+        """A sibling sharing seed / hashfunc / permutations / gpu_mode, without re-running
+        ``__init__`` (what ``copy()`` produces in datasketch/minhash.py:385-393, ~10x cheaper)."""
+        m = object.__new__(type(self))
+        m.seed = self.seed
+        m.num_perm = self.num_perm
+        m.hashfunc = self.hashfunc
+        m.hashvalues = hashvalues
+        m.permutations = self.permutations
+        m._gpu_mode = self._gpu_mode
+        return m
+
+    def _hash_sets(self, sets: List) -> Tuple[np.ndarray, np.ndarray]:
+        """Apply ``hashfunc`` per token on the host and pack the result as CSR (values, offsets)."""
+        offsets = np.zeros(len(sets) + 1, dtype=np.int64)
+        f = self.hashfunc
+        if f is prehashed:
+            parts = [_as_hash_array(s).reshape(-1) if not isinstance(s, np.ndarray) or s.dtype != np.uint64 else s.reshape(-1) for s in sets]
+        else:
+            parts = [_as_hash_array([f(t) for t in s]).reshape(-1) for s in sets]
+        for i, p in enumerate(parts):
+            offsets[i + 1] = offsets[i] + p.size
+        hv = np.concatenate(parts) if parts else np.empty(0, dtype=np.uint64)
+        return hv.astype(np.uint64, copy=False), offsets
+
+    def _bulk_chunks(self, b: Iterable) -> Generator[np.ndarray, None, None]:
+        """Yield ``[n_i, K]`` signature blocks for consecutive chunks of the corpus ``b``."""
+        init = None if self.is_empty() else self.hashvalues
+        if self.hashfunc is prehashed and isinstance(b, np.ndarray) and b.ndim == 2:
+            # dense corpus of fixed-length sets: no per-set Python work at all
+            tok = _as_hash_array(b) if b.dtype != np.uint64 else np.ascontiguousarray(b)
+            n, t = tok.shape
+            step = max(1, min(n, _BULK_CHUNK_TOKENS // max(t, 1)))
+            for s in range(0, n, step):
+                blk = tok[s : s + step]
+                yield self._signatures_csr(blk.reshape(-1), None, t, blk.shape[0], init)
+            return
+        if self.hashfunc is prehashed and isinstance(b, tuple) and len(b) == 2:
+            values, offsets = b
+            values = _as_hash_array(values).reshape(-1)
+            offsets = np.asarray(offsets, dtype=np.int64)
+            n = offsets.size - 1
+            s = 0
+            while s < n:
+                e = min(n, s + _BULK_CHUNK_SETS)
+                local = offsets[s : e + 1] - offsets[s]
+                yield self._signatures_csr(values[offsets[s] : offsets[e]], local, 0, e - s, init)
+                s = e
+            return
+        chunk: List = []
+        tokens = 0
+        for s in b:
+            s = s if hasattr(s, "__len__") else list(s)
+            chunk.append(s)
+            tokens += len(s)
+            if len(chunk) >= _BULK_CHUNK_SETS or tokens >= _BULK_CHUNK_TOKENS:
+                hv, offsets = self._hash_sets(chunk)
+                yield self._signatures_csr(hv, offsets, 0, len(chunk), init)
+                chunk, tokens = [], 0
+        if chunk:
+            hv, offsets = self._hash_sets(chunk)
+            yield self._signatures_csr(hv, offsets, 0, len(chunk), init)
+
+    def _signatures_csr(self, hv, offsets, fixed_len, n_sets, init) -> np.ndarray:
+        if self._use_gpu():
+            return _native.context().minhash_bulk(self.permutations, hv, offsets, fixed_len, n_sets, init)
+        # gpu_mode='disable': the reference's per-set numpy arithmetic (minhash.py:293-297)
+        a, c = self.permutations
+        k = len(a)
+        out = np.empty((n_sets, k), dtype=np.uint64)
+        proto = self._init_hashvalues(k) if init is None else np.asarray(init, dtype=np.uint64)
+        for i in range(n_sets):
+            beg, end = (offsets[i], offsets[i + 1]) if offsets is not None else (i * fixed_len, (i + 1) * fixed_len)
+            if end == beg:
+                out[i] = proto
+                continue
+            col = hv[beg:end].reshape(-1, 1)
+            phv = np.bitwise_and((col * a + c) % _mersenne_prime, _max_hash)
+            out[i] = np.minimum(proto, phv.min(axis=0))
+        return out
+
+    @classmethod
+    def bulk(cls, b: Iterable, **minhash_kwargs) -> List["MinHash"]:
+        """Compute one MinHash per element of ``b`` (reference: datasketch/minhash.py:464-489)."""
+        return list(cls.generator(b, **minhash_kwargs))
+
+    @classmethod
+    def generator(cls, b: Iterable, **minhash_kwargs) -> Generator["MinHash", None, None]:
+        """Lazily yield one MinHash per element of ``b`` (reference: datasketch/minhash.py:491-522).
+
+        With a device back end the corpus is consumed in chunks of up to 65 536 sets; each chunk
+        is one fused kernel launch.
+        """
+        m = cls(**minhash_kwargs)
+        for block in m._bulk_chunks(b):
+            for row in block:
+                yield m._spawn(row.copy())
+
+    @classmethod
+    def bulk_signatures(cls, b, **minhash_kwargs) -> np.ndarray:
+        """Not in the reference: the ``[N, K]`` uint64 signature matrix of a corpus, without
+        creating N Python objects.  ``b`` is any iterable of token iterables, or -- with
+        ``hashfunc=prehashed`` -- a 2-D integer array (fixed-length sets) or a ``(values, offsets)``
+        CSR pair of already hashed tokens."""
+        m = cls(**minhash_kwargs)
+        blocks = list(m._bulk_chunks(b))
+        if not blocks:
+            return np.empty((0, len(m)), dtype=np.uint64)
+        return blocks[0] if len(blocks) == 1 else np.concatenate(blocks, axis=0)
+
+    # ------------------------------------------------------------------ pickling
+    # State is plain numpy + the gpu_mode string: device handles live in the process-wide
+    # context (datasketch_amd._native), never in the object, so pickles are portable
+    # (the reference drops its CuPy arrays for the same reason, minhash.py:524-538).
+    def __getstate__(self):
+        return self.__dict__.copy()
+
+    def __setstate__(self, state):
+        state = dict(state)
+        state.pop("_a_gpu", None)  # tolerate pickles of the reference class layout
+        state.pop("_b_gpu", None)
+        self.__dict__.update(state)

@@ -1,0 +1,180 @@
+"""Weighted MinHash with the reference's API (datasketch/weighted_minhash.py) and a HIP back end.
+
+``WeightedMinHashGenerator`` draws its tables on the host from numpy's legacy RandomState
+(identical streams, identical float32 casts); ``minhash_many`` evaluates Ioffe's consistent
+weighted sampling for a whole matrix on the device when ``gpu_mode`` is 'always' / 'detect'.
+Parity: the natural log of the data is taken on the host with numpy (numpy's float32 log is not
+correctly rounded, so only the same binary reproduces it); everything downstream is IEEE
+float32 without FMA fusion on the device and yields bit-identical ``(k, t)`` pairs.
+"""
+from __future__ import annotations
+
+import collections.abc
+import copy
+from typing import List, Optional, Union
+
+import numpy as np
+import scipy.sparse as sparse
+
+from datasketch_amd import _native
+
+
+class WeightedMinHash:
+    """Value type: ``seed`` and ``hashvalues`` of shape (sample_size, 2) int64 = (k, t) pairs."""
+
+    def __init__(self, seed: int, hashvalues: np.ndarray) -> None:
+        self.seed = seed
+        self.hashvalues = hashvalues
+
+    def jaccard(self, other: "WeightedMinHash") -> float:
+        if other.seed != self.seed:
+            raise ValueError("Cannot compute Jaccard given WeightedMinHash objects with different seeds")
+        if len(self) != len(other):
+            raise ValueError("Cannot compute Jaccard given WeightedMinHash objects with different numbers of hash values")
+        same = np.all(np.asarray(self.hashvalues) == np.asarray(other.hashvalues), axis=1)
+        return float(np.count_nonzero(same)) / float(len(self))
+
+    def digest(self) -> np.ndarray:
+        return copy.copy(self.hashvalues)
+
+    def copy(self) -> "WeightedMinHash":
+        return WeightedMinHash(self.seed, self.digest())
+
+    def __len__(self) -> int:
+        return len(self.hashvalues)
+
+    def __eq__(self, other) -> bool:
+        return type(self) is type(other) and self.seed == other.seed and np.array_equal(self.hashvalues, other.hashvalues)
+
+    __hash__ = None
+
+
+class WeightedMinHashGenerator:
+    """Drop-in for ``datasketch.WeightedMinHashGenerator``.
+
+    Args:
+        dim: number of dimensions of the input vectors.
+        sample_size: number of samples.
+        seed: random seed.
+        gpu_mode: 'disable' (numpy, as the reference), 'detect' or 'always' (HIP); not in the
+            reference, which has no device path for the weighted sketch.
+        device_log: when True the device computes ``logf`` itself (fast mode, may differ from
+            numpy's float32 log in the last ulp); default False = parity mode.
+    """
+
+    def __init__(self, dim: int, sample_size: int = 128, seed: int = 1, gpu_mode: str = "disable", device_log: bool = False) -> None:
+        self.dim = dim
+        self.sample_size = sample_size
+        self.seed = seed
+        rng = np.random.RandomState(seed=seed)
+        # order of the draws and the float32 casts follow datasketch/weighted_minhash.py:118-121
+        self.rs = rng.gamma(2, 1, (sample_size, dim)).astype(np.float32)
+        self.ln_cs = np.log(rng.gamma(2, 1, (sample_size, dim))).astype(np.float32)
+        self.betas = rng.uniform(0, 1, (sample_size, dim)).astype(np.float32)
+        self._gpu_mode = gpu_mode
+        self._device_log = device_log
+        self._dev = None  # (Context, mhx_wgen handle); never pickled
+
+    # ------------------------------------------------------------------ device plumbing
+    def _use_gpu(self) -> bool:
+        if self._gpu_mode == "always":
+            try:
+                ok = _native.gpu_available()
+            except _native.MhxError as e:
+                raise RuntimeError("GPU mode 'always' requested but no HIP device (or libmhx.so) is available.") from e
+            if not ok:
+                raise RuntimeError("GPU mode 'always' requested but no HIP device (or libmhx.so) is available.")
+            return True
+        if self._gpu_mode == "detect":
+            return _native.gpu_available()
+        return False
+
+    def _device_handle(self):
+        ctx = _native.context()
+        if self._dev is None or self._dev[0] is not ctx:
+            self._dev = (ctx, ctx.wgen_create(self.rs, self.ln_cs, self.betas))
+        return self._dev
+
+    def __del__(self):
+        dev = getattr(self, "_dev", None)
+        if dev is not None:
+            try:
+                dev[0].wgen_destroy(dev[1])
+            except Exception:
+                pass
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_dev"] = None
+        return state
+
+    # ------------------------------------------------------------------ single vector
+    def minhash(self, v) -> WeightedMinHash:
+        """One vector, on the host (reference: weighted_minhash.py:123-159; note its formula
+        ``ln_a = ln_c - (t-beta)*r - r`` rounds differently from ``minhash_many``'s)."""
+        if not isinstance(v, collections.abc.Sized):
+            raise TypeError("Input vector must be sized")
+        if not len(v) == self.dim:
+            raise ValueError("Input dimension mismatch, expecting %d" % self.dim)
+        v = np.array(v, dtype=np.float32)  # always a private float32 copy
+        zeros = v == 0
+        if zeros.all():
+            raise ValueError("Input is all zeros")
+        v[zeros] = np.nan
+        vlog = np.log(v)
+        t = np.floor((vlog / self.rs) + self.betas)  # (S, dim), row i == the reference's loop body i
+        ln_y = (t - self.betas) * self.rs
+        ln_a = self.ln_cs - ln_y - self.rs
+        k = np.nanargmin(ln_a, axis=1)
+        hashvalues = np.zeros((self.sample_size, 2), dtype=int)
+        hashvalues[:, 0] = k
+        hashvalues[:, 1] = t[np.arange(self.sample_size), k].astype(int)
+        return WeightedMinHash(self.seed, hashvalues)
+
+    # ------------------------------------------------------------------ matrix
+    def minhash_many(self, X) -> List[Optional[WeightedMinHash]]:
+        """One WeightedMinHash per row of ``X`` (dense ndarray or scipy sparse matrix); rows
+        without non-zero entries give ``None`` (reference: weighted_minhash.py:161-247)."""
+        if not isinstance(X, (sparse.spmatrix, np.ndarray)):
+            raise TypeError("Input X must be a sparse matrix or numpy matrix")
+        if X.ndim != 2:
+            raise ValueError("Input must have two dimensions")
+        if X.shape[1] != self.dim:
+            raise ValueError("Input dimension mismatch, expecting %d" % self.dim)
+        out, nonempty = self.minhash_many_arrays(X)
+        return [WeightedMinHash(self.seed, out[i]) if nonempty[i] else None for i in range(out.shape[0])]
+
+    def minhash_many_arrays(self, X):
+        """Like :meth:`minhash_many` but returns ``(hashvalues[N, S, 2] int64, nonempty[N] bool)``."""
+        X = sparse.csr_matrix(X, dtype=np.float32, copy=True)
+        X.sort_indices()
+        X.eliminate_zeros()  # explicit zeros are not part of a row (the reference's nonzero() skips them too)
+        indptr = X.indptr.astype(np.int64)
+        indices = X.indices.astype(np.int32)
+        if self._use_gpu():
+            ctx, handle = self._device_handle()
+            if self._device_log:
+                return ctx.weighted_minhash_many(handle, self.sample_size, indptr, indices, X.data, False)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                log_data = np.log(X.data)
+            return ctx.weighted_minhash_many(handle, self.sample_size, indptr, indices, log_data, True)
+        return self._minhash_many_host(indptr, indices, X.data)
+
+    def _minhash_many_host(self, indptr, indices, data):
+        """gpu_mode='disable': the reference's vectorised numpy evaluation, row by row."""
+        n = indptr.size - 1
+        s = self.sample_size
+        out = np.zeros((n, s, 2), dtype=np.int64)
+        nonempty = np.diff(indptr) > 0
+        with np.errstate(invalid="ignore", divide="ignore"):
+            log_data = np.log(data)
+        rows = np.arange(s)
+        for d in np.flatnonzero(nonempty):
+            cols = indices[indptr[d] : indptr[d + 1]]
+            r, be = self.rs[:, cols], self.betas[:, cols]
+            t = np.floor(log_data[indptr[d] : indptr[d + 1]][None, :] / r + be)
+            ln_a = self.ln_cs[:, cols] - (t - be + 1) * r
+            j = np.argmin(ln_a, axis=1)
+            out[d, :, 0] = cols[j]
+            out[d, :, 1] = t[rows, j]
+        return out, nonempty

@@ -1,0 +1,201 @@
+/*
+ * mhx.h -- C ABI of libmhx, the MI355X-native MinHash signature engine.
+ *
+ * This is the drop-in boundary for ekzhu/datasketch's bulk-hashing hot path.  It is what a
+ * ctypes / cffi stub inside the reference would bind in place of its optional CuPy branch
+ * (reference datasketch/minhash.py:281-291; binding shown in INTEGRATION.md).  Plain pointers
+ * and sizes only: no C++ types, no torch types, no exceptions across the boundary.
+ *
+ * Conventions
+ *   - every function returns an int status (MHX_OK == 0); mhx_last_error() gives the
+ *     thread-local message of the last failing call.
+ *   - "host" entry points take caller-owned host buffers, block until the result is in host
+ *     memory, and never retain the pointers.  "_dev" entry points take device pointers
+ *     (from mhx_dev_alloc or any other HIP allocation on the same device), enqueue on the
+ *     context's stream and return without synchronising.
+ *   - a context owns one device + one HIP stream and is not thread-safe; distinct contexts
+ *     are independent (one context per GPU / per process is the multi-GPU model).
+ *   - citations "ref:" are paths in the reference repository (ekzhu/datasketch v1.10.0).
+ */
+#ifndef MHX_H_
+#define MHX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MHX_API __attribute__((visibility("default")))
+
+/* ---- status codes ------------------------------------------------------------------------- */
+enum {
+    MHX_OK = 0,
+    MHX_ERR_NO_DEVICE = 1,   /* no usable HIP device: maps to the reference's RuntimeError for
+                                gpu_mode='always' (ref: datasketch/minhash.py:272-275)          */
+    MHX_ERR_INVALID = 2,     /* bad argument / shape: maps to ValueError                          */
+    MHX_ERR_HIP = 3,         /* a HIP runtime call failed                                         */
+    MHX_ERR_OOM = 4,         /* device allocation failed                                          */
+    MHX_ERR_UNSUPPORTED = 5, /* valid request outside what this build implements                  */
+    MHX_ERR_COMM = 6         /* RCCL failure                                                      */
+};
+
+/* element types of token / signature buffers */
+enum { MHX_U64 = 0, MHX_U32 = 1 };
+
+typedef struct mhx_ctx mhx_ctx;     /* device + stream + scratch                                  */
+typedef struct mhx_perm mhx_perm;   /* MinHash permutations (a[K], b[K]) resident on the device   */
+typedef struct mhx_wgen mhx_wgen;   /* WeightedMinHashGenerator parameters resident on the device */
+typedef struct mhx_event mhx_event; /* HIP event on the context's stream                          */
+typedef struct mhx_comm mhx_comm;   /* RCCL communicator (one rank per context)                   */
+
+/* ---- library / device --------------------------------------------------------------------- */
+MHX_API const char *mhx_last_error(void);
+MHX_API const char *mhx_version(void);
+
+/* Number of usable devices.  Replaces ref: datasketch/minhash.py:38-48 (_gpu_available). */
+MHX_API int mhx_device_count(int *count);
+
+MHX_API int mhx_ctx_create(int device, mhx_ctx **ctx);
+MHX_API int mhx_ctx_destroy(mhx_ctx *ctx);
+MHX_API int mhx_ctx_synchronize(mhx_ctx *ctx);
+/* name: caller buffer (may be NULL); cus: compute units; hbm_bytes: total device memory */
+MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus, int64_t *hbm_bytes);
+/* Tuning / test knobs, e.g. ("minhash.path", 0=auto 1=exact-fold 2=fast-fold, 3=split-sets). */
+MHX_API int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value);
+
+/* ---- device memory + events (so callers can keep corpora resident and time kernels) ------- */
+MHX_API int mhx_dev_alloc(mhx_ctx *ctx, size_t bytes, void **dptr);
+MHX_API int mhx_dev_free(mhx_ctx *ctx, void *dptr);
+MHX_API int mhx_memcpy_h2d(mhx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+MHX_API int mhx_memcpy_d2h(mhx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+MHX_API int mhx_memset_dev(mhx_ctx *ctx, void *dst_dev, int byte_value, size_t bytes);
+
+MHX_API int mhx_event_create(mhx_ctx *ctx, mhx_event **ev);
+MHX_API int mhx_event_record(mhx_event *ev); /* on the owning context's stream */
+MHX_API int mhx_event_synchronize(mhx_event *ev);
+MHX_API int mhx_event_elapsed_ms(mhx_event *start, mhx_event *stop, float *ms);
+MHX_API int mhx_event_destroy(mhx_event *ev);
+
+/* ---- MinHash ------------------------------------------------------------------------------ */
+/*
+ * Upload permutations (a[k], b[k]) = MinHash.permutations.
+ * Replaces ref: datasketch/minhash.py:160-165 (_ensure_gpu_caches).  a, b are host arrays of
+ * num_perm uint64 as produced by ref: datasketch/minhash.py:170-184 (kept on the host: legacy
+ * numpy RandomState stream).  Any uint64 values are accepted (the reference draws a in [1,p),
+ * b in [0,p) with p = 2^61-1, but user-supplied permutations are not range-checked there either).
+ */
+MHX_API int mhx_perm_create(mhx_ctx *ctx, const uint64_t *a, const uint64_t *b, int32_t num_perm,
+                            mhx_perm **perm);
+MHX_API int mhx_perm_destroy(mhx_perm *perm);
+
+/*
+ * Bulk MinHash over a corpus of pre-hashed token sets, device-resident.
+ * Replaces the per-set loop of ref: datasketch/minhash.py:491-522 (generator / bulk) around
+ * ref: datasketch/minhash.py:293-297 (update_batch body):
+ *     out[i,k] = min( init[i,k],  min_t ((hv[t]*a[k] + b[k]) mod 2^64) mod (2^61-1) & 0xFFFFFFFF )
+ * Bit-exact with the numpy path, including the uint64 wrap-around of hv*a+b.
+ *
+ *   d_hv        token hash values, hv_dtype = MHX_U64 (any uint64) or MHX_U32
+ *   d_offsets   int64[n_sets+1] CSR row pointers into d_hv, or NULL for fixed-length sets
+ *   fixed_len   tokens per set when d_offsets == NULL (ignored otherwise)
+ *   total_tokens  number of elements in d_hv (offsets[n_sets] or n_sets*fixed_len)
+ *   d_init      NULL (fresh state 2^32-1, ref :167-168), or uint64 state with row stride
+ *               init_stride elements (0 = one [K] prototype shared by every set, K = [n,K])
+ *   d_out       [n_sets, K] of out_dtype (MHX_U64 = reference layout; MHX_U32 = compact:
+ *               values are < 2^32 unless an init value >= 2^32 survives an empty set, which
+ *               MHX_U32 output rejects by saturating to 2^32-1)
+ * An empty set leaves its state untouched (ref :265-266).
+ */
+MHX_API int mhx_minhash_bulk_dev(mhx_perm *perm, const void *d_hv, int hv_dtype,
+                                 const int64_t *d_offsets, int64_t fixed_len, int64_t n_sets,
+                                 int64_t total_tokens, const uint64_t *d_init, int64_t init_stride,
+                                 void *d_out, int out_dtype);
+
+/* Same computation from/to host buffers (H2D, kernel, D2H; blocking).  offsets may be NULL
+ * with fixed_len, init may be NULL.  out: uint64 [n_sets, K]. */
+MHX_API int mhx_minhash_bulk(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets,
+                             int64_t fixed_len, int64_t n_sets, const uint64_t *init,
+                             int64_t init_stride, uint64_t *out);
+
+/*
+ * One update_batch on one MinHash state (the reference's GPU seam itself,
+ * ref: datasketch/minhash.py:281-291): hashvalues[K] is read, min-combined with the
+ * permuted minima of hv[0..n), and written back.  n == 0 is a no-op.
+ */
+MHX_API int mhx_minhash_update_batch(mhx_perm *perm, const uint64_t *hv, int64_t n,
+                                     uint64_t *hashvalues);
+
+/* Elementwise min of two signature matrices (ref: datasketch/minhash.py:337-359 merge,
+ * :411-462 union, lean_minhash.py:237-253), count = rows*K elements.  d_out may alias d_x. */
+MHX_API int mhx_minhash_merge_dev(mhx_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y,
+                                  int64_t count, uint64_t *d_out);
+MHX_API int mhx_minhash_merge(mhx_ctx *ctx, const uint64_t *x, const uint64_t *y, int64_t count,
+                              uint64_t *out);
+
+/* ---- Weighted MinHash --------------------------------------------------------------------- */
+/*
+ * Upload generator parameters rs, ln_cs, betas: float32 [sample_size, dim] row-major, exactly the
+ * arrays of ref: datasketch/weighted_minhash.py:119-121 (drawn on the host by numpy).
+ */
+MHX_API int mhx_wgen_create(mhx_ctx *ctx, const float *rs, const float *ln_cs, const float *betas,
+                            int32_t sample_size, int32_t dim, mhx_wgen **gen);
+MHX_API int mhx_wgen_destroy(mhx_wgen *gen);
+
+/*
+ * WeightedMinHashGenerator.minhash_many over a CSR matrix (ref: datasketch/weighted_minhash.py:161-247).
+ *   indptr int64[n_rows+1], indices int32[nnz] (sorted within a row, ref :193), values float32[nnz]
+ *   values_are_logs != 0: values already hold ln(x) as float32 (parity mode: the host computes
+ *     np.log with the same numpy the reference uses; everything downstream is IEEE float32 with
+ *     no FMA contraction, so (k, t) are bit-exact);  == 0: the device takes logf(x) itself.
+ *   out int64[n_rows, sample_size, 2] = (k, t) pairs (ref :233-239); rows without stored values
+ *   get nonempty[row] = 0 (the reference returns None for them, ref :242-247) and zeros in out.
+ */
+MHX_API int mhx_weighted_minhash_many(mhx_wgen *gen, const int64_t *indptr, const int32_t *indices,
+                                      const float *values, int values_are_logs, int64_t n_rows,
+                                      int64_t *out, uint8_t *nonempty);
+MHX_API int mhx_weighted_minhash_many_dev(mhx_wgen *gen, const int64_t *d_indptr,
+                                          const int32_t *d_indices, const float *d_values,
+                                          int values_are_logs, int64_t n_rows, int64_t nnz,
+                                          int64_t *d_out, uint8_t *d_nonempty);
+
+/* ---- Packing for downstream consumers ----------------------------------------------------- */
+/* Number of uint64 blocks bBitMinHash uses for num_perm values of b bits
+ * (ref: datasketch/b_bit_minhash.py:147-172). */
+MHX_API int mhx_bbit_num_blocks(int32_t num_perm, int32_t b, int32_t *num_blocks);
+/* b-bit packing of a whole signature matrix in the bit order of ref:
+ * datasketch/b_bit_minhash.py:37-38,82-97.  sig [n,K] uint64 -> out [n,num_blocks] uint64. */
+MHX_API int mhx_bbit_pack_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n_sigs, int32_t num_perm,
+                              int32_t b, uint64_t *d_out);
+MHX_API int mhx_bbit_pack(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs, int32_t num_perm,
+                          int32_t b, uint64_t *out);
+/* MinHashLSH band keys: out[n, bands*r] holds each hashvalue byte-swapped to big-endian so that
+ * bytes(out[i, j*r:(j+1)*r]) is the key of band j (ref: datasketch/lsh.py:199,344,537-538). */
+MHX_API int mhx_band_keys_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n_sigs, int32_t num_perm,
+                              int32_t bands, int32_t r, uint64_t *d_out);
+MHX_API int mhx_band_keys(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs, int32_t num_perm,
+                          int32_t bands, int32_t r, uint64_t *out);
+/* LeanMinHash.serialize of every row, little-endian: n records of 12+4*K bytes
+ * (ref: datasketch/lean_minhash.py:126-175). */
+MHX_API int mhx_lean_serialize_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n_sigs,
+                                   int32_t num_perm, int64_t seed, uint8_t *d_out);
+MHX_API int mhx_lean_serialize(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs, int32_t num_perm,
+                               int64_t seed, uint8_t *out);
+
+/* ---- Multi-GPU: assemble the signature matrix (RCCL over xGMI) ----------------------------- */
+/* 128-byte RCCL unique id, created on rank 0 and distributed by the caller (env, file, socket). */
+#define MHX_COMM_ID_BYTES 128
+MHX_API int mhx_comm_unique_id(uint8_t id[MHX_COMM_ID_BYTES]);
+MHX_API int mhx_comm_create(mhx_ctx *ctx, const uint8_t id[MHX_COMM_ID_BYTES], int rank,
+                            int world_size, mhx_comm **comm);
+MHX_API int mhx_comm_destroy(mhx_comm *comm);
+/* All-gather equal-sized row shards: every rank contributes bytes_per_rank bytes from d_send,
+ * d_recv receives world_size*bytes_per_rank bytes in rank order.  Enqueued on the ctx stream. */
+MHX_API int mhx_comm_allgather_dev(mhx_comm *comm, const void *d_send, void *d_recv,
+                                   size_t bytes_per_rank);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MHX_H_ */
