@@ -1,0 +1,439 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the reference's golden vectors.
+
+Run on an MI355X:  python -m pytest tests -m gpu -x -q
+Every test calls libmhx through ctypes (datasketch_amd._native -> include/mhx.h).  The bar is
+bit-exact equality for the integer paths and exact (k, t) pairs for the weighted path in parity
+mode.  /root/reference is NOT needed: fixtures in tests/golden/ came from it.
+"""
+import ctypes
+import pickle
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from datasketch_amd import LeanMinHash, MinHash, WeightedMinHashGenerator, _native, bBitMinHash, prehashed
+from datasketch_amd.b_bit_minhash import pack_matrix
+from datasketch_amd.lean_minhash import serialize_matrix
+from oracle import oracle as O
+from tests.conftest import identity as fake_hash_func
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert _native.gpu_available(), "these tests need an MI355X"
+    c = _native.context()
+    yield c
+    for key in ("minhash.path", "minhash.split", "blocks_per_cu"):
+        c.set_option(key, 0)
+
+
+def _ragged(rng, n_sets, max_len, wide_fraction):
+    lens = rng.randint(0, max_len + 1, size=n_sets)
+    offsets = np.zeros(n_sets + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    hv = rng.randint(0, 2**32, size=int(offsets[-1]), dtype=np.uint64)
+    wide = rng.random_sample(hv.size) < wide_fraction
+    hv[wide] = rng.randint(0, 2**64, size=int(wide.sum()), dtype=np.uint64)
+    return hv, offsets
+
+
+# ------------------------------------------------------------------ golden vectors of the reference
+def test_library_is_the_hip_one(ctx):
+    info = ctx.info()
+    assert "gfx950" in info["name"], info
+    assert info["compute_units"] >= 200
+
+
+def test_known_answer_vector(ctx):
+    """test/test_minhash.py:109-115 through update_batch on the device."""
+    m = MinHash(4, 1, gpu_mode="always")
+    m.update_batch([b"Hello"])
+    assert m.hashvalues.tolist() == [734825475, 960773806, 359816889, 342714745]
+
+
+def test_small_golden_vectors(ctx, golden):
+    _, meta = golden
+    m = MinHash(4, 1, hashfunc=fake_hash_func, gpu_mode="always")
+    m.update_batch([12, 24])
+    assert m.hashvalues.tolist() == meta["identity_12_24_k4_seed1"]
+    m = MinHash(4, 7, hashfunc=fake_hash_func, gpu_mode="always")
+    m.update_batch([0, 1, 2**32 - 1, 2**61 - 1, 2**64 - 1])
+    assert m.hashvalues.tolist() == meta["identity_edge_k4_seed7"]
+    m = MinHash(4, 1, gpu_mode="always")
+    m.update_batch([f"token-{i}".encode() for i in range(1000)])
+    assert m.hashvalues.tolist() == meta["sha1_token1000_k4_seed1"]
+
+
+def test_config1_matrix(ctx, golden):
+    """BASELINE.json configs[0]: 1k x 64, num_perm=16."""
+    arrays, _ = golden
+    tok = np.random.RandomState(42).randint(0, 2**32, (1000, 64), dtype=np.uint64)
+    got = MinHash.bulk_signatures(tok, num_perm=16, seed=1, hashfunc=prehashed, gpu_mode="always")
+    assert np.array_equal(got, arrays["c1_matrix"])
+    objs = MinHash.bulk(tok, num_perm=16, seed=1, hashfunc=fake_hash_func, gpu_mode="always")
+    assert np.array_equal(np.stack([m.hashvalues for m in objs]), arrays["c1_matrix"])
+
+
+def test_config2_sample(ctx, golden):
+    arrays, _ = golden
+    tok = np.random.RandomState(42).randint(0, 2**32, (64, 256), dtype=np.uint64)
+    got = MinHash.bulk_signatures(tok, num_perm=128, seed=1, hashfunc=prehashed, gpu_mode="always")
+    assert np.array_equal(got, arrays["c2_sample_matrix"])
+
+
+@pytest.mark.parametrize("path", [0, 1, 2])
+@pytest.mark.parametrize("split", [0, 1, 2])
+def test_ragged_golden(ctx, golden, path, split):
+    arrays, meta = golden
+    ctx.set_option("minhash.path", path)
+    ctx.set_option("minhash.split", split)
+    try:
+        for idx, cfg in enumerate(meta["ragged"]):
+            hv, off, want = (arrays[f"ragged{idx}_{n}"] for n in ("hv", "offsets", "sig"))
+            got = MinHash.bulk_signatures((hv, off), num_perm=cfg["k"], seed=cfg["seed"], hashfunc=prehashed, gpu_mode="always")
+            assert np.array_equal(got, want), (cfg, path, split)
+    finally:
+        ctx.set_option("minhash.path", 0)
+        ctx.set_option("minhash.split", 0)
+
+
+def test_two_batches_with_state(ctx, golden):
+    """test/test_minhash_gpu.py:26-52: CPU == GPU bit-exact, also on a non-trivial state."""
+    arrays, _ = golden
+    d1 = [f"token-{i}".encode() for i in range(500)]
+    d2 = [f"token-{i}".encode() for i in range(700)]
+    m_cpu = MinHash(num_perm=128, seed=7, gpu_mode="disable")
+    m_gpu = MinHash(num_perm=128, seed=7, gpu_mode="always")
+    m_auto = MinHash(num_perm=128, seed=7, gpu_mode="detect")
+    for m in (m_cpu, m_gpu, m_auto):
+        m.update_batch(d1)
+    assert np.array_equal(m_gpu.hashvalues, arrays["two_batches_after1"])
+    for m in (m_cpu, m_gpu, m_auto):
+        m.update_batch(d2)
+    assert np.array_equal(m_gpu.hashvalues, arrays["two_batches_after2"])
+    assert np.array_equal(m_cpu.hashvalues, m_gpu.hashvalues) and np.array_equal(m_cpu.hashvalues, m_auto.hashvalues)
+    data = [f"token-{i}".encode() for i in range(1000)]
+    m_gpu = MinHash(num_perm=256, seed=7, gpu_mode="always")
+    m_gpu.update_batch(data)
+    assert np.array_equal(m_gpu.hashvalues, arrays["sha1_token1000_k256_seed7"])
+
+
+def test_pickle_roundtrip_is_portable(ctx):
+    """test/test_minhash_gpu.py:54-71."""
+    m = MinHash(num_perm=128, seed=7, gpu_mode="detect")
+    m2 = pickle.loads(pickle.dumps(m))
+    m2.update_batch([f"token-{i}".encode() for i in range(64)])
+    ref = MinHash(num_perm=128, seed=7)
+    ref.update_batch([f"token-{i}".encode() for i in range(64)])
+    assert m2 == ref
+
+
+def test_adversarial_fold_boundaries_golden(ctx, golden):
+    arrays, _ = golden
+    adv = arrays["adv_tokens"]
+    off = np.arange(len(adv) + 1, dtype=np.int64)
+    for path in (0, 1, 2):
+        ctx.set_option("minhash.path", path)
+        got = MinHash.bulk_signatures((adv, off), num_perm=8, seed=1, hashfunc=prehashed, gpu_mode="always")
+        assert np.array_equal(got, arrays["adv_per_token_sig"]), path
+    ctx.set_option("minhash.path", 0)
+
+
+# ------------------------------------------------------------------ randomized parity vs the oracle
+@pytest.mark.parametrize("k", [1, 7, 16, 63, 64, 65, 100, 128, 129, 200, 256, 257, 320, 512, 600, 1024, 1100])
+def test_num_perm_sweep(ctx, k):
+    rng = np.random.RandomState(k)
+    hv, off = _ragged(rng, 300, 90, 0.1)
+    a, b = O.np_init_permutations(k, 11)
+    want = O.c_minhash_bulk(hv, off, a, b)
+    got = ctx.minhash_bulk((a, b), hv, off, 0, 300)
+    assert np.array_equal(got, want)
+
+
+def test_dense_config2_shape_20k(ctx):
+    tok = np.random.RandomState(1).randint(0, 2**32, (20000, 256), dtype=np.uint64)
+    a, b = O.np_init_permutations(128, 1)
+    want = O.c_minhash_bulk_dense(tok, a, b)
+    got = ctx.minhash_bulk((a, b), tok.reshape(-1), None, 256, 20000)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("wide", [0.0, 0.02, 1.0])
+@pytest.mark.parametrize("k", [128, 256])
+def test_wide_tokens(ctx, wide, k):
+    rng = np.random.RandomState(int(wide * 100) + k)
+    hv, off = _ragged(rng, 2000, 300, wide)
+    a, b = O.np_init_permutations(k, 5)
+    assert np.array_equal(ctx.minhash_bulk((a, b), hv, off, 0, 2000), O.c_minhash_bulk(hv, off, a, b))
+
+
+def test_arbitrary_uint64_permutations(ctx):
+    """User-supplied permutations are not range-checked by the reference: any uint64 must work."""
+    rng = np.random.RandomState(3)
+    a = rng.randint(0, 2**64, 128, dtype=np.uint64)
+    b = rng.randint(0, 2**64, 128, dtype=np.uint64)
+    a[:4] = [0, 1, 2**64 - 1, 2**63]
+    b[:4] = [2**64 - 1, 0, 2**64 - 1, 2**61 - 1]
+    hv, off = _ragged(rng, 500, 64, 0.3)
+    assert np.array_equal(ctx.minhash_bulk((a, b), hv, off, 0, 500), O.c_minhash_bulk(hv, off, a, b))
+
+
+def _solve_tokens(a, b, targets):
+    out = []
+    for ai, bi in zip(a.tolist(), b.tolist()):
+        if ai % 2 == 0:
+            continue
+        inv = pow(ai, -1, 1 << 64)
+        out.extend(((s - bi) * inv) % (1 << 64) for s in targets)
+    return np.array(out, dtype=np.uint64)
+
+
+def test_fold_boundaries_exhaustive(ctx):
+    """Tokens whose hv*a+b (mod 2^64) sits on every kind of fold boundary, hidden inside otherwise
+    ordinary sets so that the fast fold must notice and recompute exactly."""
+    p = (1 << 61) - 1
+    m = (1 << 29) - 1
+    targets = []
+    for top in range(8):
+        base = top << 61
+        for low in (0, 1, p - 8, p - 7, p - 2, p - 1, p, (m << 32) | 0xFFFFFFF0, (m << 32) | 0xFFFFFFFF,
+                    0xFFFFFFFF, 0xFFFFFFF8, 0x1_0000_0000 - 1 - top, ((m - 1) << 32) | 0xFFFFFFFF):
+            targets.append((base + (low & p)) % (1 << 64))
+            targets.append((base + ((low - top) & p)) % (1 << 64))
+            targets.append((base + ((low - top - 1) & p)) % (1 << 64))
+    for k in (8, 128):
+        a, b = O.np_init_permutations(k, 1)
+        adv = _solve_tokens(a[:8], b[:8], targets)
+        rng = np.random.RandomState(0)
+        sets, off = [], [0]
+        for t in adv:
+            filler = rng.randint(0, 2**32, rng.randint(0, 40), dtype=np.uint64)
+            s = np.concatenate([filler, [t]])
+            rng.shuffle(s)
+            sets.append(s)
+            off.append(off[-1] + s.size)
+        hv, off = np.concatenate(sets), np.array(off, dtype=np.int64)
+        want = O.c_minhash_bulk(hv, off, a, b)
+        for path in (0, 1, 2):
+            ctx.set_option("minhash.path", path)
+            assert np.array_equal(ctx.minhash_bulk((a, b), hv, off, 0, len(sets)), want), (k, path)
+        ctx.set_option("minhash.path", 0)
+
+
+def test_initial_state_variants(ctx):
+    rng = np.random.RandomState(9)
+    k, n = 128, 400
+    a, b = O.np_init_permutations(k, 2)
+    hv, off = _ragged(rng, n, 50, 0.05)
+    proto = rng.randint(0, 2**32, k, dtype=np.uint64)
+    proto[:3] = [0, 2**32 - 1, 2**40]  # a state value >= 2^32 must survive an empty set untouched
+    full = rng.randint(0, 2**33, (n, k), dtype=np.uint64)
+    assert np.array_equal(ctx.minhash_bulk((a, b), hv, off, 0, n, proto), O.c_minhash_bulk(hv, off, a, b, proto))
+    assert np.array_equal(ctx.minhash_bulk((a, b), hv, off, 0, n, full), O.c_minhash_bulk(hv, off, a, b, full))
+    ctx.set_option("minhash.split", 2)
+    assert np.array_equal(ctx.minhash_bulk((a, b), hv, off, 0, n, full), O.c_minhash_bulk(hv, off, a, b, full))
+    ctx.set_option("minhash.split", 0)
+
+
+@pytest.mark.parametrize("n_tokens", [1, 7, 8, 9, 63, 1000, 50_000, 1_000_003])
+def test_update_batch_one_long_set(ctx, n_tokens):
+    """The reference's own GPU use case: one big set per call (split over waves + atomic min)."""
+    rng = np.random.RandomState(n_tokens % 1000)
+    hv = rng.randint(0, 2**32, n_tokens, dtype=np.uint64)
+    a, b = O.np_init_permutations(256, 7)
+    state = rng.randint(0, 2**32, 256, dtype=np.uint64)
+    want = O.c_minhash_bulk(hv, np.array([0, n_tokens]), a, b, state)[0]
+    assert np.array_equal(ctx.minhash_update_batch((a, b), hv, state), want)
+
+
+def test_few_long_ragged_sets(ctx):
+    rng = np.random.RandomState(4)
+    lens = np.array([0, 70000, 3, 0, 123457, 1, 40000], dtype=np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    hv = rng.randint(0, 2**64, int(off[-1]), dtype=np.uint64)
+    a, b = O.np_init_permutations(128, 1)
+    assert np.array_equal(ctx.minhash_bulk((a, b), hv, off, 0, len(lens)), O.c_minhash_bulk(hv, off, a, b))
+
+
+def test_device_resident_u32_variants(ctx):
+    """Device-pointer entry point with uint32 tokens in / uint32 signatures out."""
+    rng = np.random.RandomState(6)
+    n, t, k = 5000, 96, 128
+    tok = rng.randint(0, 2**32, (n, t), dtype=np.uint64)
+    a, b = O.np_init_permutations(k, 1)
+    want = O.c_minhash_bulk_dense(tok, a, b)
+    d64 = ctx.to_device(tok)
+    d32 = ctx.to_device(tok.astype(np.uint32))
+    for tok_buf, tok_dt in ((d64, _native.MHX_U64), (d32, _native.MHX_U32)):
+        for out_dt, np_dt in ((_native.MHX_U64, np.uint64), (_native.MHX_U32, np.uint32)):
+            d_out = ctx.alloc(n * k * np.dtype(np_dt).itemsize)
+            ctx.minhash_bulk_dev((a, b), tok_buf.ptr, tok_dt, None, t, n, n * t, None, 0, d_out.ptr, out_dt)
+            ctx.synchronize()
+            assert np.array_equal(d_out.download((n, k), np_dt).astype(np.uint64), want)
+    # CSR on the device with uint32 tokens and an odd row start (4-byte aligned scalar loads)
+    hv, off = _ragged(rng, 700, 40, 0.0)
+    d_hv, d_off = ctx.to_device(hv.astype(np.uint32)), ctx.to_device(off)
+    d_out = ctx.alloc(700 * k * 8)
+    ctx.minhash_bulk_dev((a, b), d_hv.ptr, _native.MHX_U32, d_off.ptr, 0, 700, hv.size, None, 0, d_out.ptr, _native.MHX_U64)
+    ctx.synchronize()
+    assert np.array_equal(d_out.download((700, k), np.uint64), O.c_minhash_bulk(hv, off, a, b))
+
+
+def test_merge(ctx):
+    rng = np.random.RandomState(8)
+    for shape in ((1, 1), (3, 7), (1000, 128), (257, 129)):
+        x = rng.randint(0, 2**32, shape, dtype=np.uint64)
+        y = rng.randint(0, 2**32, shape, dtype=np.uint64)
+        assert np.array_equal(ctx.minhash_merge(x, y), O.c_minhash_merge(x, y))
+
+
+def test_invalid_arguments_raise_value_error(ctx):
+    a, b = O.np_init_permutations(8, 1)
+    with pytest.raises(ValueError):
+        ctx.minhash_bulk((a, b), np.zeros(4, np.uint64), np.array([0, 3, 2]), 0, 2)
+    with pytest.raises(ValueError):
+        ctx.minhash_bulk((a, b), np.zeros(4, np.uint64), None, 4, 1, init=np.zeros(3, np.uint64))
+    with pytest.raises(ValueError):
+        ctx.bbit_pack(np.zeros((2, 8), np.uint64), 40)
+    with pytest.raises(ValueError):
+        ctx.band_keys(np.zeros((2, 8), np.uint64), 3, 4)
+    assert ctx.minhash_bulk((a, b), np.zeros(0, np.uint64), None, 0, 0).shape == (0, 8)
+
+
+# ------------------------------------------------------------------ full-size properties (config 2)
+def test_full_size_properties_1m_sets(ctx):
+    """BASELINE.json configs[1] at full size (1M x 256, K=128): size-independent properties plus
+    an oracle check on rows spread over the whole matrix."""
+    n, t, k = 1_000_000, 256, 128
+    tok = np.random.RandomState(42).randint(0, 2**32, (n, t), dtype=np.uint64)
+    a, b = O.np_init_permutations(k, 1)
+    d_tok = ctx.to_device(tok)
+    d_sig = ctx.alloc(n * k * 8)
+    ctx.minhash_bulk_dev((a, b), d_tok.ptr, _native.MHX_U64, None, t, n, n * t, None, 0, d_sig.ptr, _native.MHX_U64)
+    ctx.synchronize()
+    sig = d_sig.download((n, k), np.uint64)
+    rows = np.unique(np.concatenate([np.arange(0, 2048), np.linspace(0, n - 1, 4096).astype(np.int64), np.arange(n - 2048, n)]))
+    assert np.array_equal(sig[rows], O.c_minhash_bulk_dense(tok[rows], a, b))
+    assert int(sig.max()) < 2**32
+    # idempotence: hashing the same sets again on top of their own signatures changes nothing
+    d_again = ctx.alloc(n * k * 8)
+    ctx.minhash_bulk_dev((a, b), d_tok.ptr, _native.MHX_U64, None, t, n, n * t, d_sig.ptr, k, d_again.ptr, _native.MHX_U64)
+    ctx.synchronize()
+    assert np.array_equal(d_again.download((n, k), np.uint64), sig)
+    # union identity: signature(set) == min(signature(first half), signature(second half))
+    # (the dense [n, t] corpus viewed as [2n, t/2]: set 2i / 2i+1 are the halves of row i)
+    half = t // 2
+    del d_again
+    d_halves = ctx.alloc(2 * n * k * 8)
+    ctx.minhash_bulk_dev((a, b), d_tok.ptr, _native.MHX_U64, None, half, 2 * n, n * t, None, 0, d_halves.ptr, _native.MHX_U64)
+    ctx.synchronize()
+    halves = d_halves.download((n, 2, k), np.uint64)
+    assert np.array_equal(np.minimum(halves[:, 0], halves[:, 1]), sig)
+    # checksum of checksums against the oracle on a 50k-row slice
+    sl = slice(300_000, 350_000)
+    assert int(sig[sl].sum(dtype=np.uint64)) == int(O.c_minhash_bulk_dense(tok[sl], a, b).sum(dtype=np.uint64))
+
+
+# ------------------------------------------------------------------ weighted MinHash
+def test_weighted_golden(ctx, golden):
+    arrays, meta = golden
+    g = WeightedMinHashGenerator(8, 4, 1, gpu_mode="always")
+    res = g.minhash_many(np.array([[1, 0, 3, 0, 0.5, 2, 0, 7], [0] * 8, [2] * 8], dtype=np.float64))
+    assert [None if r is None else r.hashvalues.tolist() for r in res] == meta["weighted_small"]
+    g = WeightedMinHashGenerator(64, 32, 5, gpu_mode="always")
+    out, nonempty = g.minhash_many_arrays(arrays["w_dense_in"])
+    assert np.array_equal(out, arrays["w_dense_out"]) and np.array_equal(nonempty, arrays["w_dense_nonempty"])
+    X = sp.csr_matrix((arrays["w_csr_data"], arrays["w_csr_indices"], arrays["w_csr_indptr"]), shape=(30, 64))
+    out, nonempty = g.minhash_many_arrays(X)
+    assert np.array_equal(out, arrays["w_csr_out"]) and np.array_equal(nonempty, arrays["w_csr_nonempty"])
+    g2 = WeightedMinHashGenerator(512, 128, 1, gpu_mode="always")
+    out, nonempty = g2.minhash_many_arrays(arrays["w2_in"])
+    assert nonempty.all() and np.array_equal(out, arrays["w2_out"])
+
+
+@pytest.mark.parametrize("dim,s,density", [(300, 1, 0.5), (300, 100, 0.02), (4096, 128, 1.0), (1000, 200, 0.3)])
+def test_weighted_random_vs_oracle(ctx, dim, s, density):
+    rng = np.random.RandomState(dim + s)
+    g = WeightedMinHashGenerator(dim, s, seed=3, gpu_mode="always")
+    x = rng.uniform(0, 100, (48, dim)).astype(np.float32)
+    if density < 1.0:
+        x[rng.random_sample(x.shape) >= density] = 0
+    x[7] = 0
+    out, nonempty = g.minhash_many_arrays(x)
+    csr = sp.csr_matrix(x)
+    csr.sort_indices()
+    want, wn = O.c_weighted_minhash_many(csr.indptr, csr.indices, csr.data, g.rs, g.ln_cs, g.betas)
+    assert np.array_equal(nonempty, wn) and not nonempty[7]
+    assert np.array_equal(out, want)
+
+
+def test_weighted_device_log_mode_is_close(ctx):
+    """Fast mode: logf on the device.  (k, t) may differ from numpy's log only where two ln_a are
+    within float32 rounding of each other; the mismatch rate must be tiny."""
+    rng = np.random.RandomState(1)
+    x = rng.uniform(0, 100, (64, 2048)).astype(np.float32)
+    exact = WeightedMinHashGenerator(2048, 128, seed=1, gpu_mode="always").minhash_many_arrays(x)[0]
+    fast = WeightedMinHashGenerator(2048, 128, seed=1, gpu_mode="always", device_log=True).minhash_many_arrays(x)[0]
+    mismatch = np.mean(np.any(exact != fast, axis=2))
+    assert mismatch < 1e-3, mismatch
+
+
+# ------------------------------------------------------------------ packing
+@pytest.mark.parametrize("k", [8, 48, 64, 100, 128, 256, 300])
+def test_bbit_pack(ctx, k):
+    rng = np.random.RandomState(k)
+    sig = rng.randint(0, 2**32, (257, k), dtype=np.uint64)
+    for b in (0, 1, 2, 3, 4, 5, 8, 9, 13, 16, 27, 32):
+        assert np.array_equal(pack_matrix(sig, b, gpu_mode="always"), O.c_bbit_pack(sig, b)), (k, b)
+
+
+def test_bbit_states_golden(ctx, golden):
+    arrays, meta = golden
+    sig = arrays["misc_sig_k48"][None, :]
+    for b, want in meta["bbit_states_k48"].items():
+        blocks = pack_matrix(sig, int(b), gpu_mode="always")
+        assert blocks.astype("<u8").tobytes().hex() == want[42:]
+        m = MinHash(seed=3, hashvalues=arrays["misc_sig_k48"])
+        assert bytes(bBitMinHash(m, int(b)).__getstate__()).hex() == want
+
+
+def test_band_keys(ctx, golden):
+    arrays, meta = golden
+    for name, bands, r in (("k8", 2, 4), ("k48", 6, 8)):
+        keys = ctx.band_keys(arrays[f"misc_sig_{name}"][None, :], bands, r)
+        got = [keys[0, i * r : (i + 1) * r].tobytes().hex() for i in range(bands)]
+        assert got == meta[f"lsh_keys_{name}_b{bands}_r{r}"]
+    rng = np.random.RandomState(2)
+    sig = rng.randint(0, 2**32, (1001, 256), dtype=np.uint64)
+    for bands, r in ((32, 8), (20, 5), (1, 256), (3, 3)):
+        assert np.array_equal(ctx.band_keys(sig, bands, r), O.c_band_keys(sig, bands, r))
+
+
+def test_lean_serialize(ctx, golden):
+    arrays, meta = golden
+    assert serialize_matrix(arrays["misc_sig_k8"][None, :], 1, gpu_mode="always")[0].tobytes().hex() == meta["lean_serialize_le"]
+    rng = np.random.RandomState(3)
+    for k in (1, 8, 100, 128):
+        sig = rng.randint(0, 2**32, (513, k), dtype=np.uint64)
+        rows = serialize_matrix(sig, -5, gpu_mode="always")
+        assert np.array_equal(rows, O.c_lean_serialize(sig, -5))
+        lm = LeanMinHash.deserialize(rows[17].tobytes(), "<")
+        assert lm.seed == -5 and np.array_equal(lm.hashvalues, sig[17])
+
+
+# ------------------------------------------------------------------ RCCL binding (single rank)
+def test_rccl_allgather_single_rank(ctx):
+    lib = ctx.lib
+    uid = (ctypes.c_uint8 * _native.COMM_ID_BYTES)()
+    _native.check(lib.mhx_comm_unique_id(uid))
+    comm = ctypes.c_void_p()
+    _native.check(lib.mhx_comm_create(ctx.handle, uid, 0, 1, ctypes.byref(comm)))
+    x = np.random.RandomState(0).randint(0, 2**32, (1000, 128), dtype=np.uint64)
+    d_x, d_y = ctx.to_device(x), ctx.alloc(x.nbytes)
+    _native.check(lib.mhx_comm_allgather_dev(comm, d_x.ptr, d_y.ptr, x.nbytes))
+    ctx.synchronize()
+    assert np.array_equal(d_y.download(x.shape, np.uint64), x)
+    _native.check(lib.mhx_comm_destroy(comm))

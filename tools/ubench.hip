@@ -1,0 +1,112 @@
+// tools/ubench.hip -- issue-rate microbenchmark of the integer VALU instructions the MinHash
+// kernel is built from, on gfx950.  Build: hipcc --offload-arch=gfx950 -O3 tools/ubench.hip -o tools/ubench
+// Prints wave-instructions per ns per SIMD and the cost relative to v_add_u32.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+constexpr int CHAINS = 8;
+constexpr int UNROLL = 16;
+
+template <int OP>
+__device__ __forceinline__ void op(unsigned &x0, unsigned &x1, unsigned y, unsigned z, unsigned sc) {
+    // x0,x1: chain state (x1 used by 64-bit ops); y,z: loop-invariant vgprs; sc: sgpr
+    if constexpr (OP == 0) { unsigned long long d, c = ((unsigned long long)x1 << 32) | x0; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "v"(y), "v"(z), "v"(c) : "vcc"); x0 = (unsigned)d; x1 = (unsigned)(d >> 32); }
+    if constexpr (OP == 1) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x0) : "v"(y));
+    if constexpr (OP == 2) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(x0) : "v"(y));
+    if constexpr (OP == 3) asm volatile("v_add_u32 %0, %0, %1" : "+v"(x0) : "v"(y));
+    if constexpr (OP == 4) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(x0) : "v"(y), "v"(z));
+    if constexpr (OP == 5) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(x0) : "v"(y), "v"(z));
+    if constexpr (OP == 6) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(x0));
+    if constexpr (OP == 7) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(x0) : "v"(y));
+    if constexpr (OP == 8) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(x0) : "v"(y), "v"(z));
+    if constexpr (OP == 9) { unsigned long long d, c = ((unsigned long long)x1 << 32) | x0; asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %3" : "=v"(d) : "s"(sc), "v"(z), "v"(c) : "vcc"); x0 = (unsigned)d; x1 = (unsigned)(d >> 32); }
+    if constexpr (OP == 10) asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %3, vcc" : "+v"(x0), "+v"(x1) : "v"(y), "v"(z) : "vcc");
+    if constexpr (OP == 11) { unsigned long long c = ((unsigned long long)x1 << 32) | x0, d = ((unsigned long long)z << 32) | y; asm volatile("v_cmp_lt_u64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc" : "+v"(x0) : "v"(c), "v"(d) : "vcc"); }
+    if constexpr (OP == 12) { unsigned long long c = ((unsigned long long)x1 << 32) | x0, d = ((unsigned long long)z << 32) | y; asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(c) : "v"(d)); x0 = (unsigned)c; x1 = (unsigned)(c >> 32); }
+    if constexpr (OP == 13) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(x0) : "v"(y), "v"(z));
+    if constexpr (OP == 14) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(x0) : "v"(y));
+    if constexpr (OP == 15) asm volatile("v_pk_mul_lo_u16 %0, %0, %1" : "+v"(x0) : "v"(y));
+    if constexpr (OP == 16) asm volatile("v_mul_lo_u32 %0, %1, %0" : "+v"(x0) : "s"(sc));
+    if constexpr (OP == 17) asm volatile("v_min_u32 %0, %0, %1" : "+v"(x0) : "v"(y));
+    if constexpr (OP == 18) asm volatile("v_and_b32 %0, %0, %1" : "+v"(x0) : "v"(y));
+    if constexpr (OP == 19) asm volatile("v_mov_b32 %0, %1" : "=v"(x0) : "v"(x1));
+    if constexpr (OP == 20) asm volatile("v_alignbit_b32 %0, %0, %1, 29" : "+v"(x0) : "v"(y));
+    if constexpr (OP == 21) asm volatile("v_bfe_u32 %0, %0, 3, 20" : "+v"(x0));
+    if constexpr (OP == 22) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(x0) : "v"(y));
+}
+
+template <int OP>
+__global__ __launch_bounds__(256) void bench_kernel(unsigned *out, int iters, unsigned seed) {
+    unsigned x0[CHAINS], x1[CHAINS];
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int c = 0; c < CHAINS; ++c) { x0[c] = tid * 2654435761u + c * 40503u + seed; x1[c] = tid ^ (c * 7919u); }
+    unsigned y = tid * 3u + 1u, z = tid * 5u + 7u;
+    const unsigned sc = __builtin_amdgcn_readfirstlane(seed * 77u + 13u);
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int c = 0; c < CHAINS; ++c) op<OP>(x0[c], x1[c], y, z, sc);
+    }
+    unsigned acc = 0;
+    for (int c = 0; c < CHAINS; ++c) acc ^= x0[c] ^ x1[c];
+    if (acc == 0x12345678u) out[tid] = acc;  // keep results live
+}
+
+template <int OP>
+double run(const char *name, int instr_per_op, int blocks, int waves_per_simd, unsigned *d_out, double base) {
+    const int iters = 2000;
+    hipEvent_t a, b;
+    CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
+    hipLaunchKernelGGL(bench_kernel<OP>, dim3(blocks), dim3(256), 0, 0, d_out, 10, 1u);
+    CHK(hipDeviceSynchronize());
+    CHK(hipEventRecord(a));
+    hipLaunchKernelGGL(bench_kernel<OP>, dim3(blocks), dim3(256), 0, 0, d_out, iters, 2u);
+    CHK(hipEventRecord(b));
+    CHK(hipEventSynchronize(b));
+    float ms = 0; CHK(hipEventElapsedTime(&ms, a, b));
+    const double wave_instr_per_simd = (double)iters * UNROLL * CHAINS * instr_per_op * waves_per_simd;
+    const double ns_per = ms * 1e6 / wave_instr_per_simd;
+    printf("%-34s w/simd=%d  %8.3f ns/wave-instr/SIMD  (%5.2f cyc @2.4GHz)  x%.2f vs v_add_u32\n", name, waves_per_simd, ns_per, ns_per * 2.4, base > 0 ? ns_per / base : 1.0);
+    fflush(stdout);
+    return ns_per;
+}
+
+int main() {
+    hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    printf("device: %s, %d CUs, clock %d kHz\n", prop.name, cus, prop.clockRate);
+    unsigned *d_out; CHK(hipMalloc(&d_out, sizeof(unsigned) * 256 * cus * 8));
+    for (int wps : {1, 2, 4}) {
+        const int blocks = cus * wps;  // 256-thread block = 1 wave per SIMD
+        double base = run<3>("v_add_u32", 1, blocks, wps, d_out, 0);
+        run<4>("v_add3_u32", 1, blocks, wps, d_out, base);
+        run<5>("v_min3_u32", 1, blocks, wps, d_out, base);
+        run<17>("v_min_u32", 1, blocks, wps, d_out, base);
+        run<6>("v_lshrrev_b32", 1, blocks, wps, d_out, base);
+        run<18>("v_and_b32", 1, blocks, wps, d_out, base);
+        run<19>("v_mov_b32", 1, blocks, wps, d_out, base);
+        run<20>("v_alignbit_b32", 1, blocks, wps, d_out, base);
+        run<21>("v_bfe_u32", 1, blocks, wps, d_out, base);
+        run<22>("v_lshl_add_u32", 1, blocks, wps, d_out, base);
+        run<1>("v_mul_lo_u32", 1, blocks, wps, d_out, base);
+        run<16>("v_mul_lo_u32 (sgpr src)", 1, blocks, wps, d_out, base);
+        run<2>("v_mul_hi_u32", 1, blocks, wps, d_out, base);
+        run<0>("v_mad_u64_u32", 1, blocks, wps, d_out, base);
+        run<9>("v_mad_u64_u32 (sgpr src)", 1, blocks, wps, d_out, base);
+        run<7>("v_mul_u32_u24", 1, blocks, wps, d_out, base);
+        run<8>("v_mad_u32_u24", 1, blocks, wps, d_out, base);
+        run<14>("v_mul_hi_u32_u24", 1, blocks, wps, d_out, base);
+        run<15>("v_pk_mul_lo_u16", 1, blocks, wps, d_out, base);
+        run<13>("v_dot4_u32_u8", 1, blocks, wps, d_out, base);
+        run<10>("v_add_co+v_addc_co (pair)", 2, blocks, wps, d_out, base);
+        run<11>("v_cmp_lt_u64+v_addc_co (pair)", 2, blocks, wps, d_out, base);
+        run<12>("v_lshl_add_u64", 1, blocks, wps, d_out, base);
+    }
+    return 0;
+}
