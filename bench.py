@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--cpu-sample", type=int, default=40_000, help="sets timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive host->host measurement")
     ap.add_argument("--u32", action="store_true", help="compact variant: uint32 tokens in, uint32 signatures out")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="libmhx tuning knob (mhx_ctx_set_option), e.g. blocks_per_cu=4")
     return ap.parse_args()
 
 
@@ -65,6 +66,9 @@ def main():
     from datasketch_amd.minhash import MinHash
 
     ctx = _native.Context(local_rank)
+    for kv in args.opt:
+        key, _, val = kv.partition("=")
+        ctx.set_option(key, int(val))
 
     dist = None
     torch = None

@@ -68,12 +68,17 @@ __device__ __forceinline__ uint32_t fold_exact(uint32_t s_lo, uint32_t s_hi) {
     return (uint32_t)y + (y >= kMersenne ? 1u : 0u);
 }
 
-// Fast fold: u' = s_lo + top + 1 (mod 2^32).  Whenever u' >= 8 there was no carry out of
-// s_lo + top + 1, hence y < p and fold_exact == u' - 1.  u' in [0,7] is the only way the exact
-// result can differ (or the order of the minima can change), so a set whose final minimum of
-// u' is <= 7 for some permutation is recomputed with fold_exact.
+// Fast fold.  The fast path hashes with b' = b + 1 (mod 2^64), i.e. it sees s' = s + 1, and
+// computes u = s'_lo + (s'_hi >> 29) (mod 2^32): two full-rate VALU ops.
+//   * s_lo != 2^32-1: s'_lo = s_lo + 1 without carry and s'_hi = s_hi, so u = s_lo + top + 1.
+//     If u >= 8 that sum did not wrap, hence low61(s) + top < p, no "-p" correction is due and
+//     fold_exact(s) == u - 1.
+//   * s_lo == 2^32-1: u = (s_hi + 1) >> 29 <= 7.
+// So u <= 7 is the only way the exact result can differ from u - 1 (or the order of two values
+// can flip); probability 2^-29 per pair.  A set whose final minimum of u is <= 7 for some
+// permutation is recomputed with fold_exact; otherwise min(fold_exact) == min(u) - 1.
 __device__ __forceinline__ uint32_t fold_fast(uint32_t s_lo, uint32_t s_hi) {
-    return s_lo + (s_hi >> 29) + 1u;
+    return s_lo + (s_hi >> 29);
 }
 
 template <bool EXACT>
@@ -103,19 +108,20 @@ struct Chunk;
 template <>
 struct Chunk<uint64_t> {
     static constexpr int N = 8;  // 64 B = one s_load_dwordx16
-    uint64_t v[N];
+    uint32_t w[2 * N];           // little-endian halves: token i = (w[2i+1] << 32) | w[2i]
     __device__ __forceinline__ void load(const uint64_t MHX_CONST_AS *p) {
+        const uint32_t MHX_CONST_AS *q = (const uint32_t MHX_CONST_AS *)p;
 #pragma unroll
-        for (int i = 0; i < N; ++i) v[i] = p[i];
+        for (int i = 0; i < 2 * N; ++i) w[i] = q[i];
     }
-    __device__ __forceinline__ uint32_t or_hi() const {
+    __device__ __forceinline__ uint32_t or_hi() const {  // 7 x s_or_b32 on the scalar unit
         uint32_t o = 0;
 #pragma unroll
-        for (int i = 0; i < N; ++i) o |= (uint32_t)(v[i] >> 32);
+        for (int i = 0; i < N; ++i) o |= w[2 * i + 1];
         return o;
     }
-    __device__ __forceinline__ uint32_t lo(int i) const { return (uint32_t)v[i]; }
-    __device__ __forceinline__ uint32_t hi(int i) const { return (uint32_t)(v[i] >> 32); }
+    __device__ __forceinline__ uint32_t lo(int i) const { return w[2 * i]; }
+    __device__ __forceinline__ uint32_t hi(int i) const { return w[2 * i + 1]; }
 };
 template <>
 struct Chunk<uint32_t> {
@@ -146,7 +152,8 @@ __device__ __forceinline__ void hash_chunk(const Chunk<TokT> &c, const Perms<P> 
                     mad_narrow(c.lo(i + j), pm.a_lo[p], pm.a_hi[p], pm.b[p], lo, hi);
                     f[j] = fold<EXACT>(lo, hi);
                 }
-                acc[p] = min(min(acc[p], f[3]), min(min(f[0], f[1]), f[2]));  // 2 x v_min3_u32
+                acc[p] = min(min(acc[p], f[0]), f[1]);  // v_min3_u32
+                acc[p] = min(min(acc[p], f[2]), f[3]);  // v_min3_u32
             }
         }
     } else {
@@ -176,34 +183,48 @@ __device__ __forceinline__ void hash_range(const TokT MHX_CONST_AS *hv, int64_t 
     const int64_t n = end - beg;
     const int nfull = (int)(n / N);  // launcher keeps per-wave ranges far below 2^31 chunks
     if (nfull > 0) {
-        Chunk<TokT> cur;
-        cur.load(p);
-        int i = 0;
+        const auto chunk_ptr = [&](int idx) { return p + (int64_t)(idx < nfull ? idx : nfull - 1) * N; };
+        // Narrow loop over PAIRS of chunks with two ping-pong buffers: no SGPR copies, and every
+        // load is consumed on the fall-through path, so the optimiser cannot sink it below the math.
+        Chunk<TokT> a, b;
+        a.load(p);
+        const int npairs = nfull >> 1;
+        int i = 0;  // chunk index held by `a`
         bool wide = false;
-        for (;;) {  // narrow loop
-            if (cur.or_hi() != 0) {
+        for (int j = 0; j < npairs; ++j) {
+            if (a.or_hi() != 0) {
                 wide = true;
                 break;
             }
-            const bool more = i + 1 < nfull;
-            Chunk<TokT> nxt;
-            nxt.load(p + (int64_t)(more ? i + 1 : i) * N);  // clamped: no branch around the load
-            __builtin_amdgcn_sched_barrier(0);              // keep the prefetch ahead of the math
-            hash_chunk<P, EXACT, false, TokT>(cur, pm, acc);
-            cur = nxt;
+            b.load(chunk_ptr(i + 1));           // prefetch (always a real chunk)
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the math
+            hash_chunk<P, EXACT, false, TokT>(a, pm, acc);
             ++i;
-            if (!more) break;
+            if (b.or_hi() != 0) {
+                a = b;
+                wide = true;
+                break;
+            }
+            a.load(chunk_ptr(i + 1));           // next pair's first chunk (clamped at the end)
+            __builtin_amdgcn_sched_barrier(0);
+            hash_chunk<P, EXACT, false, TokT>(b, pm, acc);
+            ++i;
         }
-        if (wide) {
-            for (;;) {
-                const bool more = i + 1 < nfull;
-                Chunk<TokT> nxt;
-                nxt.load(p + (int64_t)(more ? i + 1 : i) * N);
-                __builtin_amdgcn_sched_barrier(0);
-                hash_chunk<P, EXACT, true, TokT>(cur, pm, acc);
-                cur = nxt;
+        if (!wide && (nfull & 1)) {  // odd chunk left in `a`
+            if (a.or_hi() != 0) {
+                wide = true;
+            } else {
+                hash_chunk<P, EXACT, false, TokT>(a, pm, acc);
                 ++i;
-                if (!more) break;
+            }
+        }
+        if (wide) {  // `a` holds chunk i < nfull; rare path, plain double buffering
+            for (;;) {
+                b.load(chunk_ptr(i + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                hash_chunk<P, EXACT, true, TokT>(a, pm, acc);
+                a = b;
+                if (++i >= nfull) break;
             }
         }
     }
@@ -223,13 +244,14 @@ __device__ __forceinline__ void hash_range(const TokT MHX_CONST_AS *hv, int64_t 
 // Fast fold first; recompute exactly iff some lane's minimum lands in the ambiguous zone.
 template <int P, typename TokT>
 __device__ __forceinline__ void set_minima(const TokT MHX_CONST_AS *hv, int64_t beg, int64_t end,
-                                           const Perms<P> &pm, bool force_exact, uint32_t (&res)[P]) {
+                                           const Perms<P> &pm, const Perms<P> &pm_biased, bool force_exact,
+                                           uint32_t (&res)[P]) {
     bool redo = force_exact;
     if (!force_exact) {
         uint32_t acc[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) acc[p] = kMaxHash;
-        hash_range<P, false, TokT>(hv, beg, end, pm, acc);
+        hash_range<P, false, TokT>(hv, beg, end, pm_biased, acc);
         bool suspicious = false;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -247,7 +269,7 @@ __device__ __forceinline__ void set_minima(const TokT MHX_CONST_AS *hv, int64_t 
 
 template <int P>
 __device__ __forceinline__ void load_perms(const BulkArgs &args, int kbase, int lane, Perms<P> &pm,
-                                           int (&kidx)[P]) {
+                                           Perms<P> &pm_biased, int (&kidx)[P]) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const int k = kbase + p * kWave + lane;
@@ -256,6 +278,9 @@ __device__ __forceinline__ void load_perms(const BulkArgs &args, int kbase, int 
         pm.a_lo[p] = (uint32_t)a;
         pm.a_hi[p] = (uint32_t)(a >> 32);
         pm.b[p] = kidx[p] >= 0 ? args.b[k] : 0;
+        pm_biased.a_lo[p] = pm.a_lo[p];
+        pm_biased.a_hi[p] = pm.a_hi[p];
+        pm_biased.b[p] = pm.b[p] + 1;  // wraps mod 2^64 like everything else
     }
 }
 
@@ -266,9 +291,9 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_block = blockDim.x >> 6;
-    Perms<P> pm;
+    Perms<P> pm, pm_biased;
     int kidx[P];
-    load_perms<P>(args, blockIdx.y * (kWave * P), lane, pm, kidx);
+    load_perms<P>(args, blockIdx.y * (kWave * P), lane, pm, pm_biased, kidx);
 
     const TokT MHX_CONST_AS *hv = as_const(static_cast<const TokT *>(args.hv));
     const int64_t MHX_CONST_AS *offsets = as_const(args.offsets);
@@ -284,7 +309,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) 
             end = beg + args.fixed_len;
         }
         uint32_t res[P];
-        if (end > beg) set_minima<P, TokT>(hv, beg, end, pm, args.force_exact != 0, res);
+        if (end > beg) set_minima<P, TokT>(hv, beg, end, pm, pm_biased, args.force_exact != 0, res);
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             if (kidx[p] < 0) continue;
@@ -331,9 +356,9 @@ __global__ __launch_bounds__(256) void minhash_split_kernel(const BulkArgs args,
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_block = blockDim.x >> 6;
-    Perms<P> pm;
+    Perms<P> pm, pm_biased;
     int kidx[P];
-    load_perms<P>(args, blockIdx.y * (kWave * P), lane, pm, kidx);
+    load_perms<P>(args, blockIdx.y * (kWave * P), lane, pm, pm_biased, kidx);
     const TokT MHX_CONST_AS *hv = as_const(static_cast<const TokT *>(args.hv));
     const int64_t MHX_CONST_AS *offsets = as_const(args.offsets);
     OutT *__restrict__ out = static_cast<OutT *>(args.out);
@@ -362,7 +387,7 @@ __global__ __launch_bounds__(256) void minhash_split_kernel(const BulkArgs args,
             const int64_t beg = max(set_beg, s_beg), end = min(set_end, s_end);
             if (end <= beg) continue;
             uint32_t res[P];
-            set_minima<P, TokT>(hv, beg, end, pm, args.force_exact != 0, res);
+            set_minima<P, TokT>(hv, beg, end, pm, pm_biased, args.force_exact != 0, res);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 if (kidx[p] < 0) continue;

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 (ROCm 7.2, rocpd sqlite output) results as text for profiles/.
+
+    python tools/rocpd_summary.py gpurun_out/prof_<tag> > profiles/<name>.txt
+
+Kernel trace -> per-kernel calls / total / average duration; PMC passes -> per kernel, the mean
+over dispatches of every counter summed over its instances (dimensions).
+"""
+import glob
+import os
+import sqlite3
+import sys
+from collections import defaultdict
+
+
+def trace_summary(db):
+    con = sqlite3.connect(db)
+    rows = con.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc").fetchall()
+    total = sum(r[2] for r in rows) or 1
+    print(f"# kernel trace: {db}")
+    print(f"{'calls':>6} {'total_us':>12} {'avg_us':>10} {'min_us':>10} {'max_us':>10} {'pct':>6}  kernel")
+    for name, calls, tot, avg, mn, mx in rows:
+        print(f"{calls:6d} {tot/1e3:12.1f} {avg/1e3:10.1f} {mn/1e3:10.1f} {mx/1e3:10.1f} {100*tot/total:6.2f}  {name}")
+    for r in con.execute("select name, vgpr_count, accum_vgpr_count, sgpr_count, grid_x, grid_y, workgroup_x, lds_size, scratch_size from kernels group by name"):
+        print(f"#   {r[0][:90]}: vgpr={r[1]} agpr={r[2]} sgpr={r[3]} grid=({r[4]},{r[5]}) wg={r[6]} lds={r[7]} scratch={r[8]}")
+
+
+def pmc_summary(db):
+    con = sqlite3.connect(db)
+    per = defaultdict(lambda: defaultdict(float))  # (kernel, counter) -> dispatch -> sum over instances
+    for kernel, disp, counter, value in con.execute("select kernel_name, dispatch_id, counter_name, value from counters_collection"):
+        per[(kernel, counter)][disp] += value
+    print(f"# pmc: {db}")
+    for (kernel, counter), d in sorted(per.items()):
+        vals = list(d.values())
+        print(f"{counter:28s} mean/dispatch={sum(vals)/len(vals):18.1f}  dispatches={len(vals):3d}  {kernel[:80]}")
+
+
+def main():
+    root = sys.argv[1]
+    for db in sorted(glob.glob(os.path.join(root, "**", "*.db"), recursive=True)):
+        if "trace" in os.path.basename(os.path.dirname(db)):
+            trace_summary(db)
+        else:
+            pmc_summary(db)
+        print()
+
+
+if __name__ == "__main__":
+    main()
