@@ -49,6 +49,8 @@ struct mhx_ctx {
     int64_t opt_minhash_path = 0;   // 0 auto, 1 exact fold everywhere, 2 fast fold (+exact redo)
     int64_t opt_minhash_split = 0;  // 0 auto, 1 force wave-per-set, 2 force split-sets (atomic combine)
     int64_t opt_blocks_per_cu = 0;  // 0 auto
+    int64_t opt_minhash_prefetch = 1; // warm L2 with the next set's tokens (vector load per set)
+    int64_t opt_minhash_alias = -1; // profiling only: >= 0 makes set i read the tokens of set (i & mask)
     int64_t opt_weighted_rows = 0;  // 0 auto: rows per workgroup tile in the weighted kernel
 
     int ensure_scratch(int slot, size_t bytes);

@@ -37,6 +37,8 @@ struct BulkArgs {
     const uint64_t *b;
     int32_t num_perm;
     int32_t force_exact;
+    int32_t prefetch;        // warm the next set's tokens with a vector load (option minhash.prefetch)
+    int64_t alias_mask;      // profiling only (option minhash.alias): sets read tokens of set (i & mask); -1 = off
     const uint64_t *init;
     int64_t init_stride;
     void *out;
@@ -305,11 +307,27 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) 
             beg = offsets[set];
             end = offsets[set + 1];
         } else {
-            beg = set * args.fixed_len;
+            beg = (args.alias_mask >= 0 ? (set & args.alias_mask) : set) * args.fixed_len;
             end = beg + args.fixed_len;
+        }
+        // Warm L2 / Infinity Cache with the tokens of the set this wave hashes NEXT: one vector load
+        // per wave per set, lane l touching byte 128*l of that set (up to 8 KiB).  The scalar loads
+        // of the next iteration then hit on-chip instead of paying an HBM round trip each.
+        uint32_t warm = 0;
+        if (args.prefetch) {
+            const int64_t nset = set + stride;
+            if (nset < args.n_sets) {
+                const int64_t nbeg = args.offsets ? offsets[nset] : nset * args.fixed_len;
+                const int64_t nend = args.offsets ? offsets[nset + 1] : nbeg + args.fixed_len;
+                const int64_t off = (int64_t)lane * 128;
+                if (off < (nend - nbeg) * (int64_t)sizeof(TokT))
+                    warm = *reinterpret_cast<const volatile uint32_t *>(reinterpret_cast<const char *>(args.hv) +
+                                                                         nbeg * (int64_t)sizeof(TokT) + off);
+            }
         }
         uint32_t res[P];
         if (end > beg) set_minima<P, TokT>(hv, beg, end, pm, pm_biased, args.force_exact != 0, res);
+        asm volatile("" ::"v"(warm));  // the warm-up load retires here, a whole set later
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             if (kidx[p] < 0) continue;
@@ -473,6 +491,8 @@ int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const in
     args.b = perm->d_b;
     args.num_perm = perm->num_perm;
     args.force_exact = ctx->opt_minhash_path == 1;
+    args.alias_mask = ctx->opt_minhash_alias;
+    args.prefetch = ctx->opt_minhash_prefetch != 0;
     args.init = d_init;
     args.init_stride = init_stride;
     args.out = d_out;
