@@ -187,7 +187,7 @@ def main():
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
-        "traffic": None,
+        "traffic": measured_traffic(n, t, k, args),
         "kernel": "minhash_bulk_kernel",
         "kernel_ms": kernel_ms,
         "algorithmic_bytes_per_launch": alg_bytes,
@@ -206,6 +206,16 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def measured_traffic(n, t, k, args):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_traffic_minhash_bulk.json); None for any other shape."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic_minhash_bulk.json")
+    if (n, t, k) != (1_000_000, 256, 128) or args.u32 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get("traffic_bytes_per_launch")
 
 
 def cpu_baseline(O, tokens, a, b, sample, k, t):
