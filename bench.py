@@ -141,6 +141,11 @@ def main():
     launch_ms = [evs[i].elapsed_ms(evs[i + 1]) for i in range(args.steps)]
     kernel_ms = float(np.mean(launch_ms))
 
+    # ---- one counted launch outside the timed region: how often the sieve's proof failed
+    ctx.counters(True)
+    ctx.minhash_bulk_dev(perms, d_tok.ptr, tok_dtype, None, t, n, n * t, None, 0, d_out.ptr, out_dtype)
+    counters = ctx.counters(False)
+
     # ---- parity: rows spread over the whole matrix against the C oracle (bit-exact or fail)
     from oracle import oracle as O
 
@@ -176,6 +181,8 @@ def main():
             "signature_dtype": "uint32" if args.u32 else "uint64",
             "parallelism": f"shard{world}" + ("+allgather" if args.allgather else ""),
             "parity_rows_checked": int(check),
+            "sets_redone_by_full_evaluation": counters["sieve_sets_redone"],
+            "sets_redone_by_exact_fold": counters["exact_sets_redone"],
         },
     }
     alg_bytes = n * (tok_bytes * t + out_bytes * k)  # 8*T + 8*K per signature

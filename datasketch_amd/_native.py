@@ -34,6 +34,7 @@ _PROTOTYPES = {
     "mhx_ctx_synchronize": [_vp],
     "mhx_ctx_device_info": [_vp, ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_i64)],
     "mhx_ctx_set_option": [_vp, ctypes.c_char_p, _i64],
+    "mhx_ctx_counters": [_vp, _int, ctypes.POINTER(ctypes.c_uint64)],
     "mhx_dev_alloc": [_vp, _sz, ctypes.POINTER(_vp)],
     "mhx_dev_free": [_vp, _vp],
     "mhx_memcpy_h2d": [_vp, _vp, _vp, _sz],
@@ -248,6 +249,12 @@ class Context:
 
     def set_option(self, key: str, value: int) -> None:
         check(self.lib.mhx_ctx_set_option(self.handle, key.encode(), int(value)))
+
+    def counters(self, enable: bool = True) -> dict:
+        """Kernel event counters since the previous call (then reset); see mhx_ctx_counters."""
+        out = (ctypes.c_uint64 * 4)()
+        check(self.lib.mhx_ctx_counters(self.handle, 1 if enable else 0, out))
+        return {"sieve_sets_redone": int(out[0]), "exact_sets_redone": int(out[1]), "sieve_blocks": int(out[2])}
 
     def synchronize(self) -> None:
         check(self.lib.mhx_ctx_synchronize(self.handle))

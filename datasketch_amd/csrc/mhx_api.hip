@@ -123,6 +123,7 @@ int mhx_ctx_destroy(mhx_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < 4; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return MHX_OK;
@@ -154,6 +155,30 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "minhash.prefetch")) ctx->opt_minhash_prefetch = value;
     else if (!strcmp(key, "weighted.rows")) ctx->opt_weighted_rows = value;
     else return fail(MHX_ERR_INVALID, "unknown option '%s'", key);
+    return MHX_OK;
+}
+
+int mhx_ctx_counters(mhx_ctx *ctx, int enable, uint64_t out[MHX_NUM_COUNTERS]) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    if (int rc = ctx->activate()) return rc;
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (out) {
+        for (int i = 0; i < MHX_NUM_COUNTERS; ++i) out[i] = 0;
+        if (ctx->d_stats)
+            MHX_HIP_CHECK(hipMemcpy(out, ctx->d_stats, sizeof(uint64_t) * MHX_NUM_COUNTERS, hipMemcpyDeviceToHost));
+    }
+    if (enable && !ctx->d_stats) {
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), sizeof(uint64_t) * MHX_NUM_COUNTERS);
+        if (e != hipSuccess) {
+            ctx->d_stats = nullptr;
+            return fail(MHX_ERR_OOM, "counter allocation failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (!enable && ctx->d_stats) {
+        MHX_HIP_CHECK(hipFree(ctx->d_stats));
+        ctx->d_stats = nullptr;
+    }
+    if (ctx->d_stats) MHX_HIP_CHECK(hipMemset(ctx->d_stats, 0, sizeof(uint64_t) * MHX_NUM_COUNTERS));
     return MHX_OK;
 }
 

@@ -46,12 +46,15 @@ struct mhx_ctx {
     void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[4] = {0, 0, 0, 0};
     // options (mhx_ctx_set_option)
-    int64_t opt_minhash_path = 0;   // 0 auto, 1 exact fold everywhere, 2 fast fold (+exact redo)
+    int64_t opt_minhash_path = 0;   // 0 auto (sieve + fallbacks), 1 exact fold everywhere, 2 fast fold (+exact redo)
     int64_t opt_minhash_split = 0;  // 0 auto, 1 force wave-per-set, 2 force split-sets (atomic combine)
     int64_t opt_blocks_per_cu = 0;  // 0 auto
     int64_t opt_minhash_prefetch = 1; // warm L2 with the next set's tokens (vector load per set)
     int64_t opt_minhash_alias = -1; // profiling only: >= 0 makes set i read the tokens of set (i & mask)
     int64_t opt_weighted_rows = 0;  // 0 auto: rows per workgroup tile in the weighted kernel
+
+    // device counters of the MinHash kernels (mhx_ctx_counters); nullptr until counting is enabled
+    unsigned long long *d_stats = nullptr;
 
     int ensure_scratch(int slot, size_t bytes);
     int activate() const;

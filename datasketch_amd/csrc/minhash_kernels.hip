@@ -16,9 +16,14 @@
 //     (v_mad_u64_u32 + v_mul_lo_u32) and the Mersenne fold.  The common case uses a 3-op fold
 //     whose rare failure (probability 2^-29 per pair) is detected for free from the final
 //     minima; such a set is recomputed with the exact fold, so results are always bit-exact.
+//   * the default path does not even evaluate the full hash for most pairs: a "sieve" tracks
+//     minima of the LOW WORD of the hash in a 16x16 row/column arrangement of each 256-token
+//     block (one multiply and one v_min3 per pair), which pins down the one token that can hold
+//     the minimum AND proves that no other token is close enough to matter; only that token is
+//     hashed exactly.  Blocks where the proof fails fall back to the full evaluation below.
 //   * sets with few, long token lists (update_batch on one MinHash) are split over many waves
 //     and combined with 64-bit atomic min.
-// The kernel is VALU-bound (about 190 integer ops per input byte), not HBM-bound.
+// The kernel is VALU-bound (about 100 integer ops per input byte), not HBM-bound.
 #include "mhx_internal.h"
 
 namespace mhx {
@@ -36,7 +41,9 @@ struct BulkArgs {
     const uint64_t *a;
     const uint64_t *b;
     int32_t num_perm;
-    int32_t force_exact;
+    int32_t path;            // 0 sieve (+ fallbacks), 1 exact fold everywhere, 2 fast fold (+ exact redo)
+    unsigned long long *stats;  // optional device counters: [0] sets redone after a failed sieve proof,
+                                // [1] sets redone with the exact fold, [2] sieve blocks evaluated
     int32_t prefetch;        // warm the next set's tokens with a vector load (option minhash.prefetch)
     int64_t alias_mask;      // profiling only (option minhash.alias): sets read tokens of set (i & mask); -1 = off
     const uint64_t *init;
@@ -124,6 +131,10 @@ struct Chunk<uint64_t> {
     }
     __device__ __forceinline__ uint32_t lo(int i) const { return w[2 * i]; }
     __device__ __forceinline__ uint32_t hi(int i) const { return w[2 * i + 1]; }
+    // the sieve reads low words only; this keeps the fetch one s_load_dwordx16 instead of 8 s_load_dword
+    __device__ __forceinline__ void keep_whole() const {
+        asm volatile("" ::"s"(w[1]), "s"(w[3]), "s"(w[5]), "s"(w[7]), "s"(w[9]), "s"(w[11]), "s"(w[13]), "s"(w[15]));
+    }
 };
 template <>
 struct Chunk<uint32_t> {
@@ -136,6 +147,7 @@ struct Chunk<uint32_t> {
     __device__ __forceinline__ uint32_t or_hi() const { return 0; }
     __device__ __forceinline__ uint32_t lo(int i) const { return v[i]; }
     __device__ __forceinline__ uint32_t hi(int) const { return 0; }
+    __device__ __forceinline__ void keep_whole() const {}
 };
 
 template <int P, bool EXACT, bool WIDE, typename TokT>
@@ -242,14 +254,223 @@ __device__ __forceinline__ void hash_range(const TokT MHX_CONST_AS *hv, int64_t 
     }
 }
 
-// min over tokens [beg,end) of the exact fold, for the P permutations of this lane.
-// Fast fold first; recompute exactly iff some lane's minimum lands in the ambiguous zone.
+// ---- sieve: find the minimum without hashing every pair ------------------------------------
+// The exact value of a pair is R = fold_exact(s) = s_lo + top + ge (mod 2^32) with top = s >> 61
+// <= 7 and ge <= 1, and s_lo = lo32(h_lo * a_lo + b_lo) needs ONE multiply, whatever the high
+// words of h, a and b are.  With the key  M = lo32(h_lo*a_lo + b_lo + 8)  (bias 8, see below):
+//     R + 8 = M + e,  0 <= e <= 8,  without wrap-around, for EVERY token of a block whose
+//     smallest key is >= 16  (no token then has s_lo in [2^32-8, 2^32), the only place where
+//     s_lo + top + ge can wrap).
+// So the token with the smallest R is among the tokens with M <= min M + 8.  A block of up to 256
+// tokens is laid out as a 16 x 16 grid (row, column), every token in exactly one cell, and the
+// kernel keeps min M per row and per column: one v_mad_u64_u32 and two half v_min3_u32 per pair
+// instead of two multiplies, shift, add and half a min3.  Row/column minima are tagged with
+// their index in the low 4 bits (key & ~15 | idx); with k1 < k2 the two smallest tagged values,
+// k2 - k1 >= 32 proves that every token outside the best row (column) has M >= min M + 17.  If
+// that holds for rows and columns, cell (best row, best column) is the ONLY token with
+// M <= min M + 16: it alone is fetched (one per-lane load) and hashed exactly.  If any proof
+// fails in any lane (equal tokens at the minimum, two keys within 32, min key < 16, probability
+// about 1e-5 per set of distinct random tokens) the whole set is redone by the full evaluation,
+// so results stay bit-exact unconditionally.
+// Grid mapping for token w of a 32-token group g (8 quads of 4 consecutive tokens):
+//     row = 2*g + bit1(w),  column = 2*(w >> 2) + bit0(w)
+// i.e. a quad {w, w+1, w+2, w+3} covers rows {r, r, r+1, r+1} and columns {c, c+1, c, c+1}: both
+// v_min3 of a quad take two fresh keys, and all column indices are compile-time constants.
+constexpr int kGroupTokens = 32;
+constexpr int kBlockGroups = 8;  // 16 rows
+
+__device__ __forceinline__ uint32_t sieve_key(uint32_t h, uint32_t a_lo, uint64_t b8) {
+    // Only the low word is used, but one v_mad_u64_u32 beats v_mul_lo_u32 + v_add_u32; the empty
+    // asm keeps the optimiser from narrowing the 64-bit multiply-add.
+    uint64_t r = (uint64_t)h * a_lo + b8;
+    asm("" : "+v"(r));
+    return (uint32_t)r;
+}
+__device__ __forceinline__ uint32_t umed3(uint32_t x, uint32_t y, uint32_t z) {
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+    return r;
+}
+__device__ __forceinline__ uint32_t umin3(uint32_t x, uint32_t y, uint32_t z) { return min(min(x, y), z); }
+__device__ __forceinline__ uint32_t tag16(uint32_t key, uint32_t idx) { return (key & ~15u) | idx; }  // v_and_or_b32
+
+template <int P>
+struct SievePerms {
+    uint32_t a_lo[P];
+    uint64_t b8[P];  // b + 8 (only the low word matters)
+    bool active[P];  // lane holds a real permutation (k < num_perm)
+};
+
+// One chunk of a group: quads QBASE .. QBASE + N/4 - 1 of the group.
+template <int P, typename TokT, int QBASE>
+__device__ __forceinline__ void sieve_chunk(const Chunk<TokT> &c, const SievePerms<P> &sp, uint32_t (&row)[P][2],
+                                            uint32_t (&col)[P][16]) {
+    constexpr int N = Chunk<TokT>::N;
+    c.keep_whole();
+#pragma unroll
+    for (int q = 0; q < N / 4; ++q) {
+        const int qd = QBASE + q;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const uint32_t m00 = sieve_key(c.lo(4 * q + 0), sp.a_lo[p], sp.b8[p]);
+            const uint32_t m01 = sieve_key(c.lo(4 * q + 1), sp.a_lo[p], sp.b8[p]);
+            const uint32_t m10 = sieve_key(c.lo(4 * q + 2), sp.a_lo[p], sp.b8[p]);
+            const uint32_t m11 = sieve_key(c.lo(4 * q + 3), sp.a_lo[p], sp.b8[p]);
+            if (qd == 0) {  // first quad of the group starts its two rows
+                row[p][0] = min(m00, m01);
+                row[p][1] = min(m10, m11);
+            } else {
+                row[p][0] = umin3(row[p][0], m00, m01);
+                row[p][1] = umin3(row[p][1], m10, m11);
+            }
+            col[p][2 * qd] = umin3(col[p][2 * qd], m00, m10);
+            col[p][2 * qd + 1] = umin3(col[p][2 * qd + 1], m01, m11);
+        }
+        // pin the column updates here: left alone, the optimiser sinks all of them to the end of
+        // the group and keeps every key of the group live (200 VGPRs)
+        if constexpr (P == 1)
+            asm volatile("" : "+v"(col[0][2 * qd]), "+v"(col[0][2 * qd + 1]));
+        else
+            asm volatile("" : "+v"(col[0][2 * qd]), "+v"(col[0][2 * qd + 1]), "+v"(col[P - 1][2 * qd]),
+                         "+v"(col[P - 1][2 * qd + 1]));
+        __builtin_amdgcn_sched_barrier(0);  // one quad at a time: 4P keys live, not 4P * N/4
+    }
+}
+
+// Exact minima over the first ngroups*32 tokens of [beg, ...) into res (min-combined); returns
+// true in lanes whose proof failed (the caller redoes the set).  All arguments wave-uniform
+// except the per-lane permutation registers.
 template <int P, typename TokT>
-__device__ __forceinline__ void set_minima(const TokT MHX_CONST_AS *hv, int64_t beg, int64_t end,
-                                           const Perms<P> &pm, const Perms<P> &pm_biased, bool force_exact,
-                                           uint32_t (&res)[P]) {
-    bool redo = force_exact;
-    if (!force_exact) {
+__device__ __forceinline__ bool sieve_range(const TokT MHX_CONST_AS *hv, const TokT *hv_vec, int64_t beg,
+                                            int ngroups, const Perms<P> &pm, const SievePerms<P> &sp,
+                                            uint32_t (&res)[P], int &nblocks) {
+    constexpr int N = Chunk<TokT>::N;
+    constexpr int CPG = kGroupTokens / N;  // chunks per group: 4 (uint64 tokens) or 2 (uint32)
+    const TokT MHX_CONST_AS *p = hv + beg;
+    const int nchunks = ngroups * CPG;
+    const auto chunk_ptr = [&](int idx) { return p + (int64_t)(idx < nchunks ? idx : nchunks - 1) * N; };
+    Chunk<TokT> a, b;
+    a.load(p);
+    int ci = 0;  // chunk held by `a`
+    bool fail = false;
+    for (int g0 = 0; g0 < ngroups; g0 += kBlockGroups) {
+        const int gb = min(kBlockGroups, ngroups - g0);
+        uint32_t col[P][16], k1r[P], k2r[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) col[q][j] = kMaxHash;
+            k1r[q] = kMaxHash;
+            k2r[q] = kMaxHash;
+        }
+        for (int g = 0; g < gb; ++g) {
+            uint32_t row[P][2];
+            if constexpr (CPG == 4) {
+                b.load(chunk_ptr(ci + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                sieve_chunk<P, TokT, 0>(a, sp, row, col);
+                a.load(chunk_ptr(ci + 2));
+                __builtin_amdgcn_sched_barrier(0);
+                sieve_chunk<P, TokT, 2>(b, sp, row, col);
+                b.load(chunk_ptr(ci + 3));
+                __builtin_amdgcn_sched_barrier(0);
+                sieve_chunk<P, TokT, 4>(a, sp, row, col);
+                a.load(chunk_ptr(ci + 4));
+                __builtin_amdgcn_sched_barrier(0);
+                sieve_chunk<P, TokT, 6>(b, sp, row, col);
+            } else {
+                b.load(chunk_ptr(ci + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                sieve_chunk<P, TokT, 0>(a, sp, row, col);
+                a.load(chunk_ptr(ci + 2));
+                __builtin_amdgcn_sched_barrier(0);
+                sieve_chunk<P, TokT, 4>(b, sp, row, col);
+            }
+            ci += CPG;
+            // the two rows of this group are complete: fold them into (smallest, second smallest)
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const uint32_t key = tag16(row[q][r], (uint32_t)(2 * g + r));
+                    k2r[q] = umed3(k1r[q], k2r[q], key);
+                    k1r[q] = min(k1r[q], key);
+                }
+            }
+        }
+        // block complete: columns, proofs, the one candidate token per permutation
+        const int64_t blk = beg + (int64_t)g0 * kGroupTokens;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            uint32_t key[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) key[j] = tag16(col[q][j], (uint32_t)j);
+            uint32_t k1c = umin3(key[0], key[1], key[2]);
+#pragma unroll
+            for (int j = 3; j < 15; j += 2) k1c = umin3(k1c, key[j], key[j + 1]);
+            k1c = min(k1c, key[15]);
+            // second smallest: key - (k1c + 1) wraps to 2^32-1 for the smallest itself
+            const uint32_t t = k1c + 1u;
+            uint32_t dmin = umin3(key[0] - t, key[1] - t, key[2] - t);
+#pragma unroll
+            for (int j = 3; j < 15; j += 2) dmin = umin3(dmin, key[j] - t, key[j + 1] - t);
+            dmin = min(dmin, key[15] - t);
+            const bool ok = (dmin >= 31u) && (k2r[q] - k1r[q] >= 32u) && (k1c >= 16u);
+            fail |= sp.active[q] && !ok;
+            const uint32_t i1 = k1r[q] & 15u, j1 = k1c & 15u;
+            const uint32_t w = ((i1 >> 1) << 5) | ((j1 >> 1) << 2) | ((i1 & 1u) << 1) | (j1 & 1u);
+            const uint64_t tok = hv_vec[blk + w];  // per-lane gather, always inside the block
+            uint32_t l0, h0;
+            mad_wide((uint32_t)tok, (uint32_t)(tok >> 32), pm.a_lo[q], pm.a_hi[q], pm.b[q], l0, h0);
+            res[q] = min(res[q], fold_exact(l0, h0));
+        }
+        ++nblocks;
+    }
+    return fail;
+}
+
+__device__ __forceinline__ void bump(unsigned long long *stats, int slot, int lane, unsigned long long by = 1) {
+    if (stats && lane == 0) atomicAdd(stats + slot, by);
+}
+
+// min over tokens [beg,end) of the exact fold, for the P permutations of this lane.
+//   path 0: sieve over the full 32-token groups + fast fold for the ragged tail; a failed proof
+//           (or a suspicious fast-fold minimum) sends the whole set to path 2
+//   path 2: fast fold; recompute exactly iff some lane's minimum lands in the ambiguous zone
+//   path 1: exact fold
+template <int P, typename TokT>
+__device__ __forceinline__ void set_minima(const TokT MHX_CONST_AS *hv, const TokT *hv_vec, int64_t beg,
+                                           int64_t end, const Perms<P> &pm, const Perms<P> &pm_biased,
+                                           const SievePerms<P> &sp, int path, unsigned long long *stats,
+                                           int lane, uint32_t (&res)[P]) {
+    bool redo_fast = path == 2, redo_exact = path == 1;
+    if (path == 0) {
+        const int64_t n = end - beg;
+        const int ngroups = (int)min(n / kGroupTokens, (int64_t)(1 << 26));
+#pragma unroll
+        for (int p = 0; p < P; ++p) res[p] = kMaxHash;
+        bool bad = false;
+        if (ngroups > 0) {
+            int nblocks = 0;
+            bad = sieve_range<P, TokT>(hv, hv_vec, beg, ngroups, pm, sp, res, nblocks);
+            bump(stats, 2, lane, (unsigned long long)nblocks);
+        }
+        const int64_t tail = beg + (int64_t)ngroups * kGroupTokens;
+        if (tail < end) {
+            uint32_t acc[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) acc[p] = kMaxHash;
+            hash_range<P, false, TokT>(hv, tail, end, pm_biased, acc);
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                bad |= sp.active[p] && acc[p] <= 7u;
+                res[p] = min(res[p], acc[p] - 1u);
+            }
+        }
+        redo_fast = __any(bad);
+        if (redo_fast) bump(stats, 0, lane);
+    }
+    if (redo_fast) {
         uint32_t acc[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) acc[p] = kMaxHash;
@@ -257,12 +478,13 @@ __device__ __forceinline__ void set_minima(const TokT MHX_CONST_AS *hv, int64_t 
         bool suspicious = false;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            suspicious |= acc[p] <= 7u;
+            suspicious |= sp.active[p] && acc[p] <= 7u;
             res[p] = acc[p] - 1u;
         }
-        redo = __any(suspicious);
+        redo_exact = __any(suspicious);
     }
-    if (redo) {
+    if (redo_exact) {
+        bump(stats, 1, lane);
 #pragma unroll
         for (int p = 0; p < P; ++p) res[p] = kMaxHash;
         hash_range<P, true, TokT>(hv, beg, end, pm, res);
@@ -271,7 +493,7 @@ __device__ __forceinline__ void set_minima(const TokT MHX_CONST_AS *hv, int64_t 
 
 template <int P>
 __device__ __forceinline__ void load_perms(const BulkArgs &args, int kbase, int lane, Perms<P> &pm,
-                                           Perms<P> &pm_biased, int (&kidx)[P]) {
+                                           Perms<P> &pm_biased, SievePerms<P> &sp, int (&kidx)[P]) {
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const int k = kbase + p * kWave + lane;
@@ -283,21 +505,28 @@ __device__ __forceinline__ void load_perms(const BulkArgs &args, int kbase, int 
         pm_biased.a_lo[p] = pm.a_lo[p];
         pm_biased.a_hi[p] = pm.a_hi[p];
         pm_biased.b[p] = pm.b[p] + 1;  // wraps mod 2^64 like everything else
+        sp.a_lo[p] = pm.a_lo[p];
+        sp.b8[p] = pm.b[p] + 8;
+        sp.active[p] = kidx[p] >= 0;
     }
 }
 
 // ---- kernel A: one wave per set -------------------------------------------------------------
-// grid.x strides over sets, grid.y = permutation chunk (64*P permutations each).
+// grid.x strides over sets; a wave walks the permutations of its set in chunks of 64*P (the
+// set's tokens stay in the scalar cache / L2 between chunks), so a [K] row is written by one wave.
 template <int P, typename TokT, typename OutT>
 __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_block = blockDim.x >> 6;
+    const int kchunks = (args.num_perm + kWave * P - 1) / (kWave * P);
     Perms<P> pm, pm_biased;
+    SievePerms<P> sp;
     int kidx[P];
-    load_perms<P>(args, blockIdx.y * (kWave * P), lane, pm, pm_biased, kidx);
+    load_perms<P>(args, 0, lane, pm, pm_biased, sp, kidx);
 
     const TokT MHX_CONST_AS *hv = as_const(static_cast<const TokT *>(args.hv));
+    const TokT *hv_vec = static_cast<const TokT *>(args.hv);
     const int64_t MHX_CONST_AS *offsets = as_const(args.offsets);
     OutT *__restrict__ out = static_cast<OutT *>(args.out);
     const int64_t stride = (int64_t)gridDim.x * waves_per_block;
@@ -325,27 +554,31 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) 
                                                                          nbeg * (int64_t)sizeof(TokT) + off);
             }
         }
-        uint32_t res[P];
-        if (end > beg) set_minima<P, TokT>(hv, beg, end, pm, pm_biased, args.force_exact != 0, res);
-        asm volatile("" ::"v"(warm));  // the warm-up load retires here, a whole set later
+        for (int kc = 0; kc < kchunks; ++kc) {
+            if (kchunks > 1) load_perms<P>(args, kc * (kWave * P), lane, pm, pm_biased, sp, kidx);
+            uint32_t res[P];
+            if (end > beg)
+                set_minima<P, TokT>(hv, hv_vec, beg, end, pm, pm_biased, sp, args.path, args.stats, lane, res);
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            if (kidx[p] < 0) continue;
-            uint64_t v;
-            if (args.init) {
-                const uint64_t iv = args.init[set * args.init_stride + kidx[p]];
-                if (end > beg) {
-                    const uint32_t ic = (iv >> 32) ? kMaxHash : (uint32_t)iv;
-                    v = min(ic, res[p]);
+            for (int p = 0; p < P; ++p) {
+                if (kidx[p] < 0) continue;
+                uint64_t v;
+                if (args.init) {
+                    const uint64_t iv = args.init[set * args.init_stride + kidx[p]];
+                    if (end > beg) {
+                        const uint32_t ic = (iv >> 32) ? kMaxHash : (uint32_t)iv;
+                        v = min(ic, res[p]);
+                    } else {
+                        v = iv;  // empty set: state untouched (minhash.py:265-266)
+                    }
                 } else {
-                    v = iv;  // empty set: state untouched (minhash.py:265-266)
+                    v = end > beg ? res[p] : kMaxHash;
                 }
-            } else {
-                v = end > beg ? res[p] : kMaxHash;
+                if (sizeof(OutT) == 4) v = v > kMaxHash ? kMaxHash : v;
+                out[set * args.num_perm + kidx[p]] = (OutT)v;
             }
-            if (sizeof(OutT) == 4) v = v > kMaxHash ? kMaxHash : v;
-            out[set * args.num_perm + kidx[p]] = (OutT)v;
         }
+        asm volatile("" ::"v"(warm));  // the warm-up load retires here, a whole set later
     }
 }
 
@@ -375,9 +608,11 @@ __global__ __launch_bounds__(256) void minhash_split_kernel(const BulkArgs args,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_block = blockDim.x >> 6;
     Perms<P> pm, pm_biased;
+    SievePerms<P> sp;
     int kidx[P];
-    load_perms<P>(args, blockIdx.y * (kWave * P), lane, pm, pm_biased, kidx);
+    load_perms<P>(args, blockIdx.y * (kWave * P), lane, pm, pm_biased, sp, kidx);
     const TokT MHX_CONST_AS *hv = as_const(static_cast<const TokT *>(args.hv));
+    const TokT *hv_vec = static_cast<const TokT *>(args.hv);
     const int64_t MHX_CONST_AS *offsets = as_const(args.offsets);
     OutT *__restrict__ out = static_cast<OutT *>(args.out);
 
@@ -405,7 +640,7 @@ __global__ __launch_bounds__(256) void minhash_split_kernel(const BulkArgs args,
             const int64_t beg = max(set_beg, s_beg), end = min(set_end, s_end);
             if (end <= beg) continue;
             uint32_t res[P];
-            set_minima<P, TokT>(hv, beg, end, pm, pm_biased, args.force_exact != 0, res);
+            set_minima<P, TokT>(hv, hv_vec, beg, end, pm, pm_biased, sp, args.path, args.stats, lane, res);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 if (kidx[p] < 0) continue;
@@ -445,7 +680,7 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t total_tokens, bool 
     const int64_t max_blocks = (int64_t)ctx->num_cus * blocks_per_cu;
     if (!split) {
         const int64_t want = (args.n_sets + 3) / 4;
-        dim3 grid((unsigned)std::max<int64_t>(1, std::min(want, max_blocks)), (unsigned)kchunks);
+        dim3 grid((unsigned)std::max<int64_t>(1, std::min(want, max_blocks)), 1u);  // wave loops over kchunks
         hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT>), grid, dim3(256), 0, ctx->stream, args);
     } else {
         const int64_t total_out = args.n_sets * (int64_t)args.num_perm;
@@ -468,11 +703,9 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t total_tokens, bool 
 
 template <typename TokT, typename OutT>
 int launch_p(mhx_ctx *ctx, const BulkArgs &args, int64_t total_tokens, bool split) {
-    const int k = args.num_perm;
-    if (k <= 64) return launch_typed<1, TokT, OutT>(ctx, args, total_tokens, split);
-    if (k <= 128) return launch_typed<2, TokT, OutT>(ctx, args, total_tokens, split);
-    if (k <= 256 || (k > 512 && k <= 768)) return launch_typed<4, TokT, OutT>(ctx, args, total_tokens, split);
-    return launch_typed<8, TokT, OutT>(ctx, args, total_tokens, split);
+    // P permutations per lane: 1 for K <= 64, else 2 (K > 128 walks ceil(K/128) chunks per set)
+    if (args.num_perm <= 64) return launch_typed<1, TokT, OutT>(ctx, args, total_tokens, split);
+    return launch_typed<2, TokT, OutT>(ctx, args, total_tokens, split);
 }
 
 }  // namespace
@@ -490,7 +723,8 @@ int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const in
     args.a = perm->d_a;
     args.b = perm->d_b;
     args.num_perm = perm->num_perm;
-    args.force_exact = ctx->opt_minhash_path == 1;
+    args.path = (int32_t)ctx->opt_minhash_path;
+    args.stats = ctx->d_stats;
     args.alias_mask = ctx->opt_minhash_alias;
     args.prefetch = ctx->opt_minhash_prefetch != 0;
     args.init = d_init;

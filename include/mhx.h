@@ -62,8 +62,16 @@ MHX_API int mhx_ctx_destroy(mhx_ctx *ctx);
 MHX_API int mhx_ctx_synchronize(mhx_ctx *ctx);
 /* name: caller buffer (may be NULL); cus: compute units; hbm_bytes: total device memory */
 MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus, int64_t *hbm_bytes);
-/* Tuning / test knobs, e.g. ("minhash.path", 0=auto 1=exact-fold 2=fast-fold, 3=split-sets). */
+/* Tuning / test knobs: ("minhash.path", 0 = auto: sieve with full-evaluation fallback,
+ * 1 = exact fold for every pair, 2 = fast fold with exact redo), ("minhash.split", 0 auto,
+ * 1 wave per set, 2 split sets over waves), ("blocks_per_cu", n), ("minhash.prefetch", 0/1). */
 MHX_API int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value);
+/* Kernel event counters since the last call (synchronises the stream, then resets them):
+ *   out[0] sets whose sieve proof failed and were redone with the full evaluation,
+ *   out[1] sets redone with the exact fold, out[2] 256-token sieve blocks evaluated, out[3] 0.
+ * enable != 0 starts/keeps counting, 0 stops it (counting costs one atomic per event). */
+#define MHX_NUM_COUNTERS 4
+MHX_API int mhx_ctx_counters(mhx_ctx *ctx, int enable, uint64_t out[MHX_NUM_COUNTERS]);
 
 /* ---- device memory + events (so callers can keep corpora resident and time kernels) ------- */
 MHX_API int mhx_dev_alloc(mhx_ctx *ctx, size_t bytes, void **dptr);

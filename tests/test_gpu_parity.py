@@ -223,6 +223,91 @@ def test_fold_boundaries_exhaustive(ctx):
         ctx.set_option("minhash.path", 0)
 
 
+# ------------------------------------------------------------------ sieve path (minhash.path = 0)
+@pytest.mark.parametrize("t", [31, 32, 33, 63, 64, 65, 255, 256, 257, 287, 288, 511, 512, 513, 1000, 5000])
+@pytest.mark.parametrize("k", [64, 128])
+def test_sieve_block_boundaries(ctx, t, k):
+    """Set lengths around the 32-token group and 256-token block edges, uint64 and uint32 tokens."""
+    rng = np.random.RandomState(t + k)
+    n = 300
+    tok = rng.randint(0, 2**32, (n, t), dtype=np.uint64)
+    tok[::7, t // 2] = rng.randint(2**32, 2**64, len(tok[::7]), dtype=np.uint64)  # some wide tokens
+    a, b = O.np_init_permutations(k, 3)
+    want = O.c_minhash_bulk_dense(tok, a, b)
+    assert np.array_equal(ctx.minhash_bulk((a, b), tok.reshape(-1), None, t, n), want)
+    tok32 = (tok & 0xFFFFFFFF).astype(np.uint32)
+    want32 = O.c_minhash_bulk_dense(tok32.astype(np.uint64), a, b)
+    d_tok, d_out = ctx.to_device(tok32), ctx.alloc(n * k * 8)
+    ctx.minhash_bulk_dev((a, b), d_tok.ptr, _native.MHX_U32, None, t, n, n * t, None, 0, d_out.ptr, _native.MHX_U64)
+    ctx.synchronize()
+    assert np.array_equal(d_out.download((n, k), np.uint64), want32)
+
+
+def test_sieve_duplicates_and_constant_sets(ctx):
+    """Equal tokens defeat the sieve's uniqueness proof: those sets must come out right through
+    the fallback, and the counters must show that the fallback ran."""
+    rng = np.random.RandomState(12)
+    n, t, k = 400, 256, 128
+    tok = rng.randint(0, 2**32, (n, t), dtype=np.uint64)
+    tok[:100, 128:] = tok[:100, :128]            # every token twice
+    tok[100:150] = tok[100:150, :1]              # one token repeated 256 times
+    tok[150:200, ::3] = tok[150:200, 1:2]        # a third of the set is one token
+    tok[200:250, 17] = tok[200:250, 200]         # a single duplicated pair
+    a, b = O.np_init_permutations(k, 9)
+    want = O.c_minhash_bulk_dense(tok, a, b)
+    ctx.set_option("minhash.split", 1)  # wave per set, so that the counters count sets
+    ctx.counters(True)
+    got = ctx.minhash_bulk((a, b), tok.reshape(-1), None, t, n)
+    c = ctx.counters(False)
+    ctx.set_option("minhash.split", 0)
+    assert np.array_equal(got, want)
+    assert c["sieve_blocks"] == n and 200 <= c["sieve_sets_redone"] <= 260, c
+    assert np.array_equal(ctx.minhash_bulk((a, b), tok.reshape(-1), None, t, n), want)  # split over waves
+
+
+def test_sieve_counters_on_random_sets(ctx):
+    """Distinct random tokens: the proof almost never fails (that is what makes the path fast)."""
+    n, t, k = 20000, 256, 128
+    tok = np.random.RandomState(5).randint(0, 2**32, (n, t), dtype=np.uint64)
+    a, b = O.np_init_permutations(k, 1)
+    ctx.counters(True)
+    got = ctx.minhash_bulk((a, b), tok.reshape(-1), None, t, n)
+    c = ctx.counters(False)
+    assert np.array_equal(got, O.c_minhash_bulk_dense(tok, a, b))
+    assert c["sieve_blocks"] == n and c["sieve_sets_redone"] <= n // 200 and c["exact_sets_redone"] <= 5, c
+
+
+def test_sieve_adversarial_near_minima(ctx):
+    """Two tokens whose low hash words differ by d = 1..48 at the very bottom of the range (so they
+    are the two smallest keys of the set), including low words in [2^32-8, 2^32) where the exact
+    value wraps around; wide variants change the top bits.  Every proof outcome is exercised."""
+    k = 128
+    a, b = O.np_init_permutations(k, 4)
+    rng = np.random.RandomState(2)
+    sets = []
+    for pi in range(0, 24):
+        a_lo, b_lo = int(a[pi]) & 0xFFFFFFFF, int(b[pi]) & 0xFFFFFFFF
+        if a_lo % 2 == 0:
+            continue
+        inv = pow(a_lo, -1, 1 << 32)
+        for base in (2**32 - 9, 2**32 - 8, 2**32 - 1, 0, 1, 7, 8, 9, 15, 16, 17, 40, 1000):
+            for d in (0, 1, 7, 8, 9, 15, 16, 17, 31, 32, 33, 48):
+                lows = [(base - b_lo) * inv % 2**32, (base + d - b_lo) * inv % 2**32]  # s_lo = base, base + d
+                for wide in (False, True):
+                    toks = [lo | ((int(rng.randint(0, 2**32)) << 32) if wide else 0) for lo in lows]
+                    filler = rng.randint(0, 2**32, 254, dtype=np.uint64)
+                    s = np.concatenate([filler, np.array(toks, dtype=np.uint64)])
+                    rng.shuffle(s)
+                    sets.append(s)
+    tok = np.stack(sets)
+    want = O.c_minhash_bulk_dense(tok, a, b)
+    for path in (0, 2):
+        ctx.set_option("minhash.path", path)
+        got = ctx.minhash_bulk((a, b), tok.reshape(-1), None, 256, len(sets))
+        ctx.set_option("minhash.path", 0)
+        assert np.array_equal(got, want), path
+
+
 def test_initial_state_variants(ctx):
     rng = np.random.RandomState(9)
     k, n = 128, 400

@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""tools/bench_extra.py -- device-resident timings of the non-headline kernels (DESIGN.md numbers).
+
+    python tools/bench_extra.py [--weighted-rows 20000] [--sigs 1000000]
+
+Prints one JSON object per measurement: kernel-only time from HIP events on the context's stream,
+algorithmic bytes and the implied GB/s.  Every result is first checked
+against the oracle on a sample.  Not the driver's bench (that is bench.py).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from datasketch_amd import WeightedMinHashGenerator, _native  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def timed(ctx, fn, reps=5, warmup=1):
+    for _ in range(warmup):
+        fn()
+    ctx.synchronize()
+    evs = [ctx.event() for _ in range(reps + 1)]
+    evs[0].record()
+    for i in range(reps):
+        fn()
+        evs[i + 1].record()
+    ctx.synchronize()
+    return float(np.median([evs[i].elapsed_ms(evs[i + 1]) for i in range(reps)]))
+
+
+def report(name, ms, units, unit_name, alg_bytes, **extra):
+    out = {"name": name, "ms": round(ms, 4), f"{unit_name}_per_s": units / (ms * 1e-3), "algorithmic_GBps": alg_bytes / (ms * 1e-3) / 1e9,
+           "hbm_frac_of_8TBps": alg_bytes / (ms * 1e-3) / 8e12}
+    out.update(extra)
+    print(json.dumps(out), flush=True)
+
+
+def weighted(ctx, n_rows, dim, s, density):
+    rng = np.random.RandomState(42)
+    g = WeightedMinHashGenerator(dim, s, seed=1, gpu_mode="always")
+    x = rng.uniform(0, 100, (n_rows, dim)).astype(np.float32)
+    if density < 1.0:
+        x[rng.random_sample(x.shape) >= density] = 0
+    import scipy.sparse as sp
+
+    csr = sp.csr_matrix(x)
+    csr.sort_indices()
+    indptr, indices = csr.indptr.astype(np.int64), csr.indices.astype(np.int32)
+    logs = np.log(csr.data)
+    _, handle = g._device_handle()
+    d_ptr, d_idx, d_val = ctx.to_device(indptr), ctx.to_device(indices), ctx.to_device(logs)
+    d_out, d_ne = ctx.alloc(n_rows * s * 16), ctx.alloc(n_rows)
+    lib = ctx.lib
+
+    def run():
+        _native.check(lib.mhx_weighted_minhash_many_dev(handle, d_ptr.ptr, d_idx.ptr, d_val.ptr, 1, n_rows, indices.size, d_out.ptr, d_ne.ptr))
+
+    ms = timed(ctx, run, reps=3)
+    got = d_out.download((n_rows, s, 2), np.int64)
+    chk = min(n_rows, 64)
+    want, _ = O.c_weighted_minhash_many(indptr[: chk + 1], indices[: indptr[chk]], csr.data[: indptr[chk]], g.rs, g.ln_cs, g.betas)
+    assert np.array_equal(got[:chk], want), "weighted parity failure"
+    nnz = int(indices.size)
+    report(f"weighted_minhash_many dim={dim} S={s} density={density}", ms, n_rows, "vectors", 4 * nnz + 16 * s * n_rows,
+           rows=n_rows, nnz=nnz, evals_per_s=nnz * s / (ms * 1e-3))
+
+
+def packing(ctx, n, k):
+    rng = np.random.RandomState(1)
+    sig = rng.randint(0, 2**32, (n, k), dtype=np.uint64)
+    d_sig = ctx.to_device(sig)
+    lib = ctx.lib
+    for b in (1, 4, 16):
+        nb = ctypes.c_int32(0)
+        _native.check(lib.mhx_bbit_num_blocks(k, b, ctypes.byref(nb)))
+        d_out = ctx.alloc(n * nb.value * 8)
+        ms = timed(ctx, lambda: _native.check(lib.mhx_bbit_pack_dev(ctx.handle, d_sig.ptr, n, k, b, d_out.ptr)))
+        got = d_out.download((n, nb.value), np.uint64)
+        assert np.array_equal(got[:512], O.c_bbit_pack(sig[:512], b))
+        report(f"bbit_pack b={b} K={k}", ms, n, "signatures", n * (8 * k + 8 * nb.value))
+    for bands, r in ((32, 8), (k // 4, 4)):
+        d_out = ctx.alloc(n * bands * r * 8)
+        ms = timed(ctx, lambda: _native.check(lib.mhx_band_keys_dev(ctx.handle, d_sig.ptr, n, k, bands, r, d_out.ptr)))
+        got = d_out.download((n, bands * r), np.uint64)
+        assert np.array_equal(got[:512], O.c_band_keys(sig[:512], bands, r))
+        report(f"band_keys bands={bands} r={r} K={k}", ms, n, "signatures", n * 16 * bands * r)
+    d_out = ctx.alloc(n * (12 + 4 * k))
+    ms = timed(ctx, lambda: _native.check(lib.mhx_lean_serialize_dev(ctx.handle, d_sig.ptr, n, k, 1, d_out.ptr)))
+    report(f"lean_serialize K={k}", ms, n, "signatures", n * (8 * k + 12 + 4 * k))
+    d_y = ctx.to_device(rng.randint(0, 2**32, (n, k), dtype=np.uint64))
+    d_o = ctx.alloc(n * k * 8)
+    ms = timed(ctx, lambda: _native.check(lib.mhx_minhash_merge_dev(ctx.handle, d_sig.ptr, d_y.ptr, n * k, d_o.ptr)))
+    report(f"minhash_merge K={k}", ms, n, "signatures", n * k * 24)
+
+
+def minhash_shapes(ctx):
+    rng = np.random.RandomState(3)
+    for n, t, k in ((1000, 64, 16), (1_000_000, 256, 256), (200_000, 256, 512), (1, 50_000, 128), (1, 50_000, 256), (1, 50_000, 512), (64, 100_000, 128)):
+        tok = rng.randint(0, 2**32, (n, t), dtype=np.uint64)
+        a, b = O.np_init_permutations(k, 1)
+        d_tok, d_out = ctx.to_device(tok), ctx.alloc(n * k * 8)
+        ms = timed(ctx, lambda: ctx.minhash_bulk_dev((a, b), d_tok.ptr, _native.MHX_U64, None, t, n, n * t, None, 0, d_out.ptr, _native.MHX_U64))
+        got = d_out.download((n, k), np.uint64)
+        chk = min(n, 256)
+        assert np.array_equal(got[:chk], O.c_minhash_bulk_dense(tok[:chk], a, b))
+        report(f"minhash_bulk N={n} T={t} K={k}", ms, n, "signatures", n * (8 * t + 8 * k), pairs_per_s=n * t * k / (ms * 1e-3))
+        if n == 1:
+            t0 = time.perf_counter()
+            ctx.minhash_update_batch((a, b), tok.reshape(-1), np.full(k, 2**32 - 1, dtype=np.uint64))
+            print(json.dumps({"name": f"update_batch host->host n={t} K={k}", "ms": round(1e3 * (time.perf_counter() - t0), 4)}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--weighted-rows", type=int, default=20000)
+    ap.add_argument("--sigs", type=int, default=1_000_000)
+    ap.add_argument("--only", default="")
+    args = ap.parse_args()
+    ctx = _native.context()
+    print(json.dumps(ctx.info()), flush=True)
+    if args.only in ("", "minhash"):
+        minhash_shapes(ctx)
+    if args.only in ("", "packing"):
+        packing(ctx, args.sigs, 256)
+    if args.only in ("", "weighted"):
+        weighted(ctx, args.weighted_rows, 4096, 128, 1.0)
+        weighted(ctx, args.weighted_rows * 4, 4096, 128, 0.01)
+        weighted(ctx, args.weighted_rows, 1024, 64, 0.1)
+
+
+if __name__ == "__main__":
+    main()
