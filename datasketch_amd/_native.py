@@ -14,7 +14,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmhx.so")
+LIB_PATH = os.environ.get("MHX_LIBRARY") or os.path.join(_HERE, "libmhx.so")  # MHX_LIBRARY: A/B builds (tools/)
 
 MHX_OK, MHX_ERR_NO_DEVICE, MHX_ERR_INVALID, MHX_ERR_HIP, MHX_ERR_OOM, MHX_ERR_UNSUPPORTED, MHX_ERR_COMM = range(7)
 MHX_U64, MHX_U32 = 0, 1

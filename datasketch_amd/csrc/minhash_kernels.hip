@@ -135,6 +135,9 @@ struct Chunk<uint64_t> {
     __device__ __forceinline__ void keep_whole() const {
         asm volatile("" ::"s"(w[1]), "s"(w[3]), "s"(w[5]), "s"(w[7]), "s"(w[9]), "s"(w[11]), "s"(w[13]), "s"(w[15]));
     }
+    // "the chunk has arrived": scalar loads return out of order, so the only wait is lgkmcnt(0); a use
+    // placed BEFORE the next prefetch is issued makes that wait cover this chunk alone
+    __device__ __forceinline__ void arrived() const { asm volatile("" ::"s"(w[0])); }
 };
 template <>
 struct Chunk<uint32_t> {
@@ -148,6 +151,7 @@ struct Chunk<uint32_t> {
     __device__ __forceinline__ uint32_t lo(int i) const { return v[i]; }
     __device__ __forceinline__ uint32_t hi(int) const { return 0; }
     __device__ __forceinline__ void keep_whole() const {}
+    __device__ __forceinline__ void arrived() const { asm volatile("" ::"s"(v[0])); }
 };
 
 template <int P, bool EXACT, bool WIDE, typename TokT>
@@ -365,23 +369,31 @@ __device__ __forceinline__ bool sieve_range(const TokT MHX_CONST_AS *hv, const T
         }
         for (int g = 0; g < gb; ++g) {
             uint32_t row[P][2];
+            // wait for the current chunk, THEN issue the next prefetch, then hash: one chunk of VALU
+            // work (about 70 instructions) hides every scalar load
             if constexpr (CPG == 4) {
+                a.arrived();
                 b.load(chunk_ptr(ci + 1));
                 __builtin_amdgcn_sched_barrier(0);
                 sieve_chunk<P, TokT, 0>(a, sp, row, col);
+                b.arrived();
                 a.load(chunk_ptr(ci + 2));
                 __builtin_amdgcn_sched_barrier(0);
                 sieve_chunk<P, TokT, 2>(b, sp, row, col);
+                a.arrived();
                 b.load(chunk_ptr(ci + 3));
                 __builtin_amdgcn_sched_barrier(0);
                 sieve_chunk<P, TokT, 4>(a, sp, row, col);
+                b.arrived();
                 a.load(chunk_ptr(ci + 4));
                 __builtin_amdgcn_sched_barrier(0);
                 sieve_chunk<P, TokT, 6>(b, sp, row, col);
             } else {
+                a.arrived();
                 b.load(chunk_ptr(ci + 1));
                 __builtin_amdgcn_sched_barrier(0);
                 sieve_chunk<P, TokT, 0>(a, sp, row, col);
+                b.arrived();
                 a.load(chunk_ptr(ci + 2));
                 __builtin_amdgcn_sched_barrier(0);
                 sieve_chunk<P, TokT, 4>(b, sp, row, col);
@@ -429,48 +441,39 @@ __device__ __forceinline__ bool sieve_range(const TokT MHX_CONST_AS *hv, const T
     return fail;
 }
 
-__device__ __forceinline__ void bump(unsigned long long *stats, int slot, int lane, unsigned long long by = 1) {
-    if (stats && lane == 0) atomicAdd(stats + slot, by);
-}
+template <int P>
+struct Minima {
+    uint32_t v[P];
+};
 
-// min over tokens [beg,end) of the exact fold, for the P permutations of this lane.
-//   path 0: sieve over the full 32-token groups + fast fold for the ragged tail; a failed proof
-//           (or a suspicious fast-fold minimum) sends the whole set to path 2
-//   path 2: fast fold; recompute exactly iff some lane's minimum lands in the ambiguous zone
-//   path 1: exact fold
+// Full evaluation of the tokens [beg,end): fast fold, then the exact fold iff some lane's minimum
+// lands in the ambiguous zone (or straight away with exact_only).  In the default path it runs for
+// a few sets per ten thousand (failed sieve proofs), so it is written to cost the hot path
+// nothing: it reloads the permutations of its lane itself and its address arithmetic is fenced
+// off from loop-invariant hoisting (a real call would add the callee's registers to the kernel's).
 template <int P, typename TokT>
-__device__ __forceinline__ void set_minima(const TokT MHX_CONST_AS *hv, const TokT *hv_vec, int64_t beg,
-                                           int64_t end, const Perms<P> &pm, const Perms<P> &pm_biased,
-                                           const SievePerms<P> &sp, int path, unsigned long long *stats,
-                                           int lane, uint32_t (&res)[P]) {
-    bool redo_fast = path == 2, redo_exact = path == 1;
-    if (path == 0) {
-        const int64_t n = end - beg;
-        const int ngroups = (int)min(n / kGroupTokens, (int64_t)(1 << 26));
+__device__ __forceinline__ Minima<P> full_minima(const TokT *hv_vec, int64_t beg, int64_t end, const uint64_t *a,
+                                                 const uint64_t *b, int num_perm, int kbase, bool exact_only,
+                                                 unsigned long long *stats) {
+    // Launder the range: nothing computed from it below can be hoisted above this point.
+    asm volatile("" : "+s"(beg), "+s"(end));
+    const int lane = threadIdx.x & (kWave - 1);
+    const TokT MHX_CONST_AS *hv = as_const(hv_vec);
+    Perms<P> pm, pm_biased;
+    bool active[P];
 #pragma unroll
-        for (int p = 0; p < P; ++p) res[p] = kMaxHash;
-        bool bad = false;
-        if (ngroups > 0) {
-            int nblocks = 0;
-            bad = sieve_range<P, TokT>(hv, hv_vec, beg, ngroups, pm, sp, res, nblocks);
-            bump(stats, 2, lane, (unsigned long long)nblocks);
-        }
-        const int64_t tail = beg + (int64_t)ngroups * kGroupTokens;
-        if (tail < end) {
-            uint32_t acc[P];
-#pragma unroll
-            for (int p = 0; p < P; ++p) acc[p] = kMaxHash;
-            hash_range<P, false, TokT>(hv, tail, end, pm_biased, acc);
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                bad |= sp.active[p] && acc[p] <= 7u;
-                res[p] = min(res[p], acc[p] - 1u);
-            }
-        }
-        redo_fast = __any(bad);
-        if (redo_fast) bump(stats, 0, lane);
+    for (int p = 0; p < P; ++p) {
+        const int k = kbase + p * kWave + lane;
+        active[p] = k < num_perm;
+        const uint64_t av = active[p] ? a[k] : 0;
+        pm.a_lo[p] = pm_biased.a_lo[p] = (uint32_t)av;
+        pm.a_hi[p] = pm_biased.a_hi[p] = (uint32_t)(av >> 32);
+        pm.b[p] = active[p] ? b[k] : 0;
+        pm_biased.b[p] = pm.b[p] + 1;  // wraps mod 2^64 like everything else
     }
-    if (redo_fast) {
+    Minima<P> res;
+    bool redo = exact_only;
+    if (!exact_only) {
         uint32_t acc[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) acc[p] = kMaxHash;
@@ -478,16 +481,94 @@ __device__ __forceinline__ void set_minima(const TokT MHX_CONST_AS *hv, const To
         bool suspicious = false;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            suspicious |= sp.active[p] && acc[p] <= 7u;
-            res[p] = acc[p] - 1u;
+            suspicious |= active[p] && acc[p] <= 7u;
+            res.v[p] = acc[p] - 1u;
         }
-        redo_exact = __any(suspicious);
+        redo = __any(suspicious);
     }
-    if (redo_exact) {
-        bump(stats, 1, lane);
+    if (redo) {
+        if (!exact_only && stats && lane == 0) atomicAdd(stats + 1, 1ull);
 #pragma unroll
-        for (int p = 0; p < P; ++p) res[p] = kMaxHash;
-        hash_range<P, true, TokT>(hv, beg, end, pm, res);
+        for (int p = 0; p < P; ++p) res.v[p] = kMaxHash;
+        hash_range<P, true, TokT>(hv, beg, end, pm, res.v);
+    }
+    return res;
+}
+
+// Sieve over the full 32-token groups of [beg,end) plus fast fold for the ragged tail.  Returns
+// true (wave-uniform) when a proof failed or a tail minimum is ambiguous: the caller then redoes
+// the range with full_minima.  (Sieving the tail too -- top quads of a window [end-32,end) with
+// guarded quads -- was tried: the guards and the second code path cost the dense case 10 % and
+// gained the ragged one nothing.)
+template <int P, typename TokT>
+__device__ __forceinline__ bool sieve_minima(const TokT MHX_CONST_AS *hv, const TokT *hv_vec, int64_t beg,
+                                             int64_t end, const Perms<P> &pm, const Perms<P> &pm_biased,
+                                             const SievePerms<P> &sp, unsigned long long *stats, int lane,
+                                             uint32_t (&res)[P]) {
+    const int64_t n = end - beg;
+    const int ngroups = (int)min(n / kGroupTokens, (int64_t)(1 << 26));
+#pragma unroll
+    for (int p = 0; p < P; ++p) res[p] = kMaxHash;
+    bool bad = false;
+    if (ngroups > 0) {
+        int nblocks = 0;
+        bad = sieve_range<P, TokT>(hv, hv_vec, beg, ngroups, pm, sp, res, nblocks);
+        if (stats && lane == 0) atomicAdd(stats + 2, (unsigned long long)nblocks);
+    }
+    const int64_t tail = beg + (int64_t)ngroups * kGroupTokens;
+    if (tail < end) {
+        uint32_t acc[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) acc[p] = kMaxHash;
+        hash_range<P, false, TokT>(hv, tail, end, pm_biased, acc);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            bad |= sp.active[p] && acc[p] <= 7u;
+            res[p] = min(res[p], acc[p] - 1u);
+        }
+    }
+    const bool redo = __any(bad);
+    if (redo && stats && lane == 0) atomicAdd(stats, 1ull);
+    return redo;
+}
+
+// Per-wave back-off for corpora whose sets defeat the sieve (repeated tokens inside a set): after
+// a failed proof the wave skips the sieve for `skip` ranges and goes straight to the full
+// evaluation; the gap doubles with every further failure (16 .. 64) and resets on a success.  Clean
+// corpora never see it; corpora full of repeats pay the sieve on 1 range in 64 instead of on all.
+struct SieveBackoff {
+    int skip = 0;
+    int gap = 16;
+};
+
+// min over tokens [beg,end) of the exact fold, for the P permutations of this lane.
+//   path 0: sieve; a failed proof sends the whole range to the full evaluation
+//   path 2: full evaluation (fast fold, exact redo)     path 1: exact fold for every pair
+template <int P, typename TokT>
+__device__ __forceinline__ void set_minima(const BulkArgs &args, const TokT MHX_CONST_AS *hv, const TokT *hv_vec,
+                                           int64_t beg, int64_t end, const Perms<P> &pm,
+                                           const Perms<P> &pm_biased, const SievePerms<P> &sp, int kbase,
+                                           int lane, SieveBackoff &bo, uint32_t (&res)[P]) {
+    bool full = args.path != 0;
+    if (!full) {
+        if (bo.skip > 0) {
+            --bo.skip;
+            full = true;
+        } else {
+            full = sieve_minima<P, TokT>(hv, hv_vec, beg, end, pm, pm_biased, sp, args.stats, lane, res);
+            if (full) {
+                bo.skip = bo.gap;
+                bo.gap = min(2 * bo.gap, 64);
+            } else {
+                bo.gap = 16;
+            }
+        }
+    }
+    if (full) {
+        const Minima<P> m = full_minima<P, TokT>(hv_vec, beg, end, args.a, args.b, args.num_perm, kbase,
+                                                 args.path == 1, args.stats);
+#pragma unroll
+        for (int p = 0; p < P; ++p) res[p] = m.v[p];
     }
 }
 
@@ -530,6 +611,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) 
     const int64_t MHX_CONST_AS *offsets = as_const(args.offsets);
     OutT *__restrict__ out = static_cast<OutT *>(args.out);
     const int64_t stride = (int64_t)gridDim.x * waves_per_block;
+    SieveBackoff backoff;
     for (int64_t set = (int64_t)blockIdx.x * waves_per_block + wave; set < args.n_sets; set += stride) {
         int64_t beg, end;
         if (args.offsets) {
@@ -558,7 +640,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) 
             if (kchunks > 1) load_perms<P>(args, kc * (kWave * P), lane, pm, pm_biased, sp, kidx);
             uint32_t res[P];
             if (end > beg)
-                set_minima<P, TokT>(hv, hv_vec, beg, end, pm, pm_biased, sp, args.path, args.stats, lane, res);
+                set_minima<P, TokT>(args, hv, hv_vec, beg, end, pm, pm_biased, sp, kc * (kWave * P), lane, backoff, res);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 if (kidx[p] < 0) continue;
@@ -618,6 +700,7 @@ __global__ __launch_bounds__(256) void minhash_split_kernel(const BulkArgs args,
 
     const int64_t n_slices = (total_tokens + slice - 1) / slice;
     const int64_t stride = (int64_t)gridDim.x * waves_per_block;
+    SieveBackoff backoff;
     for (int64_t s = (int64_t)blockIdx.x * waves_per_block + wave; s < n_slices; s += stride) {
         const int64_t s_beg = s * slice;
         const int64_t s_end = min(s_beg + slice, total_tokens);
@@ -640,7 +723,7 @@ __global__ __launch_bounds__(256) void minhash_split_kernel(const BulkArgs args,
             const int64_t beg = max(set_beg, s_beg), end = min(set_end, s_end);
             if (end <= beg) continue;
             uint32_t res[P];
-            set_minima<P, TokT>(hv, hv_vec, beg, end, pm, pm_biased, sp, args.path, args.stats, lane, res);
+            set_minima<P, TokT>(args, hv, hv_vec, beg, end, pm, pm_biased, sp, blockIdx.y * (kWave * P), lane, backoff, res);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 if (kidx[p] < 0) continue;
@@ -676,7 +759,7 @@ __global__ void minhash_merge_kernel(const uint64_t *__restrict__ x, const uint6
 template <int P, typename TokT, typename OutT>
 int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t total_tokens, bool split) {
     const int kchunks = (args.num_perm + kWave * P - 1) / (kWave * P);
-    const int blocks_per_cu = ctx->opt_blocks_per_cu > 0 ? (int)ctx->opt_blocks_per_cu : 16;  // > residency: dispatcher evens out the tail
+    const int blocks_per_cu = ctx->opt_blocks_per_cu > 0 ? (int)ctx->opt_blocks_per_cu : 32;  // >> residency: dispatcher evens out the tail
     const int64_t max_blocks = (int64_t)ctx->num_cus * blocks_per_cu;
     if (!split) {
         const int64_t want = (args.n_sets + 3) / 4;

@@ -120,6 +120,32 @@ def minhash_shapes(ctx):
             print(json.dumps({"name": f"update_batch host->host n={t} K={k}", "ms": round(1e3 * (time.perf_counter() - t0), 4)}), flush=True)
 
 
+def minhash_ragged(ctx):
+    """Realistic corpora: ragged sets (CSR), and sets with repeated tokens (failed sieve proofs)."""
+    rng = np.random.RandomState(7)
+    k = 128
+    a, b = O.np_init_permutations(k, 1)
+    for name, n, lo, hi, dup in (("ragged 32..480", 500_000, 32, 480, 0.0), ("ragged 1..100", 1_000_000, 1, 100, 0.0),
+                                 ("dense 256 with 10% repeated tokens", 500_000, 256, 256, 0.1)):
+        lens = rng.randint(lo, hi + 1, size=n).astype(np.int64)
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        hv = rng.randint(0, 2**32, size=int(off[-1]), dtype=np.uint64)
+        if dup:
+            idx = rng.randint(0, hv.size - 1, size=int(dup * hv.size))
+            hv[idx + 1] = hv[idx]  # neighbour copies: duplicates inside a set (a few straddle two sets)
+        d_hv, d_off, d_out = ctx.to_device(hv), ctx.to_device(off), ctx.alloc(n * k * 8)
+        run = lambda: ctx.minhash_bulk_dev((a, b), d_hv.ptr, _native.MHX_U64, d_off.ptr, 0, n, hv.size, None, 0, d_out.ptr, _native.MHX_U64)
+        ms = timed(ctx, run)
+        ctx.counters(True)
+        run()
+        c = ctx.counters(False)
+        got = d_out.download((n, k), np.uint64)
+        assert np.array_equal(got[:256], O.c_minhash_bulk(hv[: off[256]], off[:257], a, b))
+        report(f"minhash_bulk {name} N={n} K={k}", ms, n, "signatures", 8 * hv.size + 8 * k * n, pairs_per_s=hv.size * k / (ms * 1e-3),
+               tokens=int(hv.size), **c)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--weighted-rows", type=int, default=20000)
@@ -130,6 +156,8 @@ def main():
     print(json.dumps(ctx.info()), flush=True)
     if args.only in ("", "minhash"):
         minhash_shapes(ctx)
+    if args.only in ("", "minhash", "ragged"):
+        minhash_ragged(ctx)
     if args.only in ("", "packing"):
         packing(ctx, args.sigs, 256)
     if args.only in ("", "weighted"):
