@@ -76,7 +76,8 @@ def main():
         import torch  # noqa: F811  (plumbing only: rendezvous, barrier, max-over-ranks)
         import torch.distributed as dist  # noqa: F811
 
-        backend = "nccl" if args.allgather else os.environ.get("MHX_BENCH_BACKEND", "gloo")
+        # gloo: PyTorch never touches the GPU here; RCCL traffic (--allgather) goes through libmhx
+        backend = os.environ.get("MHX_BENCH_BACKEND", "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -247,24 +248,22 @@ def cpu_baseline(O, tokens, a, b, sample, k, t):
 
 
 def setup_allgather(ctx, dist, torch, d_out, shard_bytes, world, rank):
-    """All-gather of the signature shards with RCCL (torch.distributed 'nccl' backend as plumbing):
-    device buffers owned by libmhx are wrapped zero-copy through __cuda_array_interface__."""
+    """All-gather of the signature shards with RCCL through libmhx's own binding (mhx_comm_*,
+    include/mhx.h): enqueued on the kernel's stream, so it starts the moment the shard is complete.
+    torch.distributed (gloo, CPU) only carries the 128-byte RCCL id from rank 0 to the others."""
     if dist is None:
         raise SystemExit("--allgather needs a torch.distributed launch (torchrun), also for 1 GPU")
+    from datasketch_amd import _native
 
-    class _Wrap:
-        def __init__(self, ptr, nbytes):
-            self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
-
+    box = [_native.Communicator.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    comm = _native.Communicator(ctx, box[0], rank, world)
     d_all = ctx.alloc(shard_bytes * world)
-    send = torch.as_tensor(_Wrap(d_out.ptr, shard_bytes), device=f"cuda:{torch.cuda.current_device()}")
-    recv = torch.as_tensor(_Wrap(d_all.ptr, shard_bytes * world), device=f"cuda:{torch.cuda.current_device()}")
 
     def gather():
-        ctx.synchronize()  # shard complete on libmhx's stream before RCCL reads it
-        dist.all_gather_into_tensor(recv, send)
+        comm.allgather_dev(d_out.ptr, d_all.ptr, shard_bytes)
 
-    gather.keepalive = (d_all, send, recv)
+    gather.keepalive = (comm, d_all)
     return gather
 
 

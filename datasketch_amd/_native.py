@@ -408,6 +408,45 @@ class Context:
 _contexts = {}
 
 
+class Communicator:
+    """RCCL communicator of libmhx (mhx_comm_*): one rank per Context / GPU, all-gather of row shards
+    over xGMI on the context's stream.  The 128-byte unique id is created on rank 0
+    (``Communicator.unique_id()``) and handed to the other ranks by the caller -- any channel works
+    (``datasketch_amd.dist`` broadcasts it over a gloo process group)."""
+
+    ID_BYTES = 128
+
+    def __init__(self, ctx: "Context", unique_id: bytes, rank: int, world_size: int):
+        if len(unique_id) != self.ID_BYTES:
+            raise ValueError("unique_id must be 128 bytes")
+        self.ctx, self.rank, self.world_size = ctx, int(rank), int(world_size)
+        buf = (ctypes.c_uint8 * self.ID_BYTES).from_buffer_copy(unique_id)
+        h = _vp()
+        check(ctx.lib.mhx_comm_create(ctx.handle, buf, self.rank, self.world_size, ctypes.byref(h)))
+        self.handle = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (ctypes.c_uint8 * Communicator.ID_BYTES)()
+        check(load().mhx_comm_unique_id(buf))
+        return bytes(buf)
+
+    def allgather_dev(self, d_send: int, d_recv: int, bytes_per_rank: int) -> None:
+        """Enqueue the all-gather on the context's stream (device pointers; d_recv holds world*bytes)."""
+        check(self.ctx.lib.mhx_comm_allgather_dev(self.handle, _vp(d_send), _vp(d_recv), int(bytes_per_rank)))
+
+    def close(self) -> None:
+        if getattr(self, "handle", None):
+            self.ctx.lib.mhx_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def default_device() -> int:
     """Device for the implicit context: MHX_DEVICE, else LOCAL_RANK (one process per GPU), else 0."""
     for var in ("MHX_DEVICE", "LOCAL_RANK"):

@@ -1,6 +1,7 @@
 // mhx_api.hip -- C ABI of libmhx (include/mhx.h): context, device memory, events and the
 // host-buffer entry points that stage through device scratch.  Product code: no oracle here.
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -153,7 +154,7 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "blocks_per_cu")) ctx->opt_blocks_per_cu = value;
     else if (!strcmp(key, "minhash.alias")) ctx->opt_minhash_alias = value;
     else if (!strcmp(key, "minhash.prefetch")) ctx->opt_minhash_prefetch = value;
-    else if (!strcmp(key, "weighted.rows")) ctx->opt_weighted_rows = value;
+    else if (!strcmp(key, "weighted.path")) ctx->opt_weighted_path = value;
     else return fail(MHX_ERR_INVALID, "unknown option '%s'", key);
     return MHX_OK;
 }
@@ -515,7 +516,12 @@ int mhx_wgen_create(mhx_ctx *ctx, const float *rs, const float *ln_cs, const flo
     g->dim = dim;
     g->s_pad = (sample_size + 63) / 64 * 64;
     const size_t n = (size_t)sample_size * dim;
-    const size_t t_bytes = sizeof(float) * 3 * (size_t)g->s_pad * dim;
+    const size_t t_bytes = sizeof(float) * 5 * (size_t)g->s_pad * dim;
+    g->table_fast = true;
+    for (size_t j = 0; j < n && g->table_fast; ++j) {
+        const float m = fabsf(rs[j]);
+        g->table_fast = m >= 0x1p-40f && m <= 0x1p40f;  // false for NaN / inf / 0 as well
+    }
     hipError_t e = hipMalloc((void **)&g->d_params, t_bytes);
     if (e != hipSuccess) {
         delete g;

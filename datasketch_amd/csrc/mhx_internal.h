@@ -51,7 +51,7 @@ struct mhx_ctx {
     int64_t opt_blocks_per_cu = 0;  // 0 auto
     int64_t opt_minhash_prefetch = 1; // warm L2 with the next set's tokens (vector load per set)
     int64_t opt_minhash_alias = -1; // profiling only: >= 0 makes set i read the tokens of set (i & mask)
-    int64_t opt_weighted_rows = 0;  // 0 auto: rows per workgroup tile in the weighted kernel
+    int64_t opt_weighted_path = 0;  // 0 auto (reciprocal-multiply quotient + row blocks), 1 IEEE division for every element
 
     // device counters of the MinHash kernels (mhx_ctx_counters); nullptr until counting is enabled
     unsigned long long *d_stats = nullptr;
@@ -71,10 +71,13 @@ struct mhx_wgen {
     mhx_ctx *ctx = nullptr;
     int32_t sample_size = 0;
     int32_t dim = 0;
-    // parameters transposed to [dim][3][S_pad] (r, ln_c, beta) so that one column's samples are
-    // contiguous across lanes
+    // parameters transposed to [dim][5][S_pad] words (double 1/r, then r, ln_c, beta) so that one
+    // column's samples are contiguous across lanes
     float *d_params = nullptr;
     int32_t s_pad = 0;
+    // every r is finite with 2^-40 <= |r| <= 2^40: the reciprocal-multiply quotient is proven exact
+    // (weighted_kernels.hip); otherwise every element takes the IEEE division
+    bool table_fast = false;
 };
 
 struct mhx_event {

@@ -5,9 +5,11 @@ parameters, regenerated from the seed), so the compute phase has NO collective. 
 exchange step is the optional assembly of the full ``[N, K]`` signature matrix on every rank
 (an all-gather of row shards) when one consumer -- e.g. ``MinHashLSH.insert`` -- needs it whole.
 
-``torch.distributed`` is used as plumbing only (rendezvous + the collective): backend ``nccl``
-is RCCL over xGMI on MI355X, ``gloo`` is the CPU stand-in used by the tests.  libmhx also has a
-torch-free RCCL binding (``mhx_comm_*`` in include/mhx.h) for deployments without PyTorch.
+On the GPU the collective is RCCL over xGMI through libmhx's own binding (``mhx_comm_*`` in
+include/mhx.h, :class:`datasketch_amd._native.Communicator`): device buffers in, device buffer
+out, enqueued on the kernel's stream.  ``torch.distributed`` is plumbing only -- a ``gloo`` group
+carries the 128-byte RCCL id and the shard sizes, and is the CPU stand-in for the collective in
+the tests (PyTorch never touches the GPU in this package).
 """
 from __future__ import annotations
 
@@ -55,8 +57,7 @@ def allgather_signatures(local: np.ndarray, group=None, counts: Optional[Sequenc
     world = dist.get_world_size(group)
     local = np.ascontiguousarray(local, dtype=np.uint64)
     k = local.shape[1]
-    on_gpu = dist.get_backend(group) == "nccl"
-    dev = torch.device("cuda", torch.cuda.current_device()) if on_gpu else torch.device("cpu")
+    dev = torch.device("cpu")  # host arrays travel over gloo; device shards use allgather_signatures_dev
     if counts is None:
         c = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
         all_c = torch.zeros(world, dtype=torch.int64, device=dev)
@@ -75,18 +76,64 @@ def allgather_signatures(local: np.ndarray, group=None, counts: Optional[Sequenc
     return np.concatenate(parts, axis=0).astype(np.uint64)
 
 
+_COMM_CACHE = {}
+
+
+def communicator(ctx, group=None):
+    """The RCCL communicator of this rank's context for ``group`` (created once: rank 0 makes the
+    id, a gloo broadcast hands it out)."""
+    import torch.distributed as dist
+
+    key = (id(ctx), id(group))
+    if key not in _COMM_CACHE:
+        from datasketch_amd import _native
+
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        box = [_native.Communicator.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        _COMM_CACHE[key] = _native.Communicator(ctx, box[0], rank, world)
+    return _COMM_CACHE[key]
+
+
+def allgather_signatures_dev(ctx, d_local, rows: int, k: int, counts: Sequence[int], group=None) -> np.ndarray:
+    """Device path of :func:`allgather_signatures`: ``d_local`` is a DeviceBuffer holding this rank's
+    ``[rows, k]`` **uint32** shard (the compact output type of ``mhx_minhash_bulk_dev``), padded
+    capacity ``max(counts)`` rows.  RCCL gathers the padded shards; the host trims and widens."""
+    world = len(counts)
+    width = max(counts)
+    comm = communicator(ctx, group)
+    d_all = ctx.alloc(max(1, world * width * k * 4))
+    comm.allgather_dev(d_local.ptr, d_all.ptr, width * k * 4)
+    ctx.synchronize()
+    recv = d_all.download((world, width, k), np.uint32)
+    return np.concatenate([recv[r, : counts[r]] for r in range(world)], axis=0).astype(np.uint64)
+
+
 def bulk_signatures_sharded(tokens, *, num_perm: int, seed: int = 1, gpu_mode: str = "always", group=None) -> np.ndarray:
     """Config-3 shape: every rank hashes its row block of ``tokens`` (a dense ``[N, T]`` array of
     pre-hashed tokens, identical on every rank) and the shards are all-gathered; every rank
-    returns the full ``[N, K]`` matrix."""
+    returns the full ``[N, K]`` matrix.  With a GPU the shard stays on the device from the kernel
+    to the RCCL all-gather (uint32 on the wire); ``gpu_mode='disable'`` is the numpy + gloo path."""
     import torch.distributed as dist
 
+    from datasketch_amd import _native
     from datasketch_amd.hashfunc import prehashed
     from datasketch_amd.minhash import MinHash
 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     begin, end = shard_rows(tokens.shape[0], world, rank)
-    local = MinHash.bulk_signatures(tokens[begin:end], num_perm=num_perm, seed=seed, hashfunc=prehashed, gpu_mode=gpu_mode)
-    counts = [shard_rows(tokens.shape[0], world, r) for r in range(world)]
-    return allgather_signatures(local, group=group, counts=[e - b for b, e in counts])
+    counts = [e - b for b, e in (shard_rows(tokens.shape[0], world, r) for r in range(world))]
+    use_gpu = gpu_mode == "always" or (gpu_mode == "detect" and _native.gpu_available())
+    if not use_gpu or world == 1:
+        local = MinHash.bulk_signatures(tokens[begin:end], num_perm=num_perm, seed=seed, hashfunc=prehashed, gpu_mode=gpu_mode)
+        return allgather_signatures(local, group=group, counts=counts)
+    ctx = _native.context()
+    proto = MinHash(num_perm=num_perm, seed=seed, hashfunc=prehashed, gpu_mode=gpu_mode)
+    shard = np.ascontiguousarray(tokens[begin:end], dtype=np.uint64)
+    t = shard.shape[1]
+    d_tok = ctx.to_device(shard)
+    d_out = ctx.alloc(max(1, max(counts) * num_perm * 4))
+    ctx.minhash_bulk_dev(proto.permutations, d_tok.ptr, _native.MHX_U64, None, t, shard.shape[0], shard.size, None, 0,
+                         d_out.ptr, _native.MHX_U32)
+    return allgather_signatures_dev(ctx, d_out, shard.shape[0], num_perm, counts, group=group)

@@ -455,6 +455,77 @@ def test_weighted_random_vs_oracle(ctx, dim, s, density):
     assert np.array_equal(out, want)
 
 
+def _weighted_logs_case(ctx, rs, ln_cs, betas, indptr, indices, logs):
+    h = ctx.wgen_create(rs, ln_cs, betas)
+    try:
+        got, ne = ctx.weighted_minhash_many(h, rs.shape[0], indptr, indices, logs, True)
+        ctx.set_option("weighted.path", 1)
+        forced, ne2 = ctx.weighted_minhash_many(h, rs.shape[0], indptr, indices, logs, True)
+    finally:
+        ctx.set_option("weighted.path", 0)
+        ctx.wgen_destroy(h)
+    want, wn = O.c_weighted_minhash_many(indptr, indices, None, rs, ln_cs, betas, logs=logs)
+    assert np.array_equal(ne, wn) and np.array_equal(ne2, wn)
+    assert np.array_equal(forced, want)  # IEEE division everywhere
+    assert np.array_equal(got, want)     # reciprocal-multiply quotient + row blocks + guarded rows
+
+
+def test_weighted_row_blocks_and_guards(ctx):
+    """Blocks of 8 rows with a shared column list take the blocked path; rows with values outside
+    the proven range of the reciprocal-multiply quotient (huge / tiny logs), rows with other column
+    lists, empty rows and ragged block ends take the other paths.  All must agree with the oracle."""
+    rng = np.random.RandomState(21)
+    dim, s = 256, 70
+    rs, ln_cs, betas = O.np_weighted_params(dim, s, 9)
+    rows_idx, rows_log = [], []
+    dense = np.arange(dim, dtype=np.int32)
+    sparse = np.sort(rng.choice(dim, 37, replace=False)).astype(np.int32)
+    def logs_for(n):
+        l = np.log(rng.uniform(1e-3, 100, n).astype(np.float32))
+        l[rng.randint(0, n, 3)] = 0.0            # x == 1
+        l[rng.randint(0, n)] = -np.inf           # stored zero
+        return l.astype(np.float32)
+    for _ in range(16):                          # two clean dense blocks
+        rows_idx.append(dense); rows_log.append(logs_for(dim))
+    for r in range(8):                           # dense block with one out-of-range row
+        l = logs_for(dim)
+        if r == 3:
+            l[10] = np.float32(2.0**50); l[77] = np.float32(2.0**-60); l[200] = np.float32(-2.0**45)
+        rows_idx.append(dense); rows_log.append(l)
+    for r in range(8):                           # mixed column lists, one empty row
+        idx = np.sort(rng.choice(dim, rng.randint(1, 60), replace=False)).astype(np.int32) if r != 5 else np.zeros(0, np.int32)
+        rows_idx.append(idx); rows_log.append(logs_for(max(len(idx), 4))[: len(idx)])
+    for _ in range(8):                           # sparse block with a shared column list
+        rows_idx.append(sparse); rows_log.append(logs_for(len(sparse)))
+    for _ in range(5):                           # ragged end: 5 rows, same list
+        rows_idx.append(sparse); rows_log.append(logs_for(len(sparse)))
+    indptr = np.concatenate([[0], np.cumsum([len(i) for i in rows_idx])]).astype(np.int64)
+    indices, logs = np.concatenate(rows_idx), np.concatenate(rows_log).astype(np.float32)
+    _weighted_logs_case(ctx, rs, ln_cs, betas, indptr, indices, logs)
+    # a table with an r outside [2^-40, 2^40]: the generator itself falls back to IEEE division
+    rs2 = rs.copy()
+    rs2[3, 17] = np.float32(2.0**-50)
+    rs2[60, 200] = np.float32(2.0**45)
+    _weighted_logs_case(ctx, rs2, ln_cs, betas, indptr, indices, logs)
+
+
+def test_weighted_quotient_stress(ctx):
+    """The float32 quotient through a double reciprocal: many (log, r) pairs whose exact quotient
+    sits as close to a rounding boundary as float32 operands allow (r = odd * 2^e, log = r * m
+    rounded, for m near half-integers of the grid)."""
+    rng = np.random.RandomState(33)
+    dim, s, n = 512, 64, 64
+    rs, ln_cs, betas = O.np_weighted_params(dim, s, 2)
+    # q = L/r close to k + 0.5 ulp boundaries: L = fl(r * (j + 0.5 + tiny) * 2^-12)
+    j = rng.randint(1, 2**23, size=(n, dim)).astype(np.float64)
+    pick_r = rs[rng.randint(0, s, size=(n, dim)), np.arange(dim)[None, :]].astype(np.float64)
+    logs = (pick_r * (j + 0.5) * 2.0**-12 * (1 + rng.choice([-1, 1], size=(n, dim)) * 2.0**-24)).astype(np.float32)
+    logs *= rng.choice([-1.0, 1.0], size=logs.shape).astype(np.float32)
+    indptr = (np.arange(n + 1) * dim).astype(np.int64)
+    indices = np.tile(np.arange(dim, dtype=np.int32), n)
+    _weighted_logs_case(ctx, rs, ln_cs, betas, indptr, indices, logs.reshape(-1))
+
+
 def test_weighted_device_log_mode_is_close(ctx):
     """Fast mode: logf on the device.  (k, t) may differ from numpy's log only where two ln_a are
     within float32 rounding of each other; the mismatch rate must be tiny."""
@@ -522,3 +593,28 @@ def test_rccl_allgather_single_rank(ctx):
     ctx.synchronize()
     assert np.array_equal(d_y.download(x.shape, np.uint64), x)
     _native.check(lib.mhx_comm_destroy(comm))
+
+
+def test_device_allgather_through_dist_single_rank(ctx):
+    """datasketch_amd.dist device path at world size 1: kernel -> uint32 shard on the device ->
+    RCCL all-gather (libmhx communicator, id broadcast over a gloo group) -> host matrix."""
+    import socket
+
+    import torch.distributed as dist
+
+    from datasketch_amd.dist import allgather_signatures_dev
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        n, t, k = 3000, 100, 128
+        tok = np.random.RandomState(3).randint(0, 2**32, (n, t), dtype=np.uint64)
+        a, b = O.np_init_permutations(k, 1)
+        d_tok, d_out = ctx.to_device(tok), ctx.alloc(n * k * 4)
+        ctx.minhash_bulk_dev((a, b), d_tok.ptr, _native.MHX_U64, None, t, n, n * t, None, 0, d_out.ptr, _native.MHX_U32)
+        full = allgather_signatures_dev(ctx, d_out, n, k, [n])
+        assert np.array_equal(full, O.c_minhash_bulk_dense(tok, a, b))
+    finally:
+        dist.destroy_process_group()

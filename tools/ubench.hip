@@ -72,6 +72,19 @@ __device__ __forceinline__ void op(unsigned &x0, unsigned &x1, unsigned y, unsig
     if constexpr (OP == 61) asm volatile("v_pk_min_i16 %0, %0, %1" : "+v"(x0) : "v"(y));
     if constexpr (OP == 62) { unsigned long long c = ((unsigned long long)x1 << 32) | x0, d = ((unsigned long long)z << 32) | y; asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(c) : "v"(d)); x0 = (unsigned)c; x1 = (unsigned)(c >> 32); }
     if constexpr (OP == 63) { unsigned long long c = ((unsigned long long)x1 << 32) | x0, d = ((unsigned long long)z << 32) | y; asm volatile("v_min_f64 %0, %0, %1" : "+v"(c) : "v"(d)); x0 = (unsigned)c; x1 = (unsigned)(c >> 32); }
+    if constexpr (OP == 70) { unsigned long long c = ((unsigned long long)x1 << 32) | x0, d = ((unsigned long long)z << 32) | y; asm volatile("v_mul_f64 %0, %0, %1" : "+v"(c) : "v"(d)); x0 = (unsigned)c; x1 = (unsigned)(c >> 32); }
+    if constexpr (OP == 71) { unsigned long long c = ((unsigned long long)x1 << 32) | x0, d = ((unsigned long long)z << 32) | y; asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(c) : "v"(d)); x0 = (unsigned)c; x1 = (unsigned)(c >> 32); }
+    if constexpr (OP == 72) { unsigned long long c; asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(c) : "v"(x0)); x0 ^= (unsigned)c; }
+    if constexpr (OP == 73) { unsigned long long c = ((unsigned long long)x1 << 32) | x0; asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(x0) : "v"(c)); }
+    if constexpr (OP == 74) asm volatile("v_floor_f32 %0, %0" : "+v"(x0));
+    if constexpr (OP == 75) asm volatile("v_rcp_f32 %0, %0" : "+v"(x0));
+    if constexpr (OP == 76) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x0) : "v"(y) : "vcc");
+    if constexpr (OP == 77) { unsigned long long c; asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(c) : "s"(sc)); x0 ^= (unsigned)c; }
+    if constexpr (OP == 78) asm volatile("v_div_scale_f32 %0, vcc, %0, %1, %0" : "+v"(x0) : "v"(y) : "vcc");
+    if constexpr (OP == 79) asm volatile("v_div_fixup_f32 %0, %0, %1, %2" : "+v"(x0) : "v"(y), "v"(z));
+    if constexpr (OP == 80) { unsigned long long c = ((unsigned long long)x1 << 32) | x0, d = ((unsigned long long)z << 32) | y; asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(c) : "v"(d)); x0 = (unsigned)c; x1 = (unsigned)(c >> 32); }
+    if constexpr (OP == 81) asm volatile("v_cvt_f32_u32 %0, %0" : "+v"(x0));
+    if constexpr (OP == 82) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x0) : "v"(y));
     if constexpr (OP == 64) { unsigned long long c = ((unsigned long long)x1 << 32) | x0, d = ((unsigned long long)z << 32) | y; asm volatile("v_add_f64 %0, %0, %1" : "+v"(c) : "v"(d)); x0 = (unsigned)c; x1 = (unsigned)(c >> 32); }
 }
 
@@ -123,7 +136,8 @@ double run(const char *name, int instr_per_op, int blocks, int waves_per_simd, u
     return ns_per;
 }
 
-int main() {
+int main(int argc, char **argv) {
+    const bool fp_only = argc > 1 && argv[1][0] == 'f';
     hipDeviceProp_t prop; CHK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount;
     printf("device: %s, %d CUs, clock %d kHz\n", prop.name, cus, prop.clockRate);
@@ -140,6 +154,23 @@ int main() {
     for (int wps : {2, 8}) {
         const int blocks = cus * wps;  // 256-thread block = 1 wave per SIMD
         double base = run<3>("v_add_u32", 1, blocks, wps, d_out, 0);
+        run<70>("v_mul_f64", 1, blocks, wps, d_out, base);
+        run<71>("v_fma_f64", 1, blocks, wps, d_out, base);
+        run<72>("v_cvt_f64_f32 (+xor)", 2, blocks, wps, d_out, base);
+        run<77>("v_cvt_f64_f32 sgpr src (+xor)", 2, blocks, wps, d_out, base);
+        run<73>("v_cvt_f32_f64", 1, blocks, wps, d_out, base);
+        run<74>("v_floor_f32", 1, blocks, wps, d_out, base);
+        run<75>("v_rcp_f32", 1, blocks, wps, d_out, base);
+        run<76>("v_cmp_lt_f32+v_cndmask (pair)", 2, blocks, wps, d_out, base);
+        run<78>("v_div_scale_f32", 1, blocks, wps, d_out, base);
+        run<79>("v_div_fixup_f32", 1, blocks, wps, d_out, base);
+        run<80>("v_pk_mul_f32", 1, blocks, wps, d_out, base);
+        run<81>("v_cvt_f32_u32", 1, blocks, wps, d_out, base);
+        run<36>("v_min_f32", 1, blocks, wps, d_out, base);
+        run<37>("v_add_f32", 1, blocks, wps, d_out, base);
+        run<48>("v_mul_f32", 1, blocks, wps, d_out, base);
+        run<49>("v_pk_add_f32", 1, blocks, wps, d_out, base);
+        if (fp_only) continue;
         run<4>("v_add3_u32", 1, blocks, wps, d_out, base);
         run<5>("v_min3_u32", 1, blocks, wps, d_out, base);
         run<17>("v_min_u32", 1, blocks, wps, d_out, base);
