@@ -44,7 +44,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--allgather", action="store_true", help="RCCL all-gather of the shards inside every step")
     ap.add_argument("--check-rows", type=int, default=4096, help="rows verified against the oracle")
-    ap.add_argument("--cpu-sample", type=int, default=40_000, help="sets timed on the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=160_000, help="sets timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive host->host measurement")
     ap.add_argument("--u32", action="store_true", help="compact variant: uint32 tokens in, uint32 signatures out")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="libmhx tuning knob (mhx_ctx_set_option), e.g. blocks_per_cu=4")

@@ -68,6 +68,14 @@ int rccl_ready() {
 
 }  // namespace
 
+namespace mhx {
+// Called from mhx_ctx_create: bind RCCL while the process holds only the system HIP runtime.  A
+// PyTorch-ROCm wheel imported later brings its own copies of the ROCm libraries; an RCCL loaded
+// after that resolves against those and finds no device.  Failure to load is not an error here
+// (mhx_comm_* reports it when a communicator is actually requested).
+void preload_rccl() { (void)rccl(); }
+}  // namespace mhx
+
 static_assert(sizeof(ncclUniqueId) == MHX_COMM_ID_BYTES, "RCCL unique id size changed");
 
 extern "C" {

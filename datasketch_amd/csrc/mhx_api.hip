@@ -114,6 +114,7 @@ int mhx_ctx_create(int device, mhx_ctx **out) {
         delete ctx;
         return fail(MHX_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
+    mhx::preload_rccl();
     *out = ctx;
     return MHX_OK;
 }

@@ -105,5 +105,6 @@ int launch_lean_serialize(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_
                           uint8_t *d_out);
 
 int bbit_slot_size(int b);
+void preload_rccl();
 
 }  // namespace mhx

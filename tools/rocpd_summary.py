@@ -18,9 +18,14 @@ def trace_summary(db):
     rows = con.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc").fetchall()
     total = sum(r[2] for r in rows) or 1
     print(f"# kernel trace: {db}")
-    print(f"{'calls':>6} {'total_us':>12} {'avg_us':>10} {'min_us':>10} {'max_us':>10} {'pct':>6}  kernel")
+    print("# steady = mean without each kernel's first dispatch (first touch of freshly allocated output pages) and")
+    print("#          without dispatches that ran with the event counters on; this is what bench.py's timed steps see")
+    print(f"{'calls':>6} {'total_us':>12} {'avg_us':>10} {'steady_us':>10} {'median_us':>10} {'min_us':>10} {'max_us':>10} {'pct':>6}  kernel")
     for name, calls, tot, avg, mn, mx in rows:
-        print(f"{calls:6d} {tot/1e3:12.1f} {avg/1e3:10.1f} {mn/1e3:10.1f} {mx/1e3:10.1f} {100*tot/total:6.2f}  {name}")
+        durs = [d for (d,) in con.execute("select duration from kernels where name = ? order by start", (name,))]
+        steady = durs[1:-1] if len(durs) > 3 else durs
+        med = sorted(durs)[len(durs) // 2]
+        print(f"{calls:6d} {tot/1e3:12.1f} {avg/1e3:10.1f} {sum(steady)/len(steady)/1e3:10.1f} {med/1e3:10.1f} {mn/1e3:10.1f} {mx/1e3:10.1f} {100*tot/total:6.2f}  {name}")
     for r in con.execute("select name, vgpr_count, accum_vgpr_count, sgpr_count, grid_x, grid_y, workgroup_x, lds_size, scratch_size from kernels group by name"):
         print(f"#   {r[0][:90]}: vgpr={r[1]} agpr={r[2]} sgpr={r[3]} grid=({r[4]},{r[5]}) wg={r[6]} lds={r[7]} scratch={r[8]}")
 
