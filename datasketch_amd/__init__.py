@@ -6,7 +6,7 @@ results, with the permutation + min kernels written in HIP for gfx950 and reache
 ctypes C ABI (``include/mhx.h``).  No PyTorch / CuPy / Triton on the path.
 """
 from datasketch_amd.b_bit_minhash import bBitMinHash
-from datasketch_amd.hashfunc import prehashed, sha1_hash32, sha1_hash64
+from datasketch_amd.hashfunc import prehashed, sha1_hash32, sha1_hash64, sha1_hash_many
 from datasketch_amd.lean_minhash import LeanMinHash
 from datasketch_amd.minhash import MinHash
 from datasketch_amd.weighted_minhash import WeightedMinHash, WeightedMinHashGenerator
@@ -22,4 +22,5 @@ __all__ = [
     "prehashed",
     "sha1_hash32",
     "sha1_hash64",
+    "sha1_hash_many",
 ]

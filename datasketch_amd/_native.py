@@ -49,6 +49,9 @@ _PROTOTYPES = {
     "mhx_perm_destroy": [_vp],
     "mhx_minhash_bulk_dev": [_vp, _vp, _int, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _int],
     "mhx_minhash_bulk": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp],
+    "mhx_sha1_tokens_dev": [_vp, _vp, _vp, _i64, _int, _vp],
+    "mhx_sha1_tokens": [_vp, _vp, _vp, _i64, _int, _vp],
+    "mhx_minhash_bulk_bytes": [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp],
     "mhx_minhash_update_batch": [_vp, _vp, _i64, _vp],
     "mhx_minhash_merge_dev": [_vp, _vp, _vp, _i64, _vp],
     "mhx_minhash_merge": [_vp, _vp, _vp, _i64, _vp],
@@ -329,6 +332,49 @@ class Context:
                 raise ValueError("init must have shape (K,) or (n_sets, K)")
         out = np.empty((n_sets, k), dtype=np.uint64)
         check(self.lib.mhx_minhash_bulk(perm, _ptr(hv), _ptr(offsets), int(fixed_len), int(n_sets), _ptr(init), stride, _ptr(out)))
+        return out
+
+    @staticmethod
+    def pack_tokens(tokens) -> tuple:
+        """Byte tokens (bytes / bytearray / memoryview) -> (packed uint8 array, int64 offsets[n+1]).
+        ``b"".join`` raises the TypeError hashlib would raise for a str token."""
+        tokens = tokens if isinstance(tokens, (list, tuple)) else list(tokens)
+        lens = np.fromiter(map(len, tokens), dtype=np.int64, count=len(tokens))
+        offsets = np.zeros(len(tokens) + 1, dtype=np.int64)
+        np.cumsum(lens, out=offsets[1:])
+        buf = np.frombuffer(b"".join(tokens), dtype=np.uint8)
+        if buf.size != int(offsets[-1]):
+            raise TypeError("tokens must be bytes-like objects of single bytes")
+        return buf, offsets
+
+    def sha1_tokens(self, buf: np.ndarray, byte_offsets: np.ndarray, bits: int = 32) -> np.ndarray:
+        """sha1_hash32 / sha1_hash64 of every token of a packed byte corpus (host in, host out)."""
+        n = byte_offsets.size - 1
+        out = np.empty(n, dtype=np.uint32 if bits == 32 else np.uint64)
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.int64)
+        check(self.lib.mhx_sha1_tokens(self.handle, _ptr(buf), _ptr(byte_offsets), n, MHX_U32 if bits == 32 else MHX_U64, _ptr(out)))
+        return out
+
+    def minhash_bulk_bytes(self, permutations, buf: np.ndarray, byte_offsets: np.ndarray, set_offsets: np.ndarray,
+                           init: Optional[np.ndarray] = None) -> np.ndarray:
+        """Raw byte tokens -> sha1_hash32 -> [n_sets, K] uint64 signatures, all on the device."""
+        perm = self.perm_handle(permutations)
+        k = len(permutations[0])
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        byte_offsets = np.ascontiguousarray(byte_offsets, dtype=np.int64)
+        set_offsets = np.ascontiguousarray(set_offsets, dtype=np.int64)
+        n_sets, n_tokens = set_offsets.size - 1, byte_offsets.size - 1
+        stride = 0
+        if init is not None:
+            init = np.ascontiguousarray(init, dtype=np.uint64)
+            if init.shape == (n_sets, k):
+                stride = k
+            elif init.shape != (k,):
+                raise ValueError("init must have shape (K,) or (n_sets, K)")
+        out = np.empty((n_sets, k), dtype=np.uint64)
+        check(self.lib.mhx_minhash_bulk_bytes(perm, _ptr(buf), _ptr(byte_offsets), n_tokens, _ptr(set_offsets), n_sets,
+                                              _ptr(init), stride, _ptr(out)))
         return out
 
     def minhash_update_batch(self, permutations, hv: np.ndarray, hashvalues: np.ndarray) -> np.ndarray:

@@ -369,6 +369,97 @@ int mhx_minhash_bulk(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets,
     return MHX_OK;
 }
 
+// ---- token hashing (sha1_hash32 / sha1_hash64 of byte tokens) ----------------------------------
+int mhx_sha1_tokens_dev(mhx_ctx *ctx, const uint8_t *d_bytes, const int64_t *d_byte_offsets, int64_t n_tokens,
+                        int out_dtype, void *d_out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_REQUIRE(n_tokens >= 0, "n_tokens must be >= 0");
+    MHX_REQUIRE(out_dtype == MHX_U32 || out_dtype == MHX_U64, "out_dtype must be MHX_U32 or MHX_U64");
+    if (n_tokens == 0) return MHX_OK;
+    MHX_REQUIRE(d_byte_offsets && d_out, "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_sha1_tokens(ctx, d_bytes, d_byte_offsets, n_tokens, out_dtype, d_out);
+}
+
+namespace {
+// validate + upload a packed byte corpus: bytes -> scratch[0], byte offsets -> scratch[3]
+int upload_tokens(mhx_ctx *ctx, const uint8_t *bytes, const int64_t *byte_offsets, int64_t n_tokens,
+                  uint8_t **d_bytes, int64_t **d_offs) {
+    MHX_REQUIRE(byte_offsets, "byte_offsets is NULL");
+    MHX_REQUIRE(byte_offsets[0] == 0, "byte_offsets[0] must be 0");
+    for (int64_t i = 0; i < n_tokens; ++i)
+        MHX_REQUIRE(byte_offsets[i + 1] >= byte_offsets[i], "byte_offsets must be non-decreasing (token %lld)", (long long)i);
+    const int64_t total = byte_offsets[n_tokens];
+    MHX_REQUIRE(bytes || total == 0, "bytes is NULL");
+    if (int rc = ctx->ensure_scratch(0, (size_t)total + 256)) return rc;
+    if (int rc = ctx->ensure_scratch(3, sizeof(int64_t) * (size_t)(n_tokens + 1))) return rc;
+    *d_bytes = (uint8_t *)ctx->scratch[0];
+    *d_offs = (int64_t *)ctx->scratch[3];
+    if (total) MHX_HIP_CHECK(hipMemcpyAsync(*d_bytes, bytes, (size_t)total, hipMemcpyHostToDevice, ctx->stream));
+    MHX_HIP_CHECK(hipMemcpyAsync(*d_offs, byte_offsets, sizeof(int64_t) * (size_t)(n_tokens + 1), hipMemcpyHostToDevice,
+                                 ctx->stream));
+    return MHX_OK;
+}
+}  // namespace
+
+int mhx_sha1_tokens(mhx_ctx *ctx, const uint8_t *bytes, const int64_t *byte_offsets, int64_t n_tokens,
+                    int out_dtype, void *out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_REQUIRE(n_tokens >= 0, "n_tokens must be >= 0");
+    MHX_REQUIRE(out_dtype == MHX_U32 || out_dtype == MHX_U64, "out_dtype must be MHX_U32 or MHX_U64");
+    if (n_tokens == 0) return MHX_OK;
+    MHX_REQUIRE(out, "out is NULL");
+    if (int rc = ctx->activate()) return rc;
+    uint8_t *d_bytes = nullptr;
+    int64_t *d_offs = nullptr;
+    if (int rc = upload_tokens(ctx, bytes, byte_offsets, n_tokens, &d_bytes, &d_offs)) return rc;
+    const size_t out_bytes = (size_t)n_tokens * (out_dtype == MHX_U32 ? 4 : 8);
+    if (int rc = ctx->ensure_scratch(2, out_bytes)) return rc;
+    if (int rc = mhx::launch_sha1_tokens(ctx, d_bytes, d_offs, n_tokens, out_dtype, ctx->scratch[2])) return rc;
+    MHX_HIP_CHECK(hipMemcpyAsync(out, ctx->scratch[2], out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MHX_OK;
+}
+
+int mhx_minhash_bulk_bytes(mhx_perm *perm, const uint8_t *bytes, const int64_t *byte_offsets, int64_t n_tokens,
+                           const int64_t *set_offsets, int64_t n_sets, const uint64_t *init, int64_t init_stride,
+                           uint64_t *out) {
+    if (!perm) return fail(MHX_ERR_INVALID, "perm is NULL");
+    MHX_REQUIRE(n_sets >= 0 && n_tokens >= 0, "n_sets and n_tokens must be >= 0");
+    if (n_sets == 0) return MHX_OK;
+    MHX_REQUIRE(out && set_offsets, "out/set_offsets is NULL");
+    MHX_REQUIRE(set_offsets[0] == 0 && set_offsets[n_sets] == n_tokens, "set_offsets must run from 0 to n_tokens");
+    for (int64_t i = 0; i < n_sets; ++i)
+        MHX_REQUIRE(set_offsets[i + 1] >= set_offsets[i], "set_offsets must be non-decreasing (set %lld)", (long long)i);
+    mhx_ctx *ctx = perm->ctx;
+    if (int rc = ctx->activate()) return rc;
+    const int64_t k = perm->num_perm;
+    uint8_t *d_bytes = nullptr;
+    int64_t *d_boffs = nullptr;
+    if (n_tokens > 0)
+        if (int rc = upload_tokens(ctx, bytes, byte_offsets, n_tokens, &d_bytes, &d_boffs)) return rc;
+    // scratch[1]: set offsets | init | uint32 token hashes;  scratch[2]: signatures
+    const size_t off_bytes = sizeof(int64_t) * (size_t)(n_sets + 1);
+    const size_t init_bytes = init ? sizeof(uint64_t) * (size_t)(init_stride ? n_sets * init_stride : k) : 0;
+    const size_t off_pad = (off_bytes + 255) & ~(size_t)255, init_pad = (init_bytes + 255) & ~(size_t)255;
+    const size_t out_bytes = sizeof(uint64_t) * (size_t)(n_sets * k);
+    if (int rc = ctx->ensure_scratch(1, off_pad + init_pad + sizeof(uint32_t) * (size_t)n_tokens + 256)) return rc;
+    if (int rc = ctx->ensure_scratch(2, out_bytes)) return rc;
+    int64_t *d_soffs = (int64_t *)ctx->scratch[1];
+    uint64_t *d_init = init ? (uint64_t *)((char *)ctx->scratch[1] + off_pad) : nullptr;
+    uint32_t *d_hv = (uint32_t *)((char *)ctx->scratch[1] + off_pad + init_pad);
+    uint64_t *d_out = (uint64_t *)ctx->scratch[2];
+    MHX_HIP_CHECK(hipMemcpyAsync(d_soffs, set_offsets, off_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (init_bytes) MHX_HIP_CHECK(hipMemcpyAsync(d_init, init, init_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = mhx::launch_sha1_tokens(ctx, d_bytes, d_boffs, n_tokens, MHX_U32, d_hv)) return rc;
+    if (int rc = mhx::launch_minhash_bulk(perm, d_hv, MHX_U32, d_soffs, 0, n_sets, n_tokens, d_init, init_stride, d_out,
+                                          MHX_U64))
+        return rc;
+    MHX_HIP_CHECK(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MHX_OK;
+}
+
 int mhx_minhash_update_batch(mhx_perm *perm, const uint64_t *hv, int64_t n, uint64_t *hashvalues) {
     if (!perm) return fail(MHX_ERR_INVALID, "perm is NULL");
     MHX_REQUIRE(n >= 0, "n must be >= 0");

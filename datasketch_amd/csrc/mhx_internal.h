@@ -91,6 +91,8 @@ namespace mhx {
 int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const int64_t *d_offsets,
                         int64_t fixed_len, int64_t n_sets, int64_t total_tokens,
                         const uint64_t *d_init, int64_t init_stride, void *d_out, int out_dtype);
+int launch_sha1_tokens(mhx_ctx *ctx, const uint8_t *d_bytes, const int64_t *d_offsets, int64_t n_tokens,
+                       int out_dtype, void *d_out);
 int launch_minhash_merge(mhx_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y, int64_t count,
                          uint64_t *d_out);
 int launch_weighted(mhx_wgen *gen, const int64_t *d_indptr, const int32_t *d_indices,

@@ -1,7 +1,10 @@
-"""Token hash functions (host side).
+"""Token hash functions.
 
 The reference hashes tokens in Python on the CPU and hands integers to the permutation step
-(datasketch/hashfunc.py:5-28, datasketch/minhash.py:262-263); this boundary is kept.
+(datasketch/hashfunc.py:5-28, datasketch/minhash.py:262-263); these callables are that boundary,
+unchanged.  The bulk paths recognise the function objects ``sha1_hash32`` / ``sha1_hash64`` (the
+reference's default) and, with a device back end, hash whole chunks of byte tokens with the SHA-1
+kernel of libmhx instead of calling them per token (``sha1_hash_many``); results are identical.
 """
 import hashlib
 import struct
@@ -31,3 +34,23 @@ def prehashed(value):
     handed to the device as is.
     """
     return value
+
+
+def sha1_hash_many(tokens, bits: int = 32, gpu_mode: str = "detect"):
+    """``[sha1_hash32(t) for t in tokens]`` (``bits=64``: ``sha1_hash64``) as a numpy array; on the
+    device when one is available (``gpu_mode`` as for MinHash), else with hashlib."""
+    import numpy as np
+
+    from datasketch_amd import _native
+
+    if bits not in (32, 64):
+        raise ValueError("bits must be 32 or 64")
+    tokens = tokens if isinstance(tokens, (list, tuple)) else list(tokens)
+    use_gpu = gpu_mode == "always" or (gpu_mode == "detect" and _native.gpu_available())
+    if gpu_mode == "always" and not _native.gpu_available():
+        raise RuntimeError("GPU mode 'always' requested but no MI355X / libmhx.so is available.")
+    if not use_gpu:
+        f = sha1_hash32 if bits == 32 else sha1_hash64
+        return np.array([f(t) for t in tokens], dtype=np.uint32 if bits == 32 else np.uint64)
+    buf, offsets = _native.Context.pack_tokens(tokens)
+    return _native.context().sha1_tokens(buf, offsets, bits)

@@ -25,7 +25,7 @@ from typing import Callable, Generator, Iterable, List, Optional, Tuple
 import numpy as np
 
 from datasketch_amd import _native
-from datasketch_amd.hashfunc import prehashed, sha1_hash32
+from datasketch_amd.hashfunc import prehashed, sha1_hash32, sha1_hash64
 
 # The size of a hash value in number of bytes (reference: datasketch/minhash.py:27)
 hashvalue_byte_size = len(bytes(np.int64(42).data))
@@ -153,6 +153,13 @@ class MinHash:
             hv_list = b
             if b.size == 0:
                 return
+        elif self.hashfunc in (sha1_hash32, sha1_hash64) and self._use_gpu():
+            # the reference's default hash, for the whole batch at once on the device
+            b = b if isinstance(b, (list, tuple)) else list(b)
+            if not b:
+                return
+            buf, offs = _native.Context.pack_tokens(b)
+            hv_list = _native.context().sha1_tokens(buf, offs, 32 if self.hashfunc is sha1_hash32 else 64)
         else:
             hv_list = [self.hashfunc(_b) for _b in b]
             if not hv_list:  # empty batch is a no-op (minhash.py:265-266)
@@ -279,6 +286,7 @@ class MinHash:
                 yield self._signatures_csr(values[offsets[s] : offsets[e]], local, 0, e - s, init)
                 s = e
             return
+        device_sha1 = self.hashfunc is sha1_hash32 and self._use_gpu()
         chunk: List = []
         tokens = 0
         for s in b:
@@ -286,12 +294,20 @@ class MinHash:
             chunk.append(s)
             tokens += len(s)
             if len(chunk) >= _BULK_CHUNK_SETS or tokens >= _BULK_CHUNK_TOKENS:
-                hv, offsets = self._hash_sets(chunk)
-                yield self._signatures_csr(hv, offsets, 0, len(chunk), init)
+                yield self._signatures_of_sets(chunk, init, device_sha1)
                 chunk, tokens = [], 0
         if chunk:
-            hv, offsets = self._hash_sets(chunk)
-            yield self._signatures_csr(hv, offsets, 0, len(chunk), init)
+            yield self._signatures_of_sets(chunk, init, device_sha1)
+
+    def _signatures_of_sets(self, sets: List, init, device_sha1: bool) -> np.ndarray:
+        if not device_sha1:
+            hv, offsets = self._hash_sets(sets)
+            return self._signatures_csr(hv, offsets, 0, len(sets), init)
+        # default hashfunc + device: pack the byte tokens once, SHA-1 and MinHash both on the device
+        set_offsets = np.zeros(len(sets) + 1, dtype=np.int64)
+        np.cumsum(np.fromiter(map(len, sets), dtype=np.int64, count=len(sets)), out=set_offsets[1:])
+        buf, byte_offsets = _native.Context.pack_tokens([t for s in sets for t in s])
+        return _native.context().minhash_bulk_bytes(self.permutations, buf, byte_offsets, set_offsets, init)
 
     def _signatures_csr(self, hv, offsets, fixed_len, n_sets, init) -> np.ndarray:
         if self._use_gpu():

@@ -128,6 +128,28 @@ MHX_API int mhx_minhash_bulk(mhx_perm *perm, const uint64_t *hv, const int64_t *
                              int64_t init_stride, uint64_t *out);
 
 /*
+ * The reference's default token hash on the device: out[i] = sha1_hash32(token i) (MHX_U32,
+ * ref: datasketch/hashfunc.py:5-15: first 4 bytes of the SHA-1 digest, little-endian) or
+ * sha1_hash64 (MHX_U64, ref: hashfunc.py:17-28), replacing the per-token Python call of
+ * ref: datasketch/minhash.py:221,262-263.  Tokens are byte strings packed back to back in `bytes`;
+ * token i is bytes[byte_offsets[i] .. byte_offsets[i+1]) (int64[n_tokens+1], byte_offsets[0] == 0).
+ * The uint32 output can be passed straight to mhx_minhash_bulk_dev as hv with hv_dtype MHX_U32.
+ */
+MHX_API int mhx_sha1_tokens_dev(mhx_ctx *ctx, const uint8_t *d_bytes, const int64_t *d_byte_offsets,
+                                int64_t n_tokens, int out_dtype, void *d_out);
+MHX_API int mhx_sha1_tokens(mhx_ctx *ctx, const uint8_t *bytes, const int64_t *byte_offsets,
+                            int64_t n_tokens, int out_dtype, void *out);
+/*
+ * MinHash.bulk / generator on raw byte tokens with the default hashfunc (ref: minhash.py:491-522
+ * with hashfunc = sha1_hash32): H2D of the packed bytes, SHA-1 kernel, MinHash kernel, D2H of
+ * out[n_sets, K] uint64.  set_offsets int64[n_sets+1] indexes TOKENS (set i owns tokens
+ * set_offsets[i] .. set_offsets[i+1]); init as in mhx_minhash_bulk.
+ */
+MHX_API int mhx_minhash_bulk_bytes(mhx_perm *perm, const uint8_t *bytes, const int64_t *byte_offsets,
+                                   int64_t n_tokens, const int64_t *set_offsets, int64_t n_sets,
+                                   const uint64_t *init, int64_t init_stride, uint64_t *out);
+
+/*
  * One update_batch on one MinHash state (the reference's GPU seam itself,
  * ref: datasketch/minhash.py:281-291): hashvalues[K] is read, min-combined with the
  * permuted minima of hv[0..n), and written back.  n == 0 is a no-op.

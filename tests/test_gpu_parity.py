@@ -618,3 +618,46 @@ def test_device_allgather_through_dist_single_rank(ctx):
         assert np.array_equal(full, O.c_minhash_bulk_dense(tok, a, b))
     finally:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------ device SHA-1 (row f2)
+def test_sha1_tokens_against_hashlib(ctx):
+    """sha1_hash32 / sha1_hash64 of byte tokens: every length 0..260 (padding boundaries 55/56,
+    63/64, 119/120), every start alignment (tokens are packed back to back), random bytes."""
+    import hashlib
+    import struct
+
+    from datasketch_amd import sha1_hash_many
+
+    rng = np.random.RandomState(0)
+    tokens = [bytes(rng.randint(0, 256, n, dtype=np.uint8)) for n in range(0, 261)]
+    tokens += [bytes(rng.randint(0, 256, rng.randint(0, 40), dtype=np.uint8)) for _ in range(5000)]
+    tokens += [b"Hello", b"", b"a" * 1000, bytearray(b"xyz"), memoryview(b"memory")]
+    want32 = np.array([struct.unpack("<I", hashlib.sha1(t).digest()[:4])[0] for t in tokens], dtype=np.uint32)
+    want64 = np.array([struct.unpack("<Q", hashlib.sha1(t).digest()[:8])[0] for t in tokens], dtype=np.uint64)
+    assert np.array_equal(sha1_hash_many(tokens, 32, gpu_mode="always"), want32)
+    assert np.array_equal(sha1_hash_many(tokens, 64, gpu_mode="always"), want64)
+    with pytest.raises(TypeError):
+        sha1_hash_many(["not bytes"], gpu_mode="always")
+
+
+def test_bulk_on_byte_tokens_matches_host_hashing(ctx):
+    """MinHash.bulk / update_batch with the default hashfunc: device SHA-1 + device MinHash equals
+    the reference arithmetic with hashlib on the host (gpu_mode='disable')."""
+    rng = np.random.RandomState(2)
+    sets = [[f"tok-{rng.randint(0, 5000)}".encode() for _ in range(rng.randint(0, 120))] for _ in range(400)]
+    dev = MinHash.bulk_signatures(sets, num_perm=128, seed=3, gpu_mode="always")
+    host = MinHash.bulk_signatures(sets, num_perm=128, seed=3, gpu_mode="disable")
+    assert np.array_equal(dev, host)
+    objs = MinHash.bulk(sets[:50], num_perm=64, seed=3, gpu_mode="always")
+    for m, s in zip(objs, sets[:50]):
+        ref = MinHash(num_perm=64, seed=3, gpu_mode="disable")
+        ref.update_batch(s)
+        assert m == ref
+    from datasketch_amd import sha1_hash64
+
+    m64 = MinHash(num_perm=32, seed=1, hashfunc=sha1_hash64, gpu_mode="always")
+    r64 = MinHash(num_perm=32, seed=1, hashfunc=sha1_hash64, gpu_mode="disable")
+    for m in (m64, r64):
+        m.update_batch(sets[7] + sets[8])
+    assert m64 == r64

@@ -146,6 +146,35 @@ def minhash_ragged(ctx):
                tokens=int(hv.size), **c)
 
 
+def sha1(ctx):
+    """Device SHA-1 of byte tokens (row f2) and what it does to bulk() on raw byte tokens end to end."""
+    from datasketch_amd import MinHash
+
+    rng = np.random.RandomState(11)
+    n = 32_000_000
+    lens = rng.randint(3, 13, size=n).astype(np.int64)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=offs[1:])
+    buf = rng.randint(0, 256, int(offs[-1]), dtype=np.uint8)
+    d_buf, d_off, d_out = ctx.to_device(buf), ctx.to_device(offs), ctx.alloc(n * 4)
+    run = lambda: _native.check(ctx.lib.mhx_sha1_tokens_dev(ctx.handle, d_buf.ptr, d_off.ptr, n, _native.MHX_U32, d_out.ptr))
+    ms = timed(ctx, run)
+    import hashlib, struct
+    got = d_out.download((n,), np.uint32)
+    for i in (0, 1, 12345, n - 1):
+        assert got[i] == struct.unpack("<I", hashlib.sha1(buf[offs[i]:offs[i + 1]].tobytes()).digest()[:4])[0]
+    report(f"sha1_hash32 of {n} byte tokens (3..12 bytes)", ms, n, "tokens", buf.size + 8 * n + 4 * n)
+    # end to end from Python objects: 20k sets x 100 byte tokens
+    sets = [[b"w%d" % v for v in rng.randint(0, 1 << 20, 100)] for _ in range(20_000)]
+    for mode in ("always", "disable"):
+        t0 = time.perf_counter()
+        sig = MinHash.bulk_signatures(sets, num_perm=128, seed=1, gpu_mode=mode)
+        dt = time.perf_counter() - t0
+        print(json.dumps({"name": f"bulk_signatures on byte tokens, default hashfunc, gpu_mode={mode}", "sets": len(sets),
+                          "tokens_per_set": 100, "seconds": round(dt, 3), "sets_per_s": len(sets) / dt,
+                          "checksum": int(sig.sum() % (1 << 61))}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--weighted-rows", type=int, default=20000)
@@ -158,6 +187,8 @@ def main():
         minhash_shapes(ctx)
     if args.only in ("", "minhash", "ragged"):
         minhash_ragged(ctx)
+    if args.only in ("", "sha1"):
+        sha1(ctx)
     if args.only in ("", "packing"):
         packing(ctx, args.sigs, 256)
     if args.only in ("", "weighted"):

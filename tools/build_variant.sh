@@ -9,5 +9,5 @@ bash "${ROOT}/datasketch_amd/csrc/build.sh" > /dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off \
   -I"${ROOT}/include" -I"${ROOT}/datasketch_amd/csrc" -Wall -Wno-unused-function -c "${SRC}" -o "${OUT}/minhash_${NAME}.o"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "${OUT}/libmhx_${NAME}.so" "${OBJ}/mhx_api.o" "${OUT}/minhash_${NAME}.o" \
-  "${OBJ}/weighted_kernels.o" "${OBJ}/pack_kernels.o" "${OBJ}/comm.o" -ldl
+  "${OBJ}/weighted_kernels.o" "${OBJ}/pack_kernels.o" "${OBJ}/sha1_kernels.o" "${OBJ}/comm.o" -ldl
 echo "${OUT}/libmhx_${NAME}.so"
