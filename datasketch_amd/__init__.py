@@ -6,6 +6,7 @@ results, with the permutation + min kernels written in HIP for gfx950 and reache
 ctypes C ABI (``include/mhx.h``).  No PyTorch / CuPy / Triton on the path.
 """
 from datasketch_amd.b_bit_minhash import bBitMinHash
+from datasketch_amd import lsh_bulk
 from datasketch_amd.hashfunc import prehashed, sha1_hash32, sha1_hash64, sha1_hash_many
 from datasketch_amd.lean_minhash import LeanMinHash
 from datasketch_amd.minhash import MinHash
@@ -23,4 +24,5 @@ __all__ = [
     "sha1_hash32",
     "sha1_hash64",
     "sha1_hash_many",
+    "lsh_bulk",
 ]

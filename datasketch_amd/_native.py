@@ -64,6 +64,10 @@ _PROTOTYPES = {
     "mhx_bbit_pack": [_vp, _vp, _i64, _i32, _i32, _vp],
     "mhx_band_keys_dev": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "mhx_band_keys": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
+    "mhx_band_digests_dev": [_vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp],
+    "mhx_band_digests": [_vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp],
+    "mhx_jaccard_pairs_dev": [_vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp],
+    "mhx_jaccard_pairs": [_vp, _vp, _i64, ctypes.c_int32, _vp, _i64, _vp],
     "mhx_lean_serialize_dev": [_vp, _vp, _i64, _i32, _i64, _vp],
     "mhx_lean_serialize": [_vp, _vp, _i64, _i32, _i64, _vp],
     "mhx_comm_unique_id": [_vp],
@@ -417,6 +421,23 @@ class Context:
         n, k = sig.shape
         out = np.empty((n, bands * r), dtype=np.uint64)
         check(self.lib.mhx_band_keys(self.handle, _ptr(sig), n, k, int(bands), int(r), _ptr(out)))
+        return out
+
+    def band_digests(self, sig: np.ndarray, bands: int, r: int) -> np.ndarray:
+        """[n, bands] uint64: FNV-1a-64 of every band key (mhx_band_digests)."""
+        sig = np.ascontiguousarray(sig, dtype=np.uint64)
+        n, k = sig.shape
+        out = np.empty((n, bands), dtype=np.uint64)
+        check(self.lib.mhx_band_digests(self.handle, _ptr(sig), n, k, int(bands), int(r), _ptr(out)))
+        return out
+
+    def jaccard_pairs(self, sig: np.ndarray, pairs: np.ndarray) -> np.ndarray:
+        """int32 counts of equal positions for rows (pairs[:,0], pairs[:,1]) of one signature matrix."""
+        sig = np.ascontiguousarray(sig, dtype=np.uint64)
+        pairs = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+        n, k = sig.shape
+        out = np.empty(pairs.shape[0], dtype=np.int32)
+        check(self.lib.mhx_jaccard_pairs(self.handle, _ptr(sig), n, k, _ptr(pairs), pairs.shape[0], _ptr(out)))
         return out
 
     def lean_serialize(self, sig: np.ndarray, seed: int) -> np.ndarray:

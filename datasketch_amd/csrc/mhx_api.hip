@@ -583,6 +583,62 @@ int mhx_band_keys(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int32
     return fetch_out(ctx, out, out_bytes);
 }
 
+int mhx_band_digests_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
+                         uint64_t *d_out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
+    MHX_REQUIRE(n >= 0, "bad shape");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(d_sig && d_out, "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_band_digests(ctx, d_sig, n, k, bands, r, d_out);
+}
+
+int mhx_band_digests(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int32_t bands, int32_t r,
+                     uint64_t *out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
+    MHX_REQUIRE(n >= 0, "bad shape");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(sig && out, "NULL host pointer");
+    const size_t out_bytes = sizeof(uint64_t) * (size_t)(n * bands);
+    if (int rc = stage_sig(ctx, sig, n, k, out_bytes)) return rc;
+    if (int rc = mhx::launch_band_digests(ctx, (const uint64_t *)ctx->scratch[0], n, k, bands, r,
+                                          (uint64_t *)ctx->scratch[2]))
+        return rc;
+    return fetch_out(ctx, out, out_bytes);
+}
+
+int mhx_jaccard_pairs_dev(mhx_ctx *ctx, const uint64_t *d_sig_a, const uint64_t *d_sig_b, int32_t k,
+                          const int64_t *d_pairs, int64_t n_pairs, int32_t *d_counts) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_REQUIRE(k > 0 && n_pairs >= 0, "bad shape");
+    if (n_pairs == 0) return MHX_OK;
+    MHX_REQUIRE(d_sig_a && d_sig_b && d_pairs && d_counts, "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_jaccard_pairs(ctx, d_sig_a, d_sig_b, k, d_pairs, n_pairs, d_counts);
+}
+
+int mhx_jaccard_pairs(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, const int64_t *pairs,
+                      int64_t n_pairs, int32_t *counts) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_REQUIRE(k > 0 && n >= 0 && n_pairs >= 0, "bad shape");
+    if (n_pairs == 0) return MHX_OK;
+    MHX_REQUIRE(sig && pairs && counts, "NULL host pointer");
+    for (int64_t p = 0; p < 2 * n_pairs; ++p)
+        MHX_REQUIRE(pairs[p] >= 0 && pairs[p] < n, "pair index %lld out of range [0,%lld)", (long long)pairs[p], (long long)n);
+    const size_t out_bytes = sizeof(int32_t) * (size_t)n_pairs;
+    if (int rc = stage_sig(ctx, sig, n, k, out_bytes)) return rc;
+    if (int rc = ctx->ensure_scratch(1, sizeof(int64_t) * 2 * (size_t)n_pairs)) return rc;
+    MHX_HIP_CHECK(hipMemcpyAsync(ctx->scratch[1], pairs, sizeof(int64_t) * 2 * (size_t)n_pairs, hipMemcpyHostToDevice,
+                                 ctx->stream));
+    const uint64_t *d_sig = (const uint64_t *)ctx->scratch[0];
+    if (int rc = mhx::launch_jaccard_pairs(ctx, d_sig, d_sig, k, (const int64_t *)ctx->scratch[1], n_pairs,
+                                           (int32_t *)ctx->scratch[2]))
+        return rc;
+    return fetch_out(ctx, counts, out_bytes);
+}
+
 int mhx_lean_serialize(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int64_t seed, uint8_t *out) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
     MHX_REQUIRE(k > 0 && n >= 0, "bad shape");

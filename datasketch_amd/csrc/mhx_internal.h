@@ -103,6 +103,10 @@ int launch_bbit_pack(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, 
                      uint64_t *d_out);
 int launch_band_keys(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands,
                      int32_t r, uint64_t *d_out);
+int launch_band_digests(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
+                        uint64_t *d_out);
+int launch_jaccard_pairs(mhx_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, int32_t k, const int64_t *d_pairs,
+                         int64_t m, int32_t *d_counts);
 int launch_lean_serialize(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int64_t seed,
                           uint8_t *d_out);
 

@@ -96,6 +96,54 @@ __global__ __launch_bounds__(256) void lean_serialize_kernel(const uint64_t *__r
     }
 }
 
+// ---- band digests -----------------------------------------------------------------------------
+// out[i, j] = FNV-1a-64 of the band key of band j of row i, i.e. of exactly the bytes the reference
+// uses as that band's dictionary key (ref: datasketch/lsh.py:199,344,537-538: the r hashvalues of the
+// band, each as 8 big-endian bytes).  It is what MinHashLSH(hashfunc=fnv1a_64) would store
+// (ref: lsh.py:540-543), in a form a device-side sort can group by.  One lane per (row, band).
+__global__ __launch_bounds__(256) void band_digest_kernel(const uint64_t *__restrict__ sig, int64_t n, int32_t k,
+                                                          int32_t bands, int32_t r, uint64_t *__restrict__ out) {
+    const int64_t total = n * (int64_t)bands;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = idx / bands;
+        const int band = (int)(idx - row * bands);
+        const uint64_t *src = sig + row * k + (int64_t)band * r;
+        uint64_t h = 0xcbf29ce484222325ull;
+        for (int c = 0; c < r; ++c) {
+            const uint64_t v = src[c];
+#pragma unroll
+            for (int byte = 7; byte >= 0; --byte) {  // big-endian byte order of the key
+                h ^= (v >> (8 * byte)) & 0xFFu;
+                h *= 0x100000001b3ull;
+            }
+        }
+        out[idx] = h;
+    }
+}
+
+// ---- batched Jaccard estimate -----------------------------------------------------------------
+// counts[p] = number of positions where signature rows pairs[p][0] (of A) and pairs[p][1] (of B) agree;
+// MinHash.jaccard is counts / K (ref: datasketch/minhash.py:299-324).  One wave per pair, lanes
+// over the K positions (coalesced row reads), ballot + popcount.
+__global__ __launch_bounds__(256) void jaccard_pairs_kernel(const uint64_t *__restrict__ a, const uint64_t *__restrict__ b,
+                                                            int32_t k, const int64_t *__restrict__ pairs, int64_t m,
+                                                            int32_t *__restrict__ counts) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    for (int64_t p = (int64_t)blockIdx.x * waves_per_block + wave; p < m; p += (int64_t)gridDim.x * waves_per_block) {
+        const uint64_t *x = a + pairs[2 * p] * k;
+        const uint64_t *y = b + pairs[2 * p + 1] * k;
+        int32_t cnt = 0;
+        for (int c = lane; c < k + lane; c += kWave) {  // uniform trip count: every lane reaches the ballot
+            const bool eq = c < k && x[c] == y[c];
+            cnt += __popcll(__ballot(eq));
+        }
+        if (lane == 0) counts[p] = cnt;
+    }
+}
+
 inline dim3 row_grid(mhx_ctx *ctx, int64_t n) {
     const int64_t want = (n + 3) / 4;
     return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * 8)));
@@ -128,6 +176,23 @@ int launch_band_keys(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, 
     } else {
         hipLaunchKernelGGL(band_keys_kernel, row_grid(ctx, n), dim3(256), 0, ctx->stream, d_sig, n, k, w, d_out);
     }
+    MHX_HIP_CHECK(hipGetLastError());
+    return MHX_OK;
+}
+
+int launch_band_digests(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
+                        uint64_t *d_out) {
+    const int64_t want = (n * bands + 255) / 256;
+    dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * 16)));
+    hipLaunchKernelGGL(band_digest_kernel, grid, dim3(256), 0, ctx->stream, d_sig, n, k, bands, r, d_out);
+    MHX_HIP_CHECK(hipGetLastError());
+    return MHX_OK;
+}
+
+int launch_jaccard_pairs(mhx_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, int32_t k, const int64_t *d_pairs,
+                         int64_t m, int32_t *d_counts) {
+    hipLaunchKernelGGL(jaccard_pairs_kernel, row_grid(ctx, m), dim3(256), 0, ctx->stream, d_a, d_b, k, d_pairs, m,
+                       d_counts);
     MHX_HIP_CHECK(hipGetLastError());
     return MHX_OK;
 }

@@ -1,0 +1,159 @@
+"""Bulk helpers on the consumer side of the signature matrix.
+
+The reference's ``MinHashLSH`` stays what it is -- host-side control plane that duck-types on
+``.hashvalues`` -- and keeps working on our objects unchanged.  What this module adds is the
+whole-matrix form of the three per-object steps around it, so that 10^6 signatures do not cost 10^6
+Python round trips:
+
+* :func:`band_keys` / :func:`band_digests` -- every band key of every signature in one pass
+  (ref: datasketch/lsh.py:199,344,537-543), as the exact key bytes or as 64-bit FNV-1a digests of them;
+* :func:`insert_bulk` -- ``MinHashLSH.insert`` for a whole matrix (ref: lsh.py:326-347), through the
+  index's own storage API, leaving it in exactly the state the per-key loop would;
+* :func:`candidate_pairs` -- the pairs of rows that share at least one band (what ``query`` would find),
+  by grouping digests instead of probing dictionaries;
+* :func:`jaccard_pairs` -- ``MinHash.jaccard`` for a list of pairs (ref: datasketch/minhash.py:299-324).
+"""
+from __future__ import annotations
+
+import pickle
+from typing import Hashable, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+from datasketch_amd import _native
+
+_FNV_OFFSET = np.uint64(0xCBF29CE484222325)
+_FNV_PRIME = np.uint64(0x100000001B3)
+
+
+def fnv1a_64(data: bytes) -> int:
+    """64-bit FNV-1a of a byte string.  ``MinHashLSH(hashfunc=fnv1a_64)`` stores exactly the values
+    :func:`band_digests` computes."""
+    h = 0xCBF29CE484222325
+    for byte in bytes(data):
+        h = ((h ^ byte) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _use_gpu(gpu_mode: str) -> bool:
+    if gpu_mode == "always":
+        if not _native.gpu_available():
+            raise RuntimeError("GPU mode 'always' requested but no MI355X / libmhx.so is available.")
+        return True
+    return gpu_mode == "detect" and _native.gpu_available()
+
+
+def _matrix(signatures) -> np.ndarray:
+    sig = np.ascontiguousarray(signatures, dtype=np.uint64)
+    if sig.ndim != 2:
+        raise ValueError("signatures must be an [N, K] matrix")
+    return sig
+
+
+def _check_params(k: int, b: int, r: int) -> None:
+    if b <= 0 or r <= 0 or b * r > k:
+        raise ValueError("b*r must be in (0, num_perm]")
+
+
+def band_keys(signatures, b: int, r: int, gpu_mode: str = "detect") -> np.ndarray:
+    """``[N, b]`` array of ``numpy.void`` items of ``8*r`` bytes: item ``[i, j]`` holds exactly
+    ``MinHashLSH._H(hashvalues[j*r:(j+1)*r])`` of row ``i`` (big-endian words, ref: lsh.py:537-538).
+    ``.tolist()`` gives nested lists of ``bytes``; ``bytes(out[i, j])`` one key."""
+    sig = _matrix(signatures)
+    n, k = sig.shape
+    _check_params(k, b, r)
+    if _use_gpu(gpu_mode):
+        swapped = _native.context().band_keys(sig, b, r)
+    else:
+        swapped = sig[:, : b * r].byteswap()
+    swapped = np.ascontiguousarray(swapped).reshape(n, b * r)
+    return swapped.view(np.dtype((np.void, 8 * r))).reshape(n, b)
+
+
+def band_digests(signatures, b: int, r: int, gpu_mode: str = "detect") -> np.ndarray:
+    """``[N, b]`` uint64: FNV-1a-64 of every band key (equal digests <=> same bucket)."""
+    sig = _matrix(signatures)
+    n, k = sig.shape
+    _check_params(k, b, r)
+    if _use_gpu(gpu_mode):
+        return _native.context().band_digests(sig, b, r)
+    key_bytes = np.ascontiguousarray(sig[:, : b * r].byteswap()).view(np.uint8).reshape(n, b, 8 * r)
+    h = np.full((n, b), _FNV_OFFSET, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for c in range(8 * r):
+            h = (h ^ key_bytes[:, :, c].astype(np.uint64)) * _FNV_PRIME
+    return h
+
+
+def insert_bulk(lsh, keys: Iterable[Hashable], signatures, check_duplication: bool = True, gpu_mode: str = "detect") -> None:
+    """``for key, row in zip(keys, signatures): lsh.insert(key, MinHash(hashvalues=row))`` in bulk.
+
+    ``lsh`` is a ``datasketch.MinHashLSH`` (or anything with its attributes ``h, b, r, keys,
+    hashtables, prepickle, hashfunc``).  Validation, key pickling, duplicate check and the storage
+    calls are those of ref: datasketch/lsh.py:326-347; only the ``b`` band keys per signature come
+    from one pass over the matrix instead of ``b`` numpy slices per object."""
+    sig = _matrix(signatures)
+    n, k = sig.shape
+    if k != lsh.h:
+        raise ValueError("Expecting minhash with length %d, got %d" % (lsh.h, k))
+    keys = list(keys)
+    if len(keys) != n:
+        raise ValueError("keys and signatures must have the same length")
+    if getattr(lsh, "_require_bytes_keys", False):
+        for key in keys:
+            if not isinstance(key, bytes):
+                raise TypeError(
+                    f"prepickle=False requires bytes keys for non-dict storage, got {type(key).__name__}. "
+                    "Either pass bytes keys or use prepickle=True for automatic serialization."
+                )
+    if lsh.prepickle:
+        keys = [pickle.dumps(key) for key in keys]
+    if check_duplication:
+        seen = set()
+        for key in keys:
+            if key in seen or key in lsh.keys:
+                raise ValueError("The given key already exists")
+            seen.add(key)
+    columns = band_keys(sig, lsh.b, lsh.r, gpu_mode=gpu_mode).T.tolist()  # b lists of N bytes objects
+    hashfunc = getattr(lsh, "hashfunc", None)
+    if hashfunc is not None:
+        columns = [[hashfunc(h) for h in col] for col in columns]
+    for i, key in enumerate(keys):
+        lsh.keys.insert(key, *[col[i] for col in columns], buffer=False)
+    for col, hashtable in zip(columns, lsh.hashtables):
+        for h, key in zip(col, keys):
+            hashtable.insert(h, key, buffer=False)
+
+
+def candidate_pairs(signatures, b: int, r: int, gpu_mode: str = "detect") -> np.ndarray:
+    """``[M, 2]`` int64, sorted, unique pairs ``i < j`` of rows that share the key of at least one band
+    -- the pairs ``MinHashLSH(params=(b, r))`` would report for each other."""
+    dig = band_digests(signatures, b, r, gpu_mode=gpu_mode)
+    n = dig.shape[0]
+    found: List[np.ndarray] = []
+    for j in range(b):
+        col = dig[:, j]
+        order = np.argsort(col, kind="stable")
+        s = col[order]
+        starts = np.flatnonzero(np.concatenate([[True], s[1:] != s[:-1]]))
+        ends = np.concatenate([starts[1:], [n]])
+        for a, e in zip(starts[ends - starts > 1], ends[ends - starts > 1]):
+            rows = np.sort(order[a:e])
+            ii, jj = np.triu_indices(rows.size, k=1)
+            found.append(np.stack([rows[ii], rows[jj]], axis=1))
+    if not found:
+        return np.empty((0, 2), dtype=np.int64)
+    return np.unique(np.concatenate(found).astype(np.int64), axis=0)
+
+
+def jaccard_pairs(signatures, pairs, gpu_mode: str = "detect") -> np.ndarray:
+    """``MinHash.jaccard`` of rows ``pairs[:, 0]`` and ``pairs[:, 1]``: float64, equal positions / K."""
+    sig = _matrix(signatures)
+    pairs = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+    if pairs.size and (pairs.min() < 0 or pairs.max() >= sig.shape[0]):
+        raise ValueError("pair index out of range")
+    if _use_gpu(gpu_mode):
+        counts = _native.context().jaccard_pairs(sig, pairs)
+    else:
+        counts = np.count_nonzero(sig[pairs[:, 0]] == sig[pairs[:, 1]], axis=1)
+    return counts.astype(np.float64) / float(sig.shape[1])

@@ -206,6 +206,21 @@ MHX_API int mhx_band_keys_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n_sig
                               int32_t bands, int32_t r, uint64_t *d_out);
 MHX_API int mhx_band_keys(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs, int32_t num_perm,
                           int32_t bands, int32_t r, uint64_t *out);
+/* 64-bit band digests for device-side bucketing: out[n, bands], out[i,j] = FNV-1a-64 of the band key
+ * bytes of band j of row i (the very bytes of mhx_band_keys; what ref: datasketch/lsh.py:540-543 stores
+ * for MinHashLSH(hashfunc=fnv1a_64)).  Equal digests <=> same LSH bucket (up to 2^-64 collisions). */
+MHX_API int mhx_band_digests_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n_sigs, int32_t num_perm,
+                                 int32_t bands, int32_t r, uint64_t *d_out);
+MHX_API int mhx_band_digests(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs, int32_t num_perm,
+                             int32_t bands, int32_t r, uint64_t *out);
+/* Batched MinHash.jaccard numerators (ref: datasketch/minhash.py:299-324): counts[p] = number of equal
+ * positions of rows pairs[p][0] of sig_a and pairs[p][1] of sig_b (both [*, num_perm] uint64; may be the
+ * same matrix); the estimate is counts / num_perm.  pairs int64[n_pairs, 2]. */
+MHX_API int mhx_jaccard_pairs_dev(mhx_ctx *ctx, const uint64_t *d_sig_a, const uint64_t *d_sig_b,
+                                  int32_t num_perm, const int64_t *d_pairs, int64_t n_pairs,
+                                  int32_t *d_counts);
+MHX_API int mhx_jaccard_pairs(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs, int32_t num_perm,
+                              const int64_t *pairs, int64_t n_pairs, int32_t *counts);
 /* LeanMinHash.serialize of every row, little-endian: n records of 12+4*K bytes
  * (ref: datasketch/lean_minhash.py:126-175). */
 MHX_API int mhx_lean_serialize_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n_sigs,

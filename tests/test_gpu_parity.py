@@ -661,3 +661,28 @@ def test_bulk_on_byte_tokens_matches_host_hashing(ctx):
     for m in (m64, r64):
         m.update_batch(sets[7] + sets[8])
     assert m64 == r64
+
+
+# ------------------------------------------------------------------ consumer side in bulk (rows f1, f4)
+def test_band_digests_candidates_and_jaccard_on_device(ctx):
+    from datasketch_amd import lsh_bulk as LB
+
+    rng = np.random.RandomState(4)
+    tok = rng.randint(0, 2**32, (3000, 64), dtype=np.uint64)
+    tok[5::11] = tok[3:4]
+    sig = MinHash.bulk_signatures(tok, num_perm=128, seed=1, hashfunc=prehashed, gpu_mode="always")
+    for b, r in ((32, 4), (16, 8), (5, 25), (1, 128), (128, 1)):
+        assert np.array_equal(LB.band_digests(sig, b, r, gpu_mode="always"), LB.band_digests(sig, b, r, gpu_mode="disable")), (b, r)
+        dev, host = LB.band_keys(sig, b, r, gpu_mode="always"), LB.band_keys(sig, b, r, gpu_mode="disable")
+        assert dev.tobytes() == host.tobytes()
+    pairs = LB.candidate_pairs(sig, 32, 4, gpu_mode="always")
+    assert np.array_equal(pairs, LB.candidate_pairs(sig, 32, 4, gpu_mode="disable")) and len(pairs) > 1000
+    extra = rng.randint(0, 3000, (5000, 2))
+    allp = np.concatenate([pairs, extra])
+    assert np.array_equal(LB.jaccard_pairs(sig, allp, gpu_mode="always"), LB.jaccard_pairs(sig, allp, gpu_mode="disable"))
+    for k in (1, 63, 64, 65, 200):
+        s2 = rng.randint(0, 3, (100, k)).astype(np.uint64)
+        p2 = rng.randint(0, 100, (400, 2))
+        assert np.array_equal(LB.jaccard_pairs(s2, p2, gpu_mode="always"), LB.jaccard_pairs(s2, p2, gpu_mode="disable")), k
+    with pytest.raises(ValueError):
+        ctx.jaccard_pairs(sig, np.array([[0, 3000]]))

@@ -1,0 +1,94 @@
+"""Consumer-side bulk helpers (datasketch_amd/lsh_bulk.py): band keys, digests, bulk LSH insert,
+candidate pairs, batched Jaccard.  The CPU tests use the numpy fallbacks; where the reference
+repository is mounted (/root/reference, build container only) its own MinHashLSH is the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from datasketch_amd import MinHash, prehashed
+from datasketch_amd import lsh_bulk as LB
+
+REFERENCE = "/root/reference"
+
+
+def _signatures(n=300, t=40, k=64, seed=0, dup_every=7):
+    rng = np.random.RandomState(seed)
+    tok = rng.randint(0, 2**32, (n, t), dtype=np.uint64)
+    tok[dup_every::dup_every] = tok[0:1]  # clusters of identical sets
+    near = tok[1].copy()
+    near[:4] = rng.randint(0, 2**32, 4, dtype=np.uint64)
+    tok[2] = near  # a near duplicate of row 1
+    return MinHash.bulk_signatures(tok, num_perm=k, seed=1, hashfunc=prehashed, gpu_mode="disable")
+
+
+def test_band_keys_are_the_reference_key_bytes():
+    sig = _signatures()
+    keys = LB.band_keys(sig, 8, 8, gpu_mode="disable")
+    assert keys.shape == (sig.shape[0], 8)
+    for i in (0, 5, 299):
+        for j in (0, 3, 7):
+            assert bytes(keys[i, j]) == bytes(sig[i, j * 8 : (j + 1) * 8].byteswap().data)  # lsh.py:537-538
+    assert keys.T.tolist()[2][5] == bytes(keys[5, 2])
+    with pytest.raises(ValueError):
+        LB.band_keys(sig, 9, 8, gpu_mode="disable")
+
+
+def test_band_digests_are_fnv1a_of_the_key_bytes():
+    sig = _signatures(n=50)
+    dig = LB.band_digests(sig, 4, 16, gpu_mode="disable")
+    keys = LB.band_keys(sig, 4, 16, gpu_mode="disable")
+    for i in (0, 7, 49):
+        for j in range(4):
+            assert int(dig[i, j]) == LB.fnv1a_64(bytes(keys[i, j]))
+    assert LB.fnv1a_64(b"") == 0xCBF29CE484222325 and LB.fnv1a_64(b"a") == 0xAF63DC4C8601EC8C  # published test vectors
+
+
+def test_candidate_pairs_and_jaccard_pairs():
+    sig = _signatures()
+    pairs = LB.candidate_pairs(sig, 16, 4, gpu_mode="disable")
+    # brute force: rows sharing any band
+    bands = sig[:, : 16 * 4].reshape(sig.shape[0], 16, 4)
+    want = set()
+    for i in range(sig.shape[0]):
+        same = np.any(np.all(bands[i][None] == bands, axis=2), axis=1)
+        want.update((i, int(j)) for j in np.flatnonzero(same) if j > i)
+    assert set(map(tuple, pairs.tolist())) == want and len(pairs) == len(want)
+    jac = LB.jaccard_pairs(sig, pairs, gpu_mode="disable")
+    for (i, j), est in list(zip(pairs.tolist(), jac))[:200]:
+        a, b = MinHash(seed=1, hashvalues=sig[i]), MinHash(seed=1, hashvalues=sig[j])
+        assert est == a.jaccard(b)
+    assert LB.jaccard_pairs(sig, np.empty((0, 2), np.int64), gpu_mode="disable").size == 0
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference repository not mounted")
+@pytest.mark.parametrize("prepickle,use_hashfunc", [(False, False), (True, False), (False, True)])
+def test_insert_bulk_leaves_the_reference_index_in_the_same_state(prepickle, use_hashfunc):
+    sys.path.insert(0, REFERENCE)
+    try:
+        import datasketch as ref
+    finally:
+        sys.path.remove(REFERENCE)
+    sig = _signatures(n=200, k=64)
+    keys = [f"doc-{i}" for i in range(sig.shape[0])]
+    kw = dict(threshold=0.5, num_perm=64, prepickle=prepickle)
+    if use_hashfunc:
+        kw["hashfunc"] = LB.fnv1a_64
+    one, bulk = ref.MinHashLSH(**kw), ref.MinHashLSH(**kw)
+    for key, row in zip(keys, sig):
+        one.insert(key, ref.MinHash(num_perm=64, seed=1, hashvalues=row))
+    LB.insert_bulk(bulk, keys, sig, gpu_mode="disable")
+    assert one.b == bulk.b and one.r == bulk.r
+    for t1, t2 in zip(one.hashtables, bulk.hashtables):
+        assert dict(t1._dict) == dict(t2._dict)
+    assert dict(one.keys._dict) == dict(bulk.keys._dict)
+    probe = ref.MinHash(num_perm=64, seed=1, hashvalues=sig[0])
+    assert sorted(one.query(probe)) == sorted(bulk.query(probe)) and len(one.query(probe)) > 1
+    with pytest.raises(ValueError):
+        LB.insert_bulk(bulk, keys[:1], sig[:1], gpu_mode="disable")  # duplicate key
+    with pytest.raises(ValueError):
+        LB.insert_bulk(bulk, ["x"], sig[:1, :32], gpu_mode="disable")  # wrong length
+    if use_hashfunc:  # the digests are what the index stores
+        dig = LB.band_digests(sig, one.b, one.r, gpu_mode="disable")
+        assert set(one.hashtables[0]._dict) == set(int(x) for x in dig[:, 0])
