@@ -31,6 +31,9 @@
 // pre-pass (NaN, out-of-range): anything outside goes through the true IEEE division instead, so
 // the (k, t) pairs are bit-identical to numpy's in all cases.
 //
+// (Handing the blocked kernel the logs already converted to double by the pre-pass was measured:
+// 8 % slower -- the extra 8 B per element through the scalar cache cost more than the conversion.)
+//
 // Row blocking.  The table is 5 words per (column, sample): at one row per wave the kernel is
 // bound by L2 bandwidth, not arithmetic.  Blocks of 8 consecutive rows that share one column
 // list (every block of a dense matrix) are hashed together: table entries are loaded once per
@@ -44,7 +47,7 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kRowBlock = 8;   // rows hashed together when they share their column list
-constexpr int kColChunk = 4;   // columns per software-pipeline stage
+constexpr int kColChunk = 2;   // columns per software-pipeline stage (2: 72 VGPRs, 7 waves/SIMD; 4 is 10 % slower, 1 and 3 in between)
 constexpr int kWords = 5;      // table words per (column, sample)
 #define MHX_CONST_AS __attribute__((address_space(4)))
 
