@@ -266,22 +266,32 @@ __device__ __forceinline__ void hash_range(const TokT MHX_CONST_AS *hv, int64_t 
 //     smallest key is >= 16  (no token then has s_lo in [2^32-8, 2^32), the only place where
 //     s_lo + top + ge can wrap).
 // So the token with the smallest R is among the tokens with M <= min M + 8.  A block of up to 256
-// tokens is laid out as a 16 x 16 grid (row, column), every token in exactly one cell, and the
-// kernel keeps min M per row and per column: one v_mad_u64_u32 and two half v_min3_u32 per pair
-// instead of two multiplies, shift, add and half a min3.  Row/column minima are tagged with
-// their index in the low 4 bits (key & ~15 | idx); with k1 < k2 the two smallest tagged values,
-// k2 - k1 >= 32 proves that every token outside the best row (column) has M >= min M + 17.  If
-// that holds for rows and columns, cell (best row, best column) is the ONLY token with
-// M <= min M + 16: it alone is fetched (one per-lane load) and hashed exactly.  If any proof
-// fails in any lane (equal tokens at the minimum, two keys within 32, min key < 16, probability
-// about 1e-5 per set of distinct random tokens) the whole set is redone by the full evaluation,
-// so results stay bit-exact unconditionally.
-// Grid mapping for token w of a 32-token group g (8 quads of 4 consecutive tokens):
-//     row = 2*g + bit1(w),  column = 2*(w >> 2) + bit0(w)
-// i.e. a quad {w, w+1, w+2, w+3} covers rows {r, r, r+1, r+1} and columns {c, c+1, c, c+1}: both
-// v_min3 of a quad take two fresh keys, and all column indices are compile-time constants.
-constexpr int kGroupTokens = 32;
-constexpr int kBlockGroups = 8;  // 16 rows
+// tokens is cut into rows of 16 consecutive tokens and the hot loop only keeps min M per row: one
+// v_mad_u64_u32 per pair and one v_min3_u32 per TWO pairs, instead of two multiplies, shift, add
+// and half a min3.  Finished rows are tagged with their index in the low 4 bits (key & ~15 | row)
+// and folded into the two smallest tagged values k1 < k2; k2 - k1 >= 32 proves that every token
+// outside the best row has M >= min M + 17.  The best row is then rescanned (16 keys, the same
+// k1/k2 fold over the column index): if its two smallest keys are also >= 32 apart, (best row,
+// best column) is the ONLY token with M <= min M + 16: it alone is hashed exactly.  The rescan
+// reads per-lane addresses (every lane has its own best row), which the vector memory path serves
+// at one lane per clock -- 34 such loads per set made the kernel texture-address bound (3.7 ms).
+// So each block is also copied once, coalesced, into a wave-private LDS tile (rows padded to
+// distinct banks) and the rescan reads LDS.  If a proof fails in any lane (equal tokens at the minimum, two keys within 32, min
+// key < 16; about 4 sets in 10^4 of distinct random tokens) the whole set is redone by the full
+// evaluation, so results stay bit-exact unconditionally.
+// (Round-1 history: the first sieve kept row AND column minima in the hot loop -- two half min3 per
+// pair -- to pin the cell down without a rescan; the rescan costs 16 keys per block instead of 256
+// column updates and frees 32 VGPRs.)
+constexpr int kRowTokens = 16;
+constexpr int kBlockRows = 16;  // 256 tokens
+// LDS tile of one block: row stride in dwords.  144 B (uint64 tokens) / 80 B (uint32): multiples of
+// 16 B for ds_write_b128, and the 16 row starts fall into 16 different banks (36*r and 20*r mod 64).
+template <typename TokT>
+struct StageLayout {
+    static constexpr int kStride = sizeof(TokT) == 8 ? 36 : 20;
+    static constexpr int kWordsPerTok = sizeof(TokT) / 4;
+};
+constexpr int kStageWordsPerWave = kBlockRows * 36;
 
 __device__ __forceinline__ uint32_t sieve_key(uint32_t h, uint32_t a_lo, uint64_t b8) {
     // Only the low word is used, but one v_mad_u64_u32 beats v_mul_lo_u32 + v_add_u32; the empty
@@ -305,135 +315,138 @@ struct SievePerms {
     bool active[P];  // lane holds a real permutation (k < num_perm)
 };
 
-// One chunk of a group: quads QBASE .. QBASE + N/4 - 1 of the group.
-template <int P, typename TokT, int QBASE>
-__device__ __forceinline__ void sieve_chunk(const Chunk<TokT> &c, const SievePerms<P> &sp, uint32_t (&row)[P][2],
-                                            uint32_t (&col)[P][16]) {
+// (smallest, second smallest) of the tagged keys seen so far
+struct Two {
+    uint32_t k1 = kMaxHash, k2 = kMaxHash;
+    __device__ __forceinline__ void add(uint32_t key) {
+        k2 = umed3(k1, k2, key);
+        k1 = min(k1, key);
+    }
+    __device__ __forceinline__ bool apart() const { return k2 - k1 >= 32u; }  // k2 >= k1 always
+};
+
+// fold the keys of one chunk into the row minimum; OPEN: the chunk starts the row
+template <int P, typename TokT, bool OPEN>
+__device__ __forceinline__ void sieve_chunk(const Chunk<TokT> &c, const SievePerms<P> &sp, uint32_t (&row)[P]) {
     constexpr int N = Chunk<TokT>::N;
     c.keep_whole();
 #pragma unroll
-    for (int q = 0; q < N / 4; ++q) {
-        const int qd = QBASE + q;
+    for (int i = 0; i < N; i += 4) {
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const uint32_t m00 = sieve_key(c.lo(4 * q + 0), sp.a_lo[p], sp.b8[p]);
-            const uint32_t m01 = sieve_key(c.lo(4 * q + 1), sp.a_lo[p], sp.b8[p]);
-            const uint32_t m10 = sieve_key(c.lo(4 * q + 2), sp.a_lo[p], sp.b8[p]);
-            const uint32_t m11 = sieve_key(c.lo(4 * q + 3), sp.a_lo[p], sp.b8[p]);
-            if (qd == 0) {  // first quad of the group starts its two rows
-                row[p][0] = min(m00, m01);
-                row[p][1] = min(m10, m11);
-            } else {
-                row[p][0] = umin3(row[p][0], m00, m01);
-                row[p][1] = umin3(row[p][1], m10, m11);
-            }
-            col[p][2 * qd] = umin3(col[p][2 * qd], m00, m10);
-            col[p][2 * qd + 1] = umin3(col[p][2 * qd + 1], m01, m11);
+            const uint32_t m0 = sieve_key(c.lo(i + 0), sp.a_lo[p], sp.b8[p]);
+            const uint32_t m1 = sieve_key(c.lo(i + 1), sp.a_lo[p], sp.b8[p]);
+            const uint32_t m2 = sieve_key(c.lo(i + 2), sp.a_lo[p], sp.b8[p]);
+            const uint32_t m3 = sieve_key(c.lo(i + 3), sp.a_lo[p], sp.b8[p]);
+            row[p] = (OPEN && i == 0) ? min(m0, m1) : umin3(row[p], m0, m1);
+            row[p] = umin3(row[p], m2, m3);
         }
-        // pin the column updates here: left alone, the optimiser sinks all of them to the end of
-        // the group and keeps every key of the group live (200 VGPRs)
+        // pin the minima here: left alone, the optimiser hoists every multiply of the chunk above
+        // the first min3 and keeps all their results live (113 VGPRs instead of ~70)
         if constexpr (P == 1)
-            asm volatile("" : "+v"(col[0][2 * qd]), "+v"(col[0][2 * qd + 1]));
+            asm volatile("" : "+v"(row[0]));
         else
-            asm volatile("" : "+v"(col[0][2 * qd]), "+v"(col[0][2 * qd + 1]), "+v"(col[P - 1][2 * qd]),
-                         "+v"(col[P - 1][2 * qd + 1]));
-        __builtin_amdgcn_sched_barrier(0);  // one quad at a time: 4P keys live, not 4P * N/4
+            asm volatile("" : "+v"(row[0]), "+v"(row[P - 1]));
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// Exact minima over the first ngroups*32 tokens of [beg, ...) into res (min-combined); returns
-// true in lanes whose proof failed (the caller redoes the set).  All arguments wave-uniform
-// except the per-lane permutation registers.
+// Exact minima over the first nrows*16 tokens of [beg, ...) into res (min-combined); returns true
+// in lanes whose proof failed (the caller redoes the range).  All arguments wave-uniform except the
+// per-lane permutation registers.
 template <int P, typename TokT>
 __device__ __forceinline__ bool sieve_range(const TokT MHX_CONST_AS *hv, const TokT *hv_vec, int64_t beg,
-                                            int ngroups, const Perms<P> &pm, const SievePerms<P> &sp,
-                                            uint32_t (&res)[P], int &nblocks) {
+                                            int nrows, const Perms<P> &pm, const SievePerms<P> &sp,
+                                            uint32_t *lds, int lane, uint32_t (&res)[P], int &nblocks) {
     constexpr int N = Chunk<TokT>::N;
-    constexpr int CPG = kGroupTokens / N;  // chunks per group: 4 (uint64 tokens) or 2 (uint32)
+    constexpr int CPR = kRowTokens / N;  // chunks per row: 2 (uint64 tokens) or 1 (uint32)
+    constexpr int STRIDE = StageLayout<TokT>::kStride, WPT = StageLayout<TokT>::kWordsPerTok;
     const TokT MHX_CONST_AS *p = hv + beg;
-    const int nchunks = ngroups * CPG;
+    const int nchunks = nrows * CPR;
     const auto chunk_ptr = [&](int idx) { return p + (int64_t)(idx < nchunks ? idx : nchunks - 1) * N; };
     Chunk<TokT> a, b;
     a.load(p);
     int ci = 0;  // chunk held by `a`
     bool fail = false;
-    for (int g0 = 0; g0 < ngroups; g0 += kBlockGroups) {
-        const int gb = min(kBlockGroups, ngroups - g0);
-        uint32_t col[P][16], k1r[P], k2r[P];
-#pragma unroll
-        for (int q = 0; q < P; ++q) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) col[q][j] = kMaxHash;
-            k1r[q] = kMaxHash;
-            k2r[q] = kMaxHash;
+    for (int r0 = 0; r0 < nrows; r0 += kBlockRows) {
+        const int rb = min(kBlockRows, nrows - r0);
+        const int64_t blk = beg + (int64_t)r0 * kRowTokens;
+        // the block's tokens for the LDS tile: lane l carries 4 tokens (a quarter row); requested now,
+        // needed after the row loop
+        const int my_row = lane >> 2, my_part = lane & 3;
+        uint4 st0 = {0, 0, 0, 0}, st1 = {0, 0, 0, 0};
+        if (my_row < rb) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(hv_vec + blk + 4 * lane);
+            st0 = src[0];
+            if (WPT == 2) st1 = src[1];
         }
-        for (int g = 0; g < gb; ++g) {
-            uint32_t row[P][2];
-            // wait for the current chunk, THEN issue the next prefetch, then hash: one chunk of VALU
-            // work (about 70 instructions) hides every scalar load
-            if constexpr (CPG == 4) {
-                a.arrived();
-                b.load(chunk_ptr(ci + 1));
-                __builtin_amdgcn_sched_barrier(0);
-                sieve_chunk<P, TokT, 0>(a, sp, row, col);
-                b.arrived();
-                a.load(chunk_ptr(ci + 2));
-                __builtin_amdgcn_sched_barrier(0);
-                sieve_chunk<P, TokT, 2>(b, sp, row, col);
-                a.arrived();
-                b.load(chunk_ptr(ci + 3));
-                __builtin_amdgcn_sched_barrier(0);
-                sieve_chunk<P, TokT, 4>(a, sp, row, col);
-                b.arrived();
-                a.load(chunk_ptr(ci + 4));
-                __builtin_amdgcn_sched_barrier(0);
-                sieve_chunk<P, TokT, 6>(b, sp, row, col);
+        Two rows[P];
+        // Scalar loads return out of order, so the only wait is lgkmcnt(0): wait for the current
+        // chunk (a use BEFORE the next prefetch is issued), THEN issue the prefetch, then hash.
+        for (int r = 0; r < rb; r += 2) {
+            uint32_t row0[P], row1[P];
+            a.arrived();
+            b.load(chunk_ptr(ci + 1));
+            __builtin_amdgcn_sched_barrier(0);
+            sieve_chunk<P, TokT, true>(a, sp, row0);
+            b.arrived();
+            a.load(chunk_ptr(ci + 2));
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (CPR == 2) {
+                sieve_chunk<P, TokT, false>(b, sp, row0);  // second half of row r
             } else {
-                a.arrived();
-                b.load(chunk_ptr(ci + 1));
-                __builtin_amdgcn_sched_barrier(0);
-                sieve_chunk<P, TokT, 0>(a, sp, row, col);
-                b.arrived();
-                a.load(chunk_ptr(ci + 2));
-                __builtin_amdgcn_sched_barrier(0);
-                sieve_chunk<P, TokT, 4>(b, sp, row, col);
+                sieve_chunk<P, TokT, true>(b, sp, row1);   // row r + 1 (uint32 tokens: a row is one chunk)
             }
-            ci += CPG;
-            // the two rows of this group are complete: fold them into (smallest, second smallest)
+            ci += 2;
+            const bool second = r + 1 < rb;  // wave-uniform
+            if constexpr (CPR == 2) {
+                if (second) {
+                    a.arrived();
+                    b.load(chunk_ptr(ci + 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    sieve_chunk<P, TokT, true>(a, sp, row1);
+                    b.arrived();
+                    a.load(chunk_ptr(ci + 2));
+                    __builtin_amdgcn_sched_barrier(0);
+                    sieve_chunk<P, TokT, false>(b, sp, row1);
+                    ci += 2;
+                }
+            } else {
+                if (!second) ci -= 1;  // odd row count: chunk `b` was the clamped prefetch, not a row
+            }
 #pragma unroll
             for (int q = 0; q < P; ++q) {
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const uint32_t key = tag16(row[q][r], (uint32_t)(2 * g + r));
-                    k2r[q] = umed3(k1r[q], k2r[q], key);
-                    k1r[q] = min(k1r[q], key);
-                }
+                rows[q].add(tag16(row0[q], (uint32_t)r));
+                if (second) rows[q].add(tag16(row1[q], (uint32_t)(r + 1)));
             }
         }
-        // block complete: columns, proofs, the one candidate token per permutation
-        const int64_t blk = beg + (int64_t)g0 * kGroupTokens;
+        // block complete: tile -> LDS (wave-private, so program order is enough: no barrier), then
+        // rescan the best row of every permutation, prove, hash the one candidate
+        {
+            uint4 *dst = reinterpret_cast<uint4 *>(lds + my_row * STRIDE + my_part * (4 * WPT));
+            dst[0] = st0;
+            if (WPT == 2) dst[1] = st1;
+        }
+        Two cols[P];
+        uint64_t best[P];
 #pragma unroll
         for (int q = 0; q < P; ++q) {
-            uint32_t key[16];
+            const uint32_t *rowp = lds + (rows[q].k1 & 15u) * STRIDE;  // per-lane LDS address
 #pragma unroll
-            for (int j = 0; j < 16; ++j) key[j] = tag16(col[q][j], (uint32_t)j);
-            uint32_t k1c = umin3(key[0], key[1], key[2]);
+            for (int c = 0; c < kRowTokens; ++c) {
+                const uint32_t m = (uint32_t)((uint64_t)rowp[c * WPT] * sp.a_lo[q] + sp.b8[q]);
+                cols[q].add(tag16(m, (uint32_t)c));
+            }
+            const uint32_t j1 = cols[q].k1 & 15u;
+            best[q] = WPT == 2 ? *reinterpret_cast<const uint64_t *>(rowp + 2 * j1) : (uint64_t)rowp[j1];
+            __builtin_amdgcn_sched_barrier(0);  // one permutation's 16 LDS words at a time (registers)
+        }
 #pragma unroll
-            for (int j = 3; j < 15; j += 2) k1c = umin3(k1c, key[j], key[j + 1]);
-            k1c = min(k1c, key[15]);
-            // second smallest: key - (k1c + 1) wraps to 2^32-1 for the smallest itself
-            const uint32_t t = k1c + 1u;
-            uint32_t dmin = umin3(key[0] - t, key[1] - t, key[2] - t);
-#pragma unroll
-            for (int j = 3; j < 15; j += 2) dmin = umin3(dmin, key[j] - t, key[j + 1] - t);
-            dmin = min(dmin, key[15] - t);
-            const bool ok = (dmin >= 31u) && (k2r[q] - k1r[q] >= 32u) && (k1c >= 16u);
+        for (int q = 0; q < P; ++q) {
+            const bool ok = rows[q].apart() && cols[q].apart() && cols[q].k1 >= 16u;
             fail |= sp.active[q] && !ok;
-            const uint32_t i1 = k1r[q] & 15u, j1 = k1c & 15u;
-            const uint32_t w = ((i1 >> 1) << 5) | ((j1 >> 1) << 2) | ((i1 & 1u) << 1) | (j1 & 1u);
-            const uint64_t tok = hv_vec[blk + w];  // per-lane gather, always inside the block
             uint32_t l0, h0;
-            mad_wide((uint32_t)tok, (uint32_t)(tok >> 32), pm.a_lo[q], pm.a_hi[q], pm.b[q], l0, h0);
+            mad_wide((uint32_t)best[q], (uint32_t)(best[q] >> 32), pm.a_lo[q], pm.a_hi[q], pm.b[q], l0, h0);
             res[q] = min(res[q], fold_exact(l0, h0));
         }
         ++nblocks;
@@ -495,27 +508,25 @@ __device__ __forceinline__ Minima<P> full_minima(const TokT *hv_vec, int64_t beg
     return res;
 }
 
-// Sieve over the full 32-token groups of [beg,end) plus fast fold for the ragged tail.  Returns
-// true (wave-uniform) when a proof failed or a tail minimum is ambiguous: the caller then redoes
-// the range with full_minima.  (Sieving the tail too -- top quads of a window [end-32,end) with
-// guarded quads -- was tried: the guards and the second code path cost the dense case 10 % and
-// gained the ragged one nothing.)
+// Sieve over the full 16-token rows of [beg,end) plus fast fold for the ragged tail.  Returns true
+// (wave-uniform) when a proof failed or a tail minimum is ambiguous: the caller then redoes the
+// range with full_minima.
 template <int P, typename TokT>
 __device__ __forceinline__ bool sieve_minima(const TokT MHX_CONST_AS *hv, const TokT *hv_vec, int64_t beg,
                                              int64_t end, const Perms<P> &pm, const Perms<P> &pm_biased,
                                              const SievePerms<P> &sp, unsigned long long *stats, int lane,
-                                             uint32_t (&res)[P]) {
+                                             uint32_t *lds, uint32_t (&res)[P]) {
     const int64_t n = end - beg;
-    const int ngroups = (int)min(n / kGroupTokens, (int64_t)(1 << 26));
+    const int nrows = (int)min(n / kRowTokens, (int64_t)(1 << 27));
 #pragma unroll
     for (int p = 0; p < P; ++p) res[p] = kMaxHash;
     bool bad = false;
-    if (ngroups > 0) {
+    if (nrows > 0) {
         int nblocks = 0;
-        bad = sieve_range<P, TokT>(hv, hv_vec, beg, ngroups, pm, sp, res, nblocks);
+        bad = sieve_range<P, TokT>(hv, hv_vec, beg, nrows, pm, sp, lds, lane, res, nblocks);
         if (stats && lane == 0) atomicAdd(stats + 2, (unsigned long long)nblocks);
     }
-    const int64_t tail = beg + (int64_t)ngroups * kGroupTokens;
+    const int64_t tail = beg + (int64_t)nrows * kRowTokens;
     if (tail < end) {
         uint32_t acc[P];
 #pragma unroll
@@ -548,14 +559,14 @@ template <int P, typename TokT>
 __device__ __forceinline__ void set_minima(const BulkArgs &args, const TokT MHX_CONST_AS *hv, const TokT *hv_vec,
                                            int64_t beg, int64_t end, const Perms<P> &pm,
                                            const Perms<P> &pm_biased, const SievePerms<P> &sp, int kbase,
-                                           int lane, SieveBackoff &bo, uint32_t (&res)[P]) {
+                                           int lane, uint32_t *lds, SieveBackoff &bo, uint32_t (&res)[P]) {
     bool full = args.path != 0;
     if (!full) {
         if (bo.skip > 0) {
             --bo.skip;
             full = true;
         } else {
-            full = sieve_minima<P, TokT>(hv, hv_vec, beg, end, pm, pm_biased, sp, args.stats, lane, res);
+            full = sieve_minima<P, TokT>(hv, hv_vec, beg, end, pm, pm_biased, sp, args.stats, lane, lds, res);
             if (full) {
                 bo.skip = bo.gap;
                 bo.gap = min(2 * bo.gap, 64);
@@ -601,6 +612,8 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_block = blockDim.x >> 6;
     const int kchunks = (args.num_perm + kWave * P - 1) / (kWave * P);
+    __shared__ __attribute__((aligned(16))) uint32_t stage[4 * kStageWordsPerWave];  // one tile per wave
+    uint32_t *lds = stage + wave * kStageWordsPerWave;
     Perms<P> pm, pm_biased;
     SievePerms<P> sp;
     int kidx[P];
@@ -640,7 +653,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) 
             if (kchunks > 1) load_perms<P>(args, kc * (kWave * P), lane, pm, pm_biased, sp, kidx);
             uint32_t res[P];
             if (end > beg)
-                set_minima<P, TokT>(args, hv, hv_vec, beg, end, pm, pm_biased, sp, kc * (kWave * P), lane, backoff, res);
+                set_minima<P, TokT>(args, hv, hv_vec, beg, end, pm, pm_biased, sp, kc * (kWave * P), lane, lds, backoff, res);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 if (kidx[p] < 0) continue;
@@ -689,6 +702,8 @@ __global__ __launch_bounds__(256) void minhash_split_kernel(const BulkArgs args,
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_block = blockDim.x >> 6;
+    __shared__ __attribute__((aligned(16))) uint32_t stage[4 * kStageWordsPerWave];  // one tile per wave
+    uint32_t *lds = stage + wave * kStageWordsPerWave;
     Perms<P> pm, pm_biased;
     SievePerms<P> sp;
     int kidx[P];
@@ -723,7 +738,7 @@ __global__ __launch_bounds__(256) void minhash_split_kernel(const BulkArgs args,
             const int64_t beg = max(set_beg, s_beg), end = min(set_end, s_end);
             if (end <= beg) continue;
             uint32_t res[P];
-            set_minima<P, TokT>(args, hv, hv_vec, beg, end, pm, pm_biased, sp, blockIdx.y * (kWave * P), lane, backoff, res);
+            set_minima<P, TokT>(args, hv, hv_vec, beg, end, pm, pm_biased, sp, blockIdx.y * (kWave * P), lane, lds, backoff, res);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 if (kidx[p] < 0) continue;
