@@ -73,6 +73,24 @@ int mhx_ctx::ensure_scratch(int slot, size_t bytes) {
     return MHX_OK;
 }
 
+int mhx_ctx::ensure_redo(int64_t n_sets) {
+    if (n_sets <= redo_capacity && d_redo) return MHX_OK;
+    if (d_redo) {
+        (void)hipStreamSynchronize(stream);
+        (void)hipFree(d_redo);
+        d_redo = nullptr;
+        redo_capacity = 0;
+    }
+    const int64_t cap = std::max<int64_t>(n_sets + n_sets / 4, 1024);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_redo), (size_t)cap + 64);
+    if (e != hipSuccess) {
+        d_redo = nullptr;
+        return fail(MHX_ERR_OOM, "redo flag allocation of %lld bytes failed: %s", (long long)cap, hipGetErrorString(e));
+    }
+    redo_capacity = cap;
+    return MHX_OK;
+}
+
 extern "C" {
 
 const char *mhx_last_error(void) { return mhx::g_last_error.c_str(); }
@@ -126,6 +144,7 @@ int mhx_ctx_destroy(mhx_ctx *ctx) {
     for (int i = 0; i < 4; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
+    if (ctx->d_redo) (void)hipFree(ctx->d_redo);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return MHX_OK;

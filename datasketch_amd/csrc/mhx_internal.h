@@ -55,6 +55,10 @@ struct mhx_ctx {
 
     // device counters of the MinHash kernels (mhx_ctx_counters); nullptr until counting is enabled
     unsigned long long *d_stats = nullptr;
+    // redo flags of the wave-per-set MinHash launches: one byte per set (grow-only)
+    uint8_t *d_redo = nullptr;
+    int64_t redo_capacity = 0;
+    int ensure_redo(int64_t n_sets);
 
     int ensure_scratch(int slot, size_t bytes);
     int activate() const;

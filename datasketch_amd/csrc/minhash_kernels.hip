@@ -44,6 +44,7 @@ struct BulkArgs {
     int32_t path;            // 0 sieve (+ fallbacks), 1 exact fold everywhere, 2 fast fold (+ exact redo)
     unsigned long long *stats;  // optional device counters: [0] sets redone after a failed sieve proof,
                                 // [1] sets redone with the exact fold, [2] sieve blocks evaluated
+    uint8_t *redo;              // wave-per-set kernels: redo[set] != 0 <=> the sieve launch left the set to the full one
     int32_t prefetch;        // warm the next set's tokens with a vector load (option minhash.prefetch)
     int64_t alias_mask;      // profiling only (option minhash.alias): sets read tokens of set (i & mask); -1 = off
     const uint64_t *init;
@@ -538,9 +539,7 @@ __device__ __forceinline__ bool sieve_minima(const TokT MHX_CONST_AS *hv, const 
             res[p] = min(res[p], acc[p] - 1u);
         }
     }
-    const bool redo = __any(bad);
-    if (redo && stats && lane == 0) atomicAdd(stats, 1ull);
-    return redo;
+    return __any(bad);
 }
 
 // Per-wave back-off for corpora whose sets defeat the sieve (repeated tokens inside a set): after
@@ -568,6 +567,7 @@ __device__ __forceinline__ void set_minima(const BulkArgs &args, const TokT MHX_
         } else {
             full = sieve_minima<P, TokT>(hv, hv_vec, beg, end, pm, pm_biased, sp, args.stats, lane, lds, res);
             if (full) {
+                if (args.stats && lane == 0) atomicAdd(args.stats, 1ull);
                 bo.skip = bo.gap;
                 bo.gap = min(2 * bo.gap, 64);
             } else {
@@ -603,29 +603,51 @@ __device__ __forceinline__ void load_perms(const BulkArgs &args, int kbase, int 
     }
 }
 
-// ---- kernel A: one wave per set -------------------------------------------------------------
+// ---- kernel A: one wave per set, in two launches ------------------------------------------------
 // grid.x strides over sets; a wave walks the permutations of its set in chunks of 64*P (the
 // set's tokens stay in the scalar cache / L2 between chunks), so a [K] row is written by one wave.
-template <int P, typename TokT, typename OutT>
+//   MODE_SIEVE  the sieve and nothing else.  A set whose proof fails (or that the wave's back-off
+//               skips) is appended to the redo list instead of being evaluated in full here: keeping
+//               the full evaluation out of this kernel is worth 8 % (60 instead of 122 VGPRs, no
+//               hoisted address arithmetic for paths that run four times in ten thousand sets).
+//   MODE_FULL   the full evaluation (fast fold + exact redo, or the exact fold with path 1) for the
+//               listed sets -- or for every set when the sieve is switched off.
+enum { MODE_SIEVE = 0, MODE_FULL = 1 };
+
+template <int P, typename TokT, typename OutT, int MODE>
 __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_block = blockDim.x >> 6;
     const int kchunks = (args.num_perm + kWave * P - 1) / (kWave * P);
-    __shared__ __attribute__((aligned(16))) uint32_t stage[4 * kStageWordsPerWave];  // one tile per wave
-    uint32_t *lds = stage + wave * kStageWordsPerWave;
+    __shared__ __attribute__((aligned(16))) uint32_t stage[MODE == MODE_SIEVE ? 4 * kStageWordsPerWave : 4];
+    uint32_t *lds = stage + (MODE == MODE_SIEVE ? wave * kStageWordsPerWave : 0);
     Perms<P> pm, pm_biased;
     SievePerms<P> sp;
     int kidx[P];
-    load_perms<P>(args, 0, lane, pm, pm_biased, sp, kidx);
+    if (MODE == MODE_SIEVE) load_perms<P>(args, 0, lane, pm, pm_biased, sp, kidx);
 
     const TokT MHX_CONST_AS *hv = as_const(static_cast<const TokT *>(args.hv));
     const TokT *hv_vec = static_cast<const TokT *>(args.hv);
     const int64_t MHX_CONST_AS *offsets = as_const(args.offsets);
     OutT *__restrict__ out = static_cast<OutT *>(args.out);
     const int64_t stride = (int64_t)gridDim.x * waves_per_block;
+    // MODE_FULL after a sieve launch walks the flags 64 sets at a time: one byte load per lane, a
+    // ballot, then the flagged sets one by one (a flag array, not an appended list: hundreds of
+    // thousands of atomics on one counter serialise -- measured 8 ms for 500k failed sets)
+    const bool flagged_only = MODE == MODE_FULL && args.redo != nullptr;
+    const int64_t n_items = flagged_only ? (args.n_sets + kWave - 1) / kWave : args.n_sets;
     SieveBackoff backoff;
-    for (int64_t set = (int64_t)blockIdx.x * waves_per_block + wave; set < args.n_sets; set += stride) {
+    for (int64_t item = (int64_t)blockIdx.x * waves_per_block + wave; item < n_items; item += stride) {
+      unsigned long long todo = 1;  // sets of this item still to do (bit i = set 64*item + i when flagged_only)
+      if (flagged_only) {
+          const int64_t cand = item * kWave + lane;
+          todo = __ballot(cand < args.n_sets && args.redo[cand] != 0);
+      }
+      while (todo) {
+        const int bit = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int64_t set = flagged_only ? item * kWave + bit : item;
         int64_t beg, end;
         if (args.offsets) {
             beg = offsets[set];
@@ -638,9 +660,9 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) 
         // per wave per set, lane l touching byte 128*l of that set (up to 8 KiB).  The scalar loads
         // of the next iteration then hit on-chip instead of paying an HBM round trip each.
         uint32_t warm = 0;
-        if (args.prefetch) {
-            const int64_t nset = set + stride;
-            if (nset < args.n_sets) {
+        {
+            const int64_t nset = flagged_only ? (todo ? item * kWave + __builtin_ctzll(todo) : args.n_sets) : item + stride;
+            if (args.prefetch && nset < args.n_sets) {
                 const int64_t nbeg = args.offsets ? offsets[nset] : nset * args.fixed_len;
                 const int64_t nend = args.offsets ? offsets[nset + 1] : nbeg + args.fixed_len;
                 const int64_t off = (int64_t)lane * 128;
@@ -649,11 +671,37 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) 
                                                                          nbeg * (int64_t)sizeof(TokT) + off);
             }
         }
-        for (int kc = 0; kc < kchunks; ++kc) {
-            if (kchunks > 1) load_perms<P>(args, kc * (kWave * P), lane, pm, pm_biased, sp, kidx);
+        bool defer = false;  // MODE_SIEVE: leave this set to the MODE_FULL launch
+        if (MODE == MODE_SIEVE && end > beg && backoff.skip > 0) {
+            --backoff.skip;
+            defer = true;
+        }
+        for (int kc = 0; kc < kchunks && !defer; ++kc) {
             uint32_t res[P];
-            if (end > beg)
-                set_minima<P, TokT>(args, hv, hv_vec, beg, end, pm, pm_biased, sp, kc * (kWave * P), lane, lds, backoff, res);
+            if (MODE == MODE_SIEVE) {
+                if (kchunks > 1) load_perms<P>(args, kc * (kWave * P), lane, pm, pm_biased, sp, kidx);
+                if (end > beg) {
+                    defer = sieve_minima<P, TokT>(hv, hv_vec, beg, end, pm, pm_biased, sp, args.stats, lane, lds, res);
+                    if (defer) {
+                        backoff.skip = backoff.gap;
+                        backoff.gap = min(2 * backoff.gap, 64);
+                        break;
+                    }
+                    backoff.gap = 16;
+                }
+            } else {
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const int k = kc * (kWave * P) + p * kWave + lane;
+                    kidx[p] = k < args.num_perm ? k : -1;
+                }
+                if (end > beg) {
+                    const Minima<P> m = full_minima<P, TokT>(hv_vec, beg, end, args.a, args.b, args.num_perm,
+                                                             kc * (kWave * P), args.path == 1, args.stats);
+#pragma unroll
+                    for (int p = 0; p < P; ++p) res[p] = m.v[p];
+                }
+            }
 #pragma unroll
             for (int p = 0; p < P; ++p) {
                 if (kidx[p] < 0) continue;
@@ -673,7 +721,12 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) 
                 out[set * args.num_perm + kidx[p]] = (OutT)v;
             }
         }
+        if (MODE == MODE_SIEVE && lane == 0) {
+            args.redo[set] = defer ? 1 : 0;
+            if (defer && args.stats) atomicAdd(args.stats, 1ull);
+        }
         asm volatile("" ::"v"(warm));  // the warm-up load retires here, a whole set later
+      }
     }
 }
 
@@ -779,7 +832,18 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t total_tokens, bool 
     if (!split) {
         const int64_t want = (args.n_sets + 3) / 4;
         dim3 grid((unsigned)std::max<int64_t>(1, std::min(want, max_blocks)), 1u);  // wave loops over kchunks
-        hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT>), grid, dim3(256), 0, ctx->stream, args);
+        if (args.path == 0) {
+            // sieve launch (writes a flag per set), then the full evaluation of the flagged sets (usually a
+            // handful: that launch reads n_sets bytes and returns)
+            hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE>), grid, dim3(256), 0, ctx->stream, args);
+            const int64_t flag_items = (args.n_sets + kWave - 1) / kWave;  // a wave scans 64 flags at a time
+            dim3 full_grid((unsigned)std::max<int64_t>(1, std::min((flag_items + 3) / 4, max_blocks)), 1u);
+            hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_FULL>), full_grid, dim3(256), 0, ctx->stream, args);
+        } else {
+            BulkArgs all = args;
+            all.redo = nullptr;  // every set
+            hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_FULL>), grid, dim3(256), 0, ctx->stream, all);
+        }
     } else {
         const int64_t total_out = args.n_sets * (int64_t)args.num_perm;
         const int64_t fill_blocks = std::max<int64_t>(1, std::min<int64_t>((total_out + 255) / 256, max_blocks));
@@ -823,6 +887,7 @@ int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const in
     args.num_perm = perm->num_perm;
     args.path = (int32_t)ctx->opt_minhash_path;
     args.stats = ctx->d_stats;
+    args.redo = nullptr;
     args.alias_mask = ctx->opt_minhash_alias;
     args.prefetch = ctx->opt_minhash_prefetch != 0;
     args.init = d_init;
@@ -833,6 +898,10 @@ int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const in
     bool split = n_sets < waves_avail && total_tokens > n_sets * 128 && total_tokens >= 1024;
     if (ctx->opt_minhash_split == 1) split = false;
     if (ctx->opt_minhash_split == 2) split = total_tokens > 0;
+    if (!split && args.path == 0) {
+        if (int rc = ctx->ensure_redo(n_sets)) return rc;
+        args.redo = ctx->d_redo;
+    }
     if (hv_dtype == MHX_U64 && out_dtype == MHX_U64) return launch_p<uint64_t, uint64_t>(ctx, args, total_tokens, split);
     if (hv_dtype == MHX_U64 && out_dtype == MHX_U32) return launch_p<uint64_t, uint32_t>(ctx, args, total_tokens, split);
     if (hv_dtype == MHX_U32 && out_dtype == MHX_U64) return launch_p<uint32_t, uint64_t>(ctx, args, total_tokens, split);
