@@ -196,7 +196,7 @@ def main():
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
         "traffic": measured_traffic(n, t, k, args),
-        "kernel": "minhash_bulk_kernel",
+        "kernel": "minhash_bulk_kernel<MODE_SIEVE> (+ the MODE_FULL launch over the flagged sets)",
         "kernel_ms": kernel_ms,
         "algorithmic_bytes_per_launch": alg_bytes,
         "note": "integer-VALU-bound kernel: (token,perm) pair evaluations/s = %.3e" % pair_rate,
