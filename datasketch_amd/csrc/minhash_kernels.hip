@@ -817,18 +817,30 @@ __global__ __launch_bounds__(256) void minhash_split_kernel(const BulkArgs args,
 
 __global__ void minhash_merge_kernel(const uint64_t *__restrict__ x, const uint64_t *__restrict__ y,
                                      int64_t count, uint64_t *__restrict__ out) {
-    // 16 B per lane per access; HBM-bound elementwise min (minhash.py:359)
+    // 16 B per lane per access, four accesses of each input in flight; HBM-bound elementwise min
+    // (minhash.py:359)
     const int64_t n2 = count >> 1;
     const ulonglong2 *x2 = reinterpret_cast<const ulonglong2 *>(x);
     const ulonglong2 *y2 = reinterpret_cast<const ulonglong2 *>(y);
     ulonglong2 *o2 = reinterpret_cast<ulonglong2 *>(out);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const ulonglong2 xa = x2[i], ya = y2[i];
-        ulonglong2 r;
-        r.x = xa.x < ya.x ? xa.x : ya.x;
-        r.y = xa.y < ya.y ? xa.y : ya.y;
-        o2[i] = r;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += 4 * stride) {
+        ulonglong2 xa[4], ya[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i + u * stride < n2) {
+                xa[u] = x2[i + u * stride];
+                ya[u] = y2[i + u * stride];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i + u * stride >= n2) break;
+            ulonglong2 r;
+            r.x = xa[u].x < ya[u].x ? xa[u].x : ya[u].x;
+            r.y = xa[u].y < ya[u].y ? xa[u].y : ya[u].y;
+            o2[i + u * stride] = r;
+        }
     }
     if ((count & 1) && blockIdx.x == 0 && threadIdx.x == 0)
         out[count - 1] = x[count - 1] < y[count - 1] ? x[count - 1] : y[count - 1];
