@@ -580,6 +580,58 @@ def test_lean_serialize(ctx, golden):
         assert lm.seed == -5 and np.array_equal(lm.hashvalues, sig[17])
 
 
+# ------------------------------------------------------------------ full-size properties (configs 4 and 5)
+def test_full_size_weighted_100k_vectors(ctx):
+    """BASELINE.json configs[3] at full size (100k dense vectors of dim 4096, 128 samples): oracle on
+    rows spread over the matrix, and row-order equivariance -- reversing the rows must reverse the
+    output, i.e. nothing leaks between the rows of an 8-row block or between blocks."""
+    n, dim, s = 100_000, 4096, 128
+    rs, ln_cs, betas = O.np_weighted_params(dim, s, 1)
+    rng = np.random.RandomState(42)
+    logs = np.log(rng.randint(1, 2**20, (n, dim)).astype(np.float32) * np.float32(1e-4))
+    logs[12345, 77] = 0.0
+    indptr = np.arange(n + 1, dtype=np.int64) * dim
+    indices = np.tile(np.arange(dim, dtype=np.int32), n)
+    h = ctx.wgen_create(rs, ln_cs, betas)
+    try:
+        out, ne = ctx.weighted_minhash_many(h, s, indptr, indices, logs.reshape(-1), True)
+        rev, _ = ctx.weighted_minhash_many(h, s, indptr, indices, logs[::-1].reshape(-1), True)
+    finally:
+        ctx.wgen_destroy(h)
+    assert ne.all() and np.array_equal(rev[::-1], out)
+    rows = np.unique(np.concatenate([np.arange(0, 24), np.linspace(0, n - 1, 40).astype(np.int64), np.arange(n - 24, n)]))
+    want, _ = O.c_weighted_minhash_many(np.arange(len(rows) + 1, dtype=np.int64) * dim, np.tile(np.arange(dim, dtype=np.int32), len(rows)),
+                                        None, rs, ln_cs, betas, logs=logs[rows].reshape(-1))
+    assert np.array_equal(out[rows], want)
+    assert out[..., 0].min() >= 0 and out[..., 0].max() < dim
+
+
+def test_full_size_packing_1m_signatures_k256(ctx):
+    """BASELINE.json configs[4] per-GPU shape (1.25M x 256 rounded to 1M): b-bit blocks, band keys,
+    band digests and Lean records of a whole matrix -- checksums that do not need the oracle at full
+    size, plus the oracle on a slice."""
+    n, k = 1_000_000, 256
+    sig = np.random.RandomState(9).randint(0, 2**32, (n, k), dtype=np.uint64)
+    sl = slice(499_000, 500_000)
+    blocks = ctx.bbit_pack(sig, 1)
+    assert blocks.shape == (n, 4)
+    ones = np.unpackbits(blocks.view(np.uint8)).sum(dtype=np.int64)
+    assert int(ones) == int((sig & 1).sum(dtype=np.int64))          # every low bit arrived, nothing else
+    assert np.array_equal(blocks[sl], O.c_bbit_pack(sig[sl], 1))
+    keys = ctx.band_keys(sig, 32, 8)
+    assert np.array_equal(keys.byteswap(), sig)                      # byte-swapping twice is the identity
+    from datasketch_amd import lsh_bulk as LB
+
+    dig = ctx.band_digests(sig, 32, 8)
+    assert np.array_equal(dig[sl], LB.band_digests(sig[sl], 32, 8, gpu_mode="disable"))
+    assert len(np.unique(dig[:, 0])) == n                            # random signatures: no shared bucket
+    rec = serialize_matrix(sig, 7, gpu_mode="always")
+    assert rec.shape == (n, 12 + 4 * k)
+    body = rec[:, 12:].copy().view("<u4")
+    assert np.array_equal(body, sig.astype(np.uint32))
+    assert np.array_equal(rec[:, :12], np.tile(np.frombuffer(np.array([7], "<i8").tobytes() + np.array([k], "<i4").tobytes(), np.uint8), (n, 1)))
+
+
 # ------------------------------------------------------------------ RCCL binding (single rank)
 def test_rccl_allgather_single_rank(ctx):
     lib = ctx.lib
