@@ -871,10 +871,11 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t total_tokens, bool 
         const int64_t fill_blocks = std::max<int64_t>(1, std::min<int64_t>((total_out + 255) / 256, max_blocks));
         hipLaunchKernelGGL((minhash_fill_state_kernel<OutT>), dim3((unsigned)fill_blocks), dim3(256), 0,
                            ctx->stream, args);
-        // slice length: enough slices to fill the chip, but at least 64 tokens per slice
-        const int64_t waves = max_blocks * 4;
+        // slice length: whole 256-token sieve blocks, about 8 slices (waves) per SIMD; short inputs
+        // keep 64-token slices so that a single 50k-token update_batch still spreads over the chip
+        const int64_t waves = (int64_t)ctx->num_cus * 32;
         int64_t slice = (total_tokens + waves - 1) / waves;
-        slice = std::max<int64_t>(64, (slice + 15) / 16 * 16);
+        slice = slice > 128 ? (slice + 255) / 256 * 256 : std::max<int64_t>(64, (slice + 15) / 16 * 16);
         const int64_t n_slices = (total_tokens + slice - 1) / slice;
         const int64_t want = (n_slices + 3) / 4;
         dim3 grid((unsigned)std::max<int64_t>(1, std::min(want, max_blocks)), (unsigned)kchunks);

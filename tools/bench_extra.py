@@ -97,6 +97,18 @@ def packing(ctx, n, k):
     d_out = ctx.alloc(n * (12 + 4 * k))
     ms = timed(ctx, lambda: _native.check(lib.mhx_lean_serialize_dev(ctx.handle, d_sig.ptr, n, k, 1, d_out.ptr)))
     report(f"lean_serialize K={k}", ms, n, "signatures", n * (8 * k + 12 + 4 * k))
+    d_dig = ctx.alloc(n * 32 * 8)
+    ms = timed(ctx, lambda: _native.check(lib.mhx_band_digests_dev(ctx.handle, d_sig.ptr, n, k, 32, 8, d_dig.ptr)))
+    from datasketch_amd import lsh_bulk as LB
+    assert np.array_equal(d_dig.download((n, 32), np.uint64)[:256], LB.band_digests(sig[:256], 32, 8, gpu_mode="disable"))
+    report(f"band_digests bands=32 r=8 K={k}", ms, n, "signatures", n * (8 * k + 8 * 32))
+    m = 4_000_000
+    pairs = rng.randint(0, n, (m, 2)).astype(np.int64)
+    d_pairs, d_cnt = ctx.to_device(pairs), ctx.alloc(m * 4)
+    ms = timed(ctx, lambda: _native.check(lib.mhx_jaccard_pairs_dev(ctx.handle, d_sig.ptr, d_sig.ptr, k, d_pairs.ptr, m, d_cnt.ptr)))
+    got = d_cnt.download((m,), np.int32)
+    assert np.array_equal(got[:512], np.count_nonzero(sig[pairs[:512, 0]] == sig[pairs[:512, 1]], axis=1))
+    report(f"jaccard_pairs {m} random pairs K={k}", ms, m, "pairs", m * (16 * k + 16 + 4))
     d_y = ctx.to_device(rng.randint(0, 2**32, (n, k), dtype=np.uint64))
     d_o = ctx.alloc(n * k * 8)
     ms = timed(ctx, lambda: _native.check(lib.mhx_minhash_merge_dev(ctx.handle, d_sig.ptr, d_y.ptr, n * k, d_o.ptr)))
