@@ -110,6 +110,8 @@ __global__ __launch_bounds__(256) void lean_serialize_kernel(const uint64_t *__r
 // (ref: lsh.py:540-543), in a form a device-side sort can group by.  One lane per (row, band).
 __global__ __launch_bounds__(256) void band_digest_kernel(const uint64_t *__restrict__ sig, int64_t n, int32_t k,
                                                           int32_t bands, int32_t r, uint64_t *__restrict__ out) {
+    constexpr uint64_t kPrime = 0x100000001b3ull;
+    constexpr uint64_t kPrime4 = kPrime * kPrime * kPrime * kPrime;  // four zero bytes: h ^= 0 leaves h, so h *= prime^4
     const int64_t total = n * (int64_t)bands;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
@@ -117,13 +119,34 @@ __global__ __launch_bounds__(256) void band_digest_kernel(const uint64_t *__rest
         const int band = (int)(idx - row * bands);
         const uint64_t *src = sig + row * k + (int64_t)band * r;
         uint64_t h = 0xcbf29ce484222325ull;
-        for (int c = 0; c < r; ++c) {
-            const uint64_t v = src[c];
+        const auto absorb = [&](uint64_t v) {
+            const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
+            if (hi == 0) {  // every real hashvalue: the 4 leading key bytes are zero
+                h *= kPrime4;
+            } else {
 #pragma unroll
-            for (int byte = 7; byte >= 0; --byte) {  // big-endian byte order of the key
-                h ^= (v >> (8 * byte)) & 0xFFu;
-                h *= 0x100000001b3ull;
+                for (int byte = 3; byte >= 0; --byte) {
+                    h ^= (hi >> (8 * byte)) & 0xFFu;
+                    h *= kPrime;
+                }
             }
+#pragma unroll
+            for (int byte = 3; byte >= 0; --byte) {  // big-endian byte order of the key
+                h ^= (lo >> (8 * byte)) & 0xFFu;
+                h *= kPrime;
+            }
+        };
+        if (((r | k) & 1) == 0 && (reinterpret_cast<uintptr_t>(sig) & 15) == 0) {
+            // 16-byte loads: a lane's band is r*8 contiguous bytes, but neighbouring lanes are r*8 bytes
+            // apart, so every load instruction touches many lines -- fewer, wider loads it is
+            const ulonglong2 *src2 = reinterpret_cast<const ulonglong2 *>(src);
+            for (int c = 0; c < r / 2; ++c) {
+                const ulonglong2 v = src2[c];
+                absorb(v.x);
+                absorb(v.y);
+            }
+        } else {
+            for (int c = 0; c < r; ++c) absorb(src[c]);
         }
         out[idx] = h;
     }
