@@ -143,9 +143,11 @@ def minhash_ragged(ctx):
         off = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(lens, out=off[1:])
         hv = rng.randint(0, 2**32, size=int(off[-1]), dtype=np.uint64)
-        if dup:
-            idx = rng.randint(0, hv.size - 1, size=int(dup * hv.size))
-            hv[idx + 1] = hv[idx]  # neighbour copies: duplicates inside a set (a few straddle two sets)
+        if dup:  # repeated tokens at random places of the same set (dense corpus: set i = tokens [256 i, 256 i + 256))
+            m = int(dup * hv.size)
+            dst = rng.randint(0, hv.size, size=m)
+            src = (dst // 256) * 256 + rng.randint(0, 256, size=m)
+            hv[dst] = hv[src]
         d_hv, d_off, d_out = ctx.to_device(hv), ctx.to_device(off), ctx.alloc(n * k * 8)
         run = lambda: ctx.minhash_bulk_dev((a, b), d_hv.ptr, _native.MHX_U64, d_off.ptr, 0, n, hv.size, None, 0, d_out.ptr, _native.MHX_U64)
         ms = timed(ctx, run)
