@@ -66,6 +66,8 @@ _PROTOTYPES = {
     "mhx_band_keys": [_vp, _vp, _i64, _i32, _i32, _i32, _vp],
     "mhx_band_digests_dev": [_vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp],
     "mhx_band_digests": [_vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp],
+    "mhx_lsh_sort_bands_dev": [_vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
+    "mhx_lsh_sort_bands": [_vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
     "mhx_jaccard_pairs_dev": [_vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp],
     "mhx_jaccard_pairs": [_vp, _vp, _i64, ctypes.c_int32, _vp, _i64, _vp],
     "mhx_lean_serialize_dev": [_vp, _vp, _i64, _i32, _i64, _vp],
@@ -430,6 +432,16 @@ class Context:
         out = np.empty((n, bands), dtype=np.uint64)
         check(self.lib.mhx_band_digests(self.handle, _ptr(sig), n, k, int(bands), int(r), _ptr(out)))
         return out
+
+    def lsh_sort_bands(self, sig: np.ndarray, bands: int, r: int):
+        """(sorted_digests [bands, n] uint64, sorted_rows [bands, n] uint32): per band, the band digests in
+        ascending order and the rows in that order (mhx_lsh_sort_bands)."""
+        sig = np.ascontiguousarray(sig, dtype=np.uint64)
+        n, k = sig.shape
+        dig = np.empty((bands, n), dtype=np.uint64)
+        rows = np.empty((bands, n), dtype=np.uint32)
+        check(self.lib.mhx_lsh_sort_bands(self.handle, _ptr(sig), n, k, int(bands), int(r), _ptr(dig), _ptr(rows)))
+        return dig, rows
 
     def jaccard_pairs(self, sig: np.ndarray, pairs: np.ndarray) -> np.ndarray:
         """int32 counts of equal positions for rows (pairs[:,0], pairs[:,1]) of one signature matrix."""

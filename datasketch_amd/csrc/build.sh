@@ -10,7 +10,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off
        -I"${HERE}/../../include" -I"${HERE}" -Wall -Wno-unused-function)
 pids=()
-for src in mhx_api minhash_kernels weighted_kernels pack_kernels sha1_kernels comm; do
+for src in mhx_api minhash_kernels weighted_kernels pack_kernels sha1_kernels lsh_kernels comm; do
   if [[ ! -f "${OBJ}/${src}.o" || "${HERE}/${src}.hip" -nt "${OBJ}/${src}.o" \
         || "${HERE}/mhx_internal.h" -nt "${OBJ}/${src}.o" || "${HERE}/../../include/mhx.h" -nt "${OBJ}/${src}.o" ]]; then
     "${HIPCC}" "${FLAGS[@]}" -c "${HERE}/${src}.hip" -o "${OBJ}/${src}.o" &
@@ -19,5 +19,5 @@ for src in mhx_api minhash_kernels weighted_kernels pack_kernels sha1_kernels co
 done
 for p in "${pids[@]:-}"; do [[ -n "${p}" ]] && wait "${p}"; done
 "${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${OUT}" "${OBJ}"/mhx_api.o "${OBJ}"/minhash_kernels.o \
-  "${OBJ}"/weighted_kernels.o "${OBJ}"/pack_kernels.o "${OBJ}"/sha1_kernels.o "${OBJ}"/comm.o -ldl
+  "${OBJ}"/weighted_kernels.o "${OBJ}"/pack_kernels.o "${OBJ}"/sha1_kernels.o "${OBJ}"/lsh_kernels.o "${OBJ}"/comm.o -ldl
 echo "built ${OUT}"

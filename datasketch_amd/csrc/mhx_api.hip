@@ -628,6 +628,36 @@ int mhx_band_digests(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, in
     return fetch_out(ctx, out, out_bytes);
 }
 
+int mhx_lsh_sort_bands_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
+                           uint64_t *d_sorted_digests, uint32_t *d_sorted_rows) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
+    MHX_REQUIRE(n >= 0, "bad shape");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(d_sig && d_sorted_digests && d_sorted_rows, "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_lsh_sort_bands(ctx, d_sig, n, k, bands, r, d_sorted_digests, d_sorted_rows);
+}
+
+int mhx_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int32_t bands, int32_t r,
+                       uint64_t *sorted_digests, uint32_t *sorted_rows) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
+    MHX_REQUIRE(n >= 0, "bad shape");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(sig && sorted_digests && sorted_rows, "NULL host pointer");
+    const size_t dig_bytes = sizeof(uint64_t) * (size_t)n * bands, row_bytes = sizeof(uint32_t) * (size_t)n * bands;
+    const size_t dig_pad = (dig_bytes + 255) & ~(size_t)255;
+    if (int rc = stage_sig(ctx, sig, n, k, dig_pad + row_bytes)) return rc;
+    uint64_t *d_dig = (uint64_t *)ctx->scratch[2];
+    uint32_t *d_rows = (uint32_t *)((char *)ctx->scratch[2] + dig_pad);
+    if (int rc = mhx::launch_lsh_sort_bands(ctx, (const uint64_t *)ctx->scratch[0], n, k, bands, r, d_dig, d_rows)) return rc;
+    MHX_HIP_CHECK(hipMemcpyAsync(sorted_digests, d_dig, dig_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipMemcpyAsync(sorted_rows, d_rows, row_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MHX_OK;
+}
+
 int mhx_jaccard_pairs_dev(mhx_ctx *ctx, const uint64_t *d_sig_a, const uint64_t *d_sig_b, int32_t k,
                           const int64_t *d_pairs, int64_t n_pairs, int32_t *d_counts) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");

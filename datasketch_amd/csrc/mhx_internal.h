@@ -111,6 +111,8 @@ int launch_band_digests(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t 
                         uint64_t *d_out);
 int launch_jaccard_pairs(mhx_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, int32_t k, const int64_t *d_pairs,
                          int64_t m, int32_t *d_counts);
+int launch_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
+                          uint64_t *d_sorted_digests, uint32_t *d_sorted_rows);
 int launch_lean_serialize(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int64_t seed,
                           uint8_t *d_out);
 

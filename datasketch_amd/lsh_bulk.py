@@ -9,8 +9,9 @@ Python round trips:
   (ref: datasketch/lsh.py:199,344,537-543), as the exact key bytes or as 64-bit FNV-1a digests of them;
 * :func:`insert_bulk` -- ``MinHashLSH.insert`` for a whole matrix (ref: lsh.py:326-347), through the
   index's own storage API, leaving it in exactly the state the per-key loop would;
-* :func:`candidate_pairs` -- the pairs of rows that share at least one band (what ``query`` would find),
-  by grouping digests instead of probing dictionaries;
+* :func:`sorted_bands` / :func:`candidate_pairs` -- LSH bucketing by sort: per band the digests in
+  ascending order with their rows (device radix sort), and from that the pairs of rows that share at
+  least one band (what ``query`` would find), without probing dictionaries;
 * :func:`jaccard_pairs` -- ``MinHash.jaccard`` for a list of pairs (ref: datasketch/minhash.py:299-324).
 """
 from __future__ import annotations
@@ -125,22 +126,39 @@ def insert_bulk(lsh, keys: Iterable[Hashable], signatures, check_duplication: bo
             hashtable.insert(h, key, buffer=False)
 
 
+def sorted_bands(signatures, b: int, r: int, gpu_mode: str = "detect"):
+    """``(digests [b, N] uint64 ascending per band, rows [b, N] uint32 in the same order)``: every LSH
+    bucket of band ``j`` is a run of equal values in ``digests[j]``.  On the device this is one digest
+    pass plus ``b`` radix sorts (mhx_lsh_sort_bands); the numpy fallback is ``argsort`` per band."""
+    sig = _matrix(signatures)
+    n, k = sig.shape
+    _check_params(k, b, r)
+    if _use_gpu(gpu_mode) and n:
+        return _native.context().lsh_sort_bands(sig, b, r)
+    dig = band_digests(sig, b, r, gpu_mode="disable").T
+    order = np.argsort(dig, axis=1, kind="stable")
+    return np.take_along_axis(dig, order, axis=1), order.astype(np.uint32)
+
+
 def candidate_pairs(signatures, b: int, r: int, gpu_mode: str = "detect") -> np.ndarray:
     """``[M, 2]`` int64, sorted, unique pairs ``i < j`` of rows that share the key of at least one band
     -- the pairs ``MinHashLSH(params=(b, r))`` would report for each other."""
-    dig = band_digests(signatures, b, r, gpu_mode=gpu_mode)
-    n = dig.shape[0]
+    dig, rows = sorted_bands(signatures, b, r, gpu_mode=gpu_mode)
+    n = dig.shape[1]
     found: List[np.ndarray] = []
     for j in range(b):
-        col = dig[:, j]
-        order = np.argsort(col, kind="stable")
-        s = col[order]
-        starts = np.flatnonzero(np.concatenate([[True], s[1:] != s[:-1]]))
-        ends = np.concatenate([starts[1:], [n]])
-        for a, e in zip(starts[ends - starts > 1], ends[ends - starts > 1]):
-            rows = np.sort(order[a:e])
-            ii, jj = np.triu_indices(rows.size, k=1)
-            found.append(np.stack([rows[ii], rows[jj]], axis=1))
+        s, order = dig[j], rows[j].astype(np.int64)
+        starts = np.flatnonzero(np.concatenate([[True], s[1:] != s[:-1]])) if n else np.empty(0, np.int64)
+        ends = np.concatenate([starts[1:], [n]]) if n else starts
+        size = ends - starts
+        two = starts[size == 2]  # the common bucket: exactly two rows
+        if two.size:
+            pair = np.stack([order[two], order[two + 1]], axis=1)
+            found.append(np.sort(pair, axis=1))
+        for a, e in zip(starts[size > 2], ends[size > 2]):
+            members = np.sort(order[a:e])
+            ii, jj = np.triu_indices(members.size, k=1)
+            found.append(np.stack([members[ii], members[jj]], axis=1))
     if not found:
         return np.empty((0, 2), dtype=np.int64)
     return np.unique(np.concatenate(found).astype(np.int64), axis=0)

@@ -213,6 +213,15 @@ MHX_API int mhx_band_digests_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n_
                                  int32_t bands, int32_t r, uint64_t *d_out);
 MHX_API int mhx_band_digests(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs, int32_t num_perm,
                              int32_t bands, int32_t r, uint64_t *out);
+/* LSH bucketing by sort (what the per-band dictionaries of ref: datasketch/lsh.py:326-347,370-400 do by
+ * hashing): for every band j, sorted_digests[j*n .. (j+1)*n) are the band-j digests of all n signatures in
+ * ascending order and sorted_rows[...] the row numbers in the same order -- every LSH bucket of band j is
+ * a run of equal digests.  Rows are uint32 (n < 2^32). */
+MHX_API int mhx_lsh_sort_bands_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n_sigs, int32_t num_perm,
+                                   int32_t bands, int32_t r, uint64_t *d_sorted_digests,
+                                   uint32_t *d_sorted_rows);
+MHX_API int mhx_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs, int32_t num_perm,
+                               int32_t bands, int32_t r, uint64_t *sorted_digests, uint32_t *sorted_rows);
 /* Batched MinHash.jaccard numerators (ref: datasketch/minhash.py:299-324): counts[p] = number of equal
  * positions of rows pairs[p][0] of sig_a and pairs[p][1] of sig_b (both [*, num_perm] uint64; may be the
  * same matrix); the estimate is counts / num_perm.  pairs int64[n_pairs, 2]. */

@@ -727,6 +727,13 @@ def test_band_digests_candidates_and_jaccard_on_device(ctx):
         assert np.array_equal(LB.band_digests(sig, b, r, gpu_mode="always"), LB.band_digests(sig, b, r, gpu_mode="disable")), (b, r)
         dev, host = LB.band_keys(sig, b, r, gpu_mode="always"), LB.band_keys(sig, b, r, gpu_mode="disable")
         assert dev.tobytes() == host.tobytes()
+    dev_dig, dev_rows = LB.sorted_bands(sig, 32, 4, gpu_mode="always")
+    host_dig, _ = LB.sorted_bands(sig, 32, 4, gpu_mode="disable")
+    assert np.array_equal(dev_dig, host_dig)                       # same multiset per band, sorted
+    full = LB.band_digests(sig, 32, 4, gpu_mode="disable")
+    for j in (0, 17, 31):                                          # rows are a permutation consistent with the keys
+        assert np.array_equal(np.sort(dev_rows[j]), np.arange(sig.shape[0]))
+        assert np.array_equal(full[dev_rows[j].astype(np.int64), j], dev_dig[j])
     pairs = LB.candidate_pairs(sig, 32, 4, gpu_mode="always")
     assert np.array_equal(pairs, LB.candidate_pairs(sig, 32, 4, gpu_mode="disable")) and len(pairs) > 1000
     extra = rng.randint(0, 3000, (5000, 2))

@@ -102,6 +102,11 @@ def packing(ctx, n, k):
     from datasketch_amd import lsh_bulk as LB
     assert np.array_equal(d_dig.download((n, 32), np.uint64)[:256], LB.band_digests(sig[:256], 32, 8, gpu_mode="disable"))
     report(f"band_digests bands=32 r=8 K={k}", ms, n, "signatures", n * (8 * k + 8 * 32))
+    d_sd, d_sr = ctx.alloc(n * 32 * 8), ctx.alloc(n * 32 * 4)
+    ms = timed(ctx, lambda: _native.check(lib.mhx_lsh_sort_bands_dev(ctx.handle, d_sig.ptr, n, k, 32, 8, d_sd.ptr, d_sr.ptr)), reps=3)
+    sd = d_sd.download((32, n), np.uint64)
+    assert np.all(sd[:, 1:] >= sd[:, :-1])
+    report(f"lsh_sort_bands bands=32 r=8 K={k} (digests + 32 radix sorts of {n} keys)", ms, n, "signatures", n * (8 * k + 12 * 32))
     m = 4_000_000
     pairs = rng.randint(0, n, (m, 2)).astype(np.int64)
     d_pairs, d_cnt = ctx.to_device(pairs), ctx.alloc(m * 4)

@@ -10,7 +10,7 @@ bash "${ROOT}/datasketch_amd/csrc/build.sh" > /dev/null
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off \
   -I"${ROOT}/include" -I"${ROOT}/datasketch_amd/csrc" -Wall -Wno-unused-function -c "${SRC}" -o "${OUT}/${MOD}_${NAME}.o"
 OBJS=()
-for m in mhx_api minhash_kernels weighted_kernels pack_kernels sha1_kernels comm; do
+for m in mhx_api minhash_kernels weighted_kernels pack_kernels sha1_kernels lsh_kernels comm; do
   if [[ "$m" == "$MOD" ]]; then OBJS+=("${OUT}/${MOD}_${NAME}.o"); else OBJS+=("${OBJ}/${m}.o"); fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "${OUT}/libmhx_${NAME}.so" "${OBJS[@]}" -ldl
