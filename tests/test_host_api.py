@@ -372,3 +372,36 @@ class TestWeightedMinHash:
         assert a.copy() == a and pickle.loads(pickle.dumps(a)) == a
         with pytest.raises(ValueError):
             a.jaccard(WeightedMinHashGenerator(8, 4, 2).minhash([1] * 8))
+
+
+# ------------------------------------------------------------------ helpers added around the path
+def test_pack_tokens_and_sha1_hash_many_on_the_host():
+    """Packing byte tokens for the device and the host fallback of sha1_hash_many."""
+    import hashlib
+    import struct
+
+    from datasketch_amd import _native, sha1_hash_many
+
+    tokens = [b"", b"a", bytearray(b"bc"), memoryview(b"def"), b"\x00" * 70]
+    buf, offs = _native.Context.pack_tokens(tokens)
+    assert buf.dtype == np.uint8 and offs.tolist() == [0, 0, 1, 3, 6, 76]
+    assert bytes(buf[1:3]) == b"bc" and bytes(buf[3:6]) == b"def"
+    with pytest.raises(TypeError):
+        _native.Context.pack_tokens(["text"])
+    want32 = [struct.unpack("<I", hashlib.sha1(bytes(t)).digest()[:4])[0] for t in tokens]
+    want64 = [struct.unpack("<Q", hashlib.sha1(bytes(t)).digest()[:8])[0] for t in tokens]
+    assert sha1_hash_many(tokens, 32, gpu_mode="disable").tolist() == want32
+    assert sha1_hash_many(tokens, 64, gpu_mode="disable").tolist() == want64
+    with pytest.raises(ValueError):
+        sha1_hash_many(tokens, 16, gpu_mode="disable")
+
+
+def test_bulk_with_repeated_tokens_equals_update_batch():
+    """bulk() may drop repeated tokens of a set before hashing them: the signatures must not change."""
+    rng = np.random.RandomState(3)
+    sets = [[b"w%d" % v for v in rng.randint(0, 30, rng.randint(0, 80))] for _ in range(40)]
+    sig = MinHash.bulk_signatures(sets, num_perm=32, seed=2, gpu_mode="disable")
+    for row, s in zip(sig, sets):
+        m = MinHash(num_perm=32, seed=2, gpu_mode="disable")
+        m.update_batch(s)
+        assert np.array_equal(row, m.hashvalues)
