@@ -257,8 +257,6 @@ class MinHash:
             parts = [_as_hash_array(s).reshape(-1) if not isinstance(s, np.ndarray) or s.dtype != np.uint64 else s.reshape(-1) for s in sets]
         else:
             parts = [_as_hash_array([f(t) for t in s]).reshape(-1) for s in sets]
-            if self._use_gpu():  # see _signatures_of_sets: repeated hash values only slow the kernel down
-                parts = [np.unique(p) if p.size > 16 else p for p in parts]
         for i, p in enumerate(parts):
             offsets[i + 1] = offsets[i] + p.size
         hv = np.concatenate(parts) if parts else np.empty(0, dtype=np.uint64)
@@ -306,12 +304,8 @@ class MinHash:
             hv, offsets = self._hash_sets(sets)
             return self._signatures_csr(hv, offsets, 0, len(sets), init)
         # default hashfunc + device: pack the byte tokens once, SHA-1 and MinHash both on the device
-        # repeated tokens change nothing (min is idempotent) but defeat the kernel's uniqueness proof and
-        # send the set down the slow path: drop them here, where every token is touched anyway
-        try:
-            sets = [list(dict.fromkeys(s)) if len(s) > 16 else s for s in sets]
-        except TypeError:  # unhashable byte tokens (bytearray, memoryview): keep them as they are
-            pass
+        # (repeated tokens are left in: dropping them here costs more host time per set -- a dict per set --
+        # than the kernel's slow path for such sets costs on the device)
         set_offsets = np.zeros(len(sets) + 1, dtype=np.int64)
         np.cumsum(np.fromiter(map(len, sets), dtype=np.int64, count=len(sets)), out=set_offsets[1:])
         buf, byte_offsets = _native.Context.pack_tokens([t for s in sets for t in s])
