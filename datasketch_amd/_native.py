@@ -263,7 +263,8 @@ class Context:
         """Kernel event counters since the previous call (then reset); see mhx_ctx_counters."""
         out = (ctypes.c_uint64 * 4)()
         check(self.lib.mhx_ctx_counters(self.handle, 1 if enable else 0, out))
-        return {"sieve_sets_redone": int(out[0]), "exact_sets_redone": int(out[1]), "sieve_blocks": int(out[2])}
+        return {"sieve_sets_redone": int(out[0]), "exact_sets_redone": int(out[1]), "sieve_blocks": int(out[2]),
+                "pairwise_sets": int(out[3])}
 
     def synchronize(self) -> None:
         check(self.lib.mhx_ctx_synchronize(self.handle))

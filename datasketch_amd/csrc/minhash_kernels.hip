@@ -352,6 +352,38 @@ __device__ __forceinline__ void sieve_chunk(const Chunk<TokT> &c, const SievePer
     }
 }
 
+// End of a block: rescan the best row of every permutation in the LDS tile (row stride STRIDE dwords,
+// WPT dwords per token), prove uniqueness, hash the one candidate exactly.  Returns the lanes whose
+// proof failed.
+template <int P, int STRIDE, int WPT>
+__device__ __forceinline__ bool finish_block(const Two (&rows)[P], const uint32_t *tile, const Perms<P> &pm,
+                                             const SievePerms<P> &sp, uint32_t (&res)[P]) {
+    Two cols[P];
+    uint64_t best[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const uint32_t *rowp = tile + (rows[q].k1 & 15u) * STRIDE;  // per-lane LDS address
+#pragma unroll
+        for (int c = 0; c < kRowTokens; ++c) {
+            const uint32_t m = (uint32_t)((uint64_t)rowp[c * WPT] * sp.a_lo[q] + sp.b8[q]);
+            cols[q].add(tag16(m, (uint32_t)c));
+        }
+        const uint32_t j1 = cols[q].k1 & 15u;
+        best[q] = WPT == 2 ? *reinterpret_cast<const uint64_t *>(rowp + 2 * j1) : (uint64_t)rowp[j1];
+        __builtin_amdgcn_sched_barrier(0);  // one permutation's 16 LDS words at a time (registers)
+    }
+    bool fail = false;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const bool ok = rows[q].apart() && cols[q].apart() && cols[q].k1 >= 16u;
+        fail |= sp.active[q] && !ok;
+        uint32_t l0, h0;
+        mad_wide((uint32_t)best[q], (uint32_t)(best[q] >> 32), pm.a_lo[q], pm.a_hi[q], pm.b[q], l0, h0);
+        res[q] = min(res[q], fold_exact(l0, h0));
+    }
+    return fail;
+}
+
 // Exact minima over the first nrows*16 tokens of [beg, ...) into res (min-combined); returns true
 // in lanes whose proof failed (the caller redoes the range).  All arguments wave-uniform except the
 // per-lane permutation registers.
@@ -428,29 +460,137 @@ __device__ __forceinline__ bool sieve_range(const TokT MHX_CONST_AS *hv, const T
             dst[0] = st0;
             if (WPT == 2) dst[1] = st1;
         }
-        Two cols[P];
-        uint64_t best[P];
-#pragma unroll
-        for (int q = 0; q < P; ++q) {
-            const uint32_t *rowp = lds + (rows[q].k1 & 15u) * STRIDE;  // per-lane LDS address
-#pragma unroll
-            for (int c = 0; c < kRowTokens; ++c) {
-                const uint32_t m = (uint32_t)((uint64_t)rowp[c * WPT] * sp.a_lo[q] + sp.b8[q]);
-                cols[q].add(tag16(m, (uint32_t)c));
-            }
-            const uint32_t j1 = cols[q].k1 & 15u;
-            best[q] = WPT == 2 ? *reinterpret_cast<const uint64_t *>(rowp + 2 * j1) : (uint64_t)rowp[j1];
-            __builtin_amdgcn_sched_barrier(0);  // one permutation's 16 LDS words at a time (registers)
-        }
-#pragma unroll
-        for (int q = 0; q < P; ++q) {
-            const bool ok = rows[q].apart() && cols[q].apart() && cols[q].k1 >= 16u;
-            fail |= sp.active[q] && !ok;
-            uint32_t l0, h0;
-            mad_wide((uint32_t)best[q], (uint32_t)(best[q] >> 32), pm.a_lo[q], pm.a_hi[q], pm.b[q], l0, h0);
-            res[q] = min(res[q], fold_exact(l0, h0));
-        }
+        fail |= finish_block<P, STRIDE, WPT>(rows, lds, pm, sp, res);
         ++nblocks;
+    }
+    return fail;
+}
+
+// ---- the full launch's first attempt at a flagged set: drop repeated tokens, then sieve ---------
+// A set usually fails the sieve because a token occurs twice (two cells tie at the minimum).  Here
+// each block of up to 256 tokens is copied into the wave's LDS tile, repeated tokens are found with two
+// 1024-slot hash tables in LDS (ds_min of the token index; a token whose slot holds a smaller index
+// with the same value is a repeat), the survivors are compacted in place (ballot + mbcnt prefix), and
+// the sieve runs over the compacted tile -- tokens now come from LDS as broadcast reads instead of
+// scalar loads.  The < 16 tokens left over after the full rows are hashed exactly.  Repeats that the
+// tables miss (both slots taken by an earlier, different token: ~1 %) or keys that are genuinely
+// within 32 still fail the proof; the caller then hashes the set pair by pair.
+constexpr int kDedupSlots = 1024;
+constexpr int kDedupWordsPerWave = kStageWordsPerWave + 2 * kDedupSlots;
+
+// lane l's four tokens of the block that starts at blk (zero where the block has ended)
+template <typename TokT>
+__device__ __forceinline__ void load_quad(const TokT *hv_vec, int64_t blk, int64_t end, int lane, uint64_t (&t)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = blk + 4 * lane + i < end ? (uint64_t)hv_vec[blk + 4 * lane + i] : 0;
+}
+
+// `first`: the quad of the first block, loaded by the caller while the previous set was being processed
+template <int P, typename TokT>
+__device__ __forceinline__ bool dedup_sieve_range(const TokT *hv_vec, int64_t beg, int64_t end, const Perms<P> &pm,
+                                                  const SievePerms<P> &sp, uint32_t *lds, int lane,
+                                                  const uint64_t (&first)[4], uint32_t (&res)[P]) {
+    constexpr int STRIDE = 36;  // the tile always holds 64-bit tokens here
+    uint32_t *tile = lds;
+    uint32_t *table = lds + kStageWordsPerWave;  // [2][kDedupSlots] token indices
+    bool fail = false;
+    for (int64_t blk = beg; blk < end; blk += kBlockRows * kRowTokens) {
+        const int nb = (int)min((int64_t)(kBlockRows * kRowTokens), end - blk);
+        // lane l owns tokens 4l .. 4l+3 of the block
+        uint64_t t[4];
+        bool valid[4];
+        if (blk == beg) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) t[i] = first[i];
+        } else {
+            load_quad<TokT>(hv_vec, blk, end, lane, t);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) valid[i] = 4 * lane + i < nb;
+#pragma unroll
+        for (int i = 0; i < 2 * kDedupSlots / kWave; i += 4)
+            *reinterpret_cast<uint4 *>(table + (2 * kDedupSlots / kWave) * lane + i) = uint4{~0u, ~0u, ~0u, ~0u};
+        uint32_t h1[4], h2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t idx = 4 * lane + i;
+            const uint32_t m = (uint32_t)t[i] ^ (uint32_t)(t[i] >> 32);
+            h1[i] = (m * 0x9E3779B1u) >> 22;
+            h2[i] = kDedupSlots + ((m * 0x85EBCA77u) >> 22);
+            uint32_t *cell = tile + (idx >> 4) * STRIDE + (idx & 15u) * 2;  // raw tile: token idx at (row idx/16, column idx%16)
+            cell[0] = (uint32_t)t[i];
+            cell[1] = (uint32_t)(t[i] >> 32);
+            if (valid[i]) {
+                atomicMin(table + h1[i], idx);
+                atomicMin(table + h2[i], idx);
+            }
+        }
+        bool keep[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t idx = 4 * lane + i;
+            bool repeat = false;
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb) {
+                const uint32_t first = table[tb == 0 ? h1[i] : h2[i]];
+                if (valid[i] && first < idx) {
+                    const uint32_t *cell = tile + (first >> 4) * STRIDE + (first & 15u) * 2;
+                    repeat |= cell[0] == (uint32_t)t[i] && cell[1] == (uint32_t)(t[i] >> 32);
+                }
+            }
+            keep[i] = valid[i] && !repeat;
+        }
+        // compact in place (every read of the raw tile is done: the tile is private to the wave and LDS
+        // operations of one wave complete in order)
+        uint32_t below = 0;  // kept tokens of lower lanes
+        int kept = 0;        // kept tokens of the block (wave-uniform)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned long long mask = __ballot(keep[i]);
+            below += __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+            kept += __popcll(mask);
+        }
+        uint32_t pos = below;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (keep[i]) {
+                uint32_t *cell = tile + (pos >> 4) * STRIDE + (pos & 15u) * 2;
+                cell[0] = (uint32_t)t[i];
+                cell[1] = (uint32_t)(t[i] >> 32);
+                ++pos;
+            }
+        }
+        // sieve over the full rows of the compacted tile: wave-uniform LDS addresses = broadcast reads
+        const int nrows = kept >> 4, rest = kept & 15;
+        if (nrows > 0) {
+            Two rows[P];
+            for (int r = 0; r < nrows; ++r) {
+                const uint4 *rowq = reinterpret_cast<const uint4 *>(tile + r * STRIDE);
+                uint32_t row[P];
+#pragma unroll
+                for (int c2 = 0; c2 < kRowTokens / 2; ++c2) {
+                    const uint4 two = rowq[c2];  // tokens 2*c2 and 2*c2+1: low words .x and .z
+#pragma unroll
+                    for (int q = 0; q < P; ++q) {
+                        const uint32_t k0 = (uint32_t)((uint64_t)two.x * sp.a_lo[q] + sp.b8[q]);
+                        const uint32_t k1 = (uint32_t)((uint64_t)two.z * sp.a_lo[q] + sp.b8[q]);
+                        row[q] = c2 == 0 ? min(k0, k1) : umin3(row[q], k0, k1);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < P; ++q) rows[q].add(tag16(row[q], (uint32_t)r));
+            }
+            fail |= finish_block<P, STRIDE, 2>(rows, tile, pm, sp, res);
+        }
+        for (int i = 0; i < rest; ++i) {  // the tokens after the last full row: exact
+            const uint32_t *cell = tile + nrows * STRIDE + i * 2;
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                uint32_t l0, h0;
+                mad_wide(cell[0], cell[1], pm.a_lo[q], pm.a_hi[q], pm.b[q], l0, h0);
+                res[q] = min(res[q], fold_exact(l0, h0));
+            }
+        }
     }
     return fail;
 }
@@ -631,8 +771,10 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_block = blockDim.x >> 6;
     const int kchunks = (args.num_perm + kWave * P - 1) / (kWave * P);
-    __shared__ __attribute__((aligned(16))) uint32_t stage[MODE == MODE_SIEVE ? 4 * kStageWordsPerWave : 4];
-    uint32_t *lds = stage + (MODE == MODE_SIEVE ? wave * kStageWordsPerWave : 0);
+    // LDS per wave: the token tile of the rescan; the full launch adds the hash tables of its dedup sieve
+    constexpr int kLdsPerWave = MODE == MODE_SIEVE ? kStageWordsPerWave : kDedupWordsPerWave;
+    __shared__ __attribute__((aligned(16))) uint32_t stage[4 * kLdsPerWave];
+    uint32_t *lds = stage + wave * kLdsPerWave;
     Perms<P> pm, pm_biased;
     SievePerms<P> sp;
     int kidx[P];
@@ -647,14 +789,20 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) 
     // ballot, then the flagged sets one by one (a flag array, not an appended list: hundreds of
     // thousands of atomics on one counter serialise -- measured 8 ms for 500k failed sets)
     const bool flagged_only = MODE == MODE_FULL && args.redo != nullptr;
-    const int64_t n_items = flagged_only ? (args.n_sets + kWave - 1) / kWave : args.n_sets;
+    // (the four waves of a workgroup share one group of 64 flags and take every fourth flagged set of it:
+    // one wave per 64 sets left 2.5 rounds of 64-set waves when everything was flagged)
+    const int64_t n_items = flagged_only ? (args.n_sets + kWave - 1) / kWave * waves_per_block : args.n_sets;
     SieveBackoff backoff;
-    for (int64_t item = (int64_t)blockIdx.x * waves_per_block + wave; item < n_items; item += stride) {
+    for (int64_t item0 = (int64_t)blockIdx.x * waves_per_block + wave; item0 < n_items; item0 += stride) {
+      const int64_t item = flagged_only ? item0 / waves_per_block : item0;  // 64-flag group
       unsigned long long todo = 1;  // sets of this item still to do (bit i = set 64*item + i when flagged_only)
       if (flagged_only) {
           const int64_t cand = item * kWave + lane;
-          todo = __ballot(cand < args.n_sets && args.redo[cand] != 0);
+          const bool mine = (lane % waves_per_block) == wave;
+          todo = __ballot(mine && cand < args.n_sets && args.redo[cand] != 0);
       }
+      uint64_t quad[4] = {0, 0, 0, 0};  // MODE_FULL after a sieve launch: first tokens of the current set, fetched one set ahead
+      int64_t quad_set = -1;  // the set `quad` belongs to
       while (todo) {
         const int bit = __builtin_ctzll(todo);
         todo &= todo - 1;
@@ -706,10 +854,36 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) 
                     kidx[p] = k < args.num_perm ? k : -1;
                 }
                 if (end > beg) {
-                    const Minima<P> m = full_minima<P, TokT>(hv_vec, beg, end, args.a, args.b, args.num_perm,
-                                                             kc * (kWave * P), args.path == 1, args.stats);
+                    // a flagged set first gets the dedup sieve (repeated tokens are what usually broke the
+                    // proof); only what that cannot prove either is hashed pair by pair
+                    bool pairwise = true;
+                    if (flagged_only) {
+                        load_perms<P>(args, kc * (kWave * P), lane, pm, pm_biased, sp, kidx);
 #pragma unroll
-                    for (int p = 0; p < P; ++p) res[p] = m.v[p];
+                        for (int p = 0; p < P; ++p) res[p] = kMaxHash;
+                        uint64_t cur[4];
+                        if (quad_set == set && kc == 0) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) cur[i] = quad[i];
+                        } else {
+                            load_quad<TokT>(hv_vec, beg, end, lane, cur);
+                        }
+                        if (kc == kchunks - 1 && todo) {  // the next flagged set of this item: its tokens travel while this one is hashed
+                            const int64_t nset = item * kWave + __builtin_ctzll(todo);
+                            const int64_t nbeg = args.offsets ? offsets[nset] : nset * args.fixed_len;
+                            const int64_t nend = args.offsets ? offsets[nset + 1] : nbeg + args.fixed_len;
+                            load_quad<TokT>(hv_vec, nbeg, nend, lane, quad);
+                            quad_set = nset;
+                        }
+                        pairwise = __any(dedup_sieve_range<P, TokT>(hv_vec, beg, end, pm, sp, lds, lane, cur, res));
+                        if (pairwise && args.stats && lane == 0) atomicAdd(args.stats + 3, 1ull);
+                    }
+                    if (pairwise) {
+                        const Minima<P> m = full_minima<P, TokT>(hv_vec, beg, end, args.a, args.b, args.num_perm,
+                                                                 kc * (kWave * P), args.path == 1, args.stats);
+#pragma unroll
+                        for (int p = 0; p < P; ++p) res[p] = m.v[p];
+                    }
                 }
             }
 #pragma unroll
@@ -858,8 +1032,8 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t total_tokens, bool 
             // sieve launch (writes a flag per set), then the full evaluation of the flagged sets (usually a
             // handful: that launch reads n_sets bytes and returns)
             hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE>), grid, dim3(256), 0, ctx->stream, args);
-            const int64_t flag_items = (args.n_sets + kWave - 1) / kWave;  // a wave scans 64 flags at a time
-            dim3 full_grid((unsigned)std::max<int64_t>(1, std::min((flag_items + 3) / 4, max_blocks)), 1u);
+            const int64_t flag_groups = (args.n_sets + kWave - 1) / kWave;  // a workgroup scans 64 flags at a time
+            dim3 full_grid((unsigned)std::max<int64_t>(1, std::min(flag_groups, max_blocks)), 1u);
             hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_FULL>), full_grid, dim3(256), 0, ctx->stream, args);
         } else {
             BulkArgs all = args;

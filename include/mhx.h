@@ -67,8 +67,9 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * 1 wave per set, 2 split sets over waves), ("blocks_per_cu", n), ("minhash.prefetch", 0/1). */
 MHX_API int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value);
 /* Kernel event counters since the last call (synchronises the stream, then resets them):
- *   out[0] sets whose sieve proof failed and were redone with the full evaluation,
- *   out[1] sets redone with the exact fold, out[2] 256-token sieve blocks evaluated, out[3] 0.
+ *   out[0] sets the sieve launch left to the full launch (failed proof, or skipped by the back-off),
+ *   out[1] sets redone with the exact fold, out[2] 256-token sieve blocks evaluated,
+ *   out[3] sets the full launch had to hash pair by pair (its dedup sieve failed too).
  * enable != 0 starts/keeps counting, 0 stops it (counting costs one atomic per event). */
 #define MHX_NUM_COUNTERS 4
 MHX_API int mhx_ctx_counters(mhx_ctx *ctx, int enable, uint64_t out[MHX_NUM_COUNTERS]);
