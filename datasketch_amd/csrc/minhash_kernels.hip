@@ -12,18 +12,18 @@
 //   * tokens are wave-uniform: they are fetched with scalar loads (s_load_dwordx16 = 8 uint64
 //     tokens) into SGPRs and feed v_mad_u64_u32 directly as the scalar operand; the next chunk
 //     is prefetched while the current one is being hashed.
-//   * per (token, permutation) pair the work is integer VALU: two 32x32 multiplies
-//     (v_mad_u64_u32 + v_mul_lo_u32) and the Mersenne fold.  The common case uses a 3-op fold
-//     whose rare failure (probability 2^-29 per pair) is detected for free from the final
-//     minima; such a set is recomputed with the exact fold, so results are always bit-exact.
-//   * the default path does not even evaluate the full hash for most pairs: a "sieve" tracks
-//     minima of the LOW WORD of the hash in a 16x16 row/column arrangement of each 256-token
-//     block (one multiply and one v_min3 per pair), which pins down the one token that can hold
-//     the minimum AND proves that no other token is close enough to matter; only that token is
-//     hashed exactly.  Blocks where the proof fails fall back to the full evaluation below.
+//   * hashing a (token, permutation) pair in full is integer VALU: two 32x32 multiplies and the
+//     Mersenne fold ("full evaluation": a 3-op fold whose rare failure, probability 2^-29 per pair,
+//     shows in the final minima; such a set is recomputed with the exact fold).
+//   * the default path does not hash most pairs in full: a "sieve" keeps, per row of 16 tokens, the
+//     minimum of the LOW WORD of the hash (one multiply per pair, one v_min3 per two pairs), which pins
+//     down the one token that can hold the minimum AND proves that no other token is close enough to
+//     matter; only that token is hashed exactly (rescan of the best row from a wave-private LDS tile).
+//     Results are bit-exact unconditionally: a set whose proof fails is flagged and a second launch
+//     settles it (repeated tokens dropped + sieve, else the full evaluation).
 //   * sets with few, long token lists (update_batch on one MinHash) are split over many waves
 //     and combined with 64-bit atomic min.
-// The kernel is VALU-bound (about 100 integer ops per input byte), not HBM-bound.
+// The kernels are VALU-bound (about 75 integer ops per input byte), not HBM-bound.
 #include "mhx_internal.h"
 
 namespace mhx {
@@ -42,8 +42,8 @@ struct BulkArgs {
     const uint64_t *b;
     int32_t num_perm;
     int32_t path;            // 0 sieve (+ fallbacks), 1 exact fold everywhere, 2 fast fold (+ exact redo)
-    unsigned long long *stats;  // optional device counters: [0] sets redone after a failed sieve proof,
-                                // [1] sets redone with the exact fold, [2] sieve blocks evaluated
+    unsigned long long *stats;  // optional device counters: [0] sets the sieve launch left to the full one,
+                                // [1] sets redone with the exact fold, [2] sieve blocks, [3] sets hashed pair by pair
     uint8_t *redo;              // wave-per-set kernels: redo[set] != 0 <=> the sieve launch left the set to the full one
     int32_t prefetch;        // warm the next set's tokens with a vector load (option minhash.prefetch)
     int64_t alias_mask;      // profiling only (option minhash.alias): sets read tokens of set (i & mask); -1 = off
