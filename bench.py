@@ -133,8 +133,8 @@ def main():
         step()
         evs[i + 1].record()
     sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0  # this rank's K steps, device work complete
+    barrier()                           # closing barrier; the job's time is the MAX over ranks below
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
