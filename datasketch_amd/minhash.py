@@ -70,6 +70,12 @@ class MinHash:
         permutations: optional ``(a, b)`` permutation parameters to reuse.
     """
 
+    # The reference keeps its CuPy copies of (a, b) in these two attributes (datasketch/minhash.py:
+    # 156-165) and nulls them when pickling; here device state lives in the process-wide libmhx
+    # context, never in the object, so they exist for compatibility and stay None.
+    _a_gpu = None
+    _b_gpu = None
+
     def __init__(
         self,
         num_perm: int = 128,
