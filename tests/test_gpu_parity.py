@@ -223,6 +223,42 @@ def test_fold_boundaries_exhaustive(ctx):
         ctx.set_option("minhash.path", 0)
 
 
+def test_fuzz_random_configurations(ctx):
+    """150 seeded random configurations: set counts, ragged lengths (empty sets, rows of exactly 16,
+    blocks of exactly 256), share of wide tokens, repeated tokens, num_perm, initial state, launch shape."""
+    rng = np.random.RandomState(20260922)
+    try:
+        for case in range(150):
+            n = int(rng.choice([1, 2, 5, 33, 200]))
+            kind = rng.randint(0, 4)
+            if kind == 0:
+                lens = rng.randint(0, 40, n)
+            elif kind == 1:
+                lens = rng.choice([0, 15, 16, 17, 31, 32, 255, 256, 257, 272, 511, 512, 600], n)
+            elif kind == 2:
+                lens = rng.randint(200, 700, n)
+            else:
+                lens = np.full(n, int(rng.choice([16, 64, 256, 300])))
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            hv = rng.randint(0, 2**32, int(off[-1]), dtype=np.uint64)
+            wide = rng.random_sample(hv.size) < rng.choice([0.0, 0.0, 0.01, 0.5])
+            hv[wide] = rng.randint(0, 2**64, int(wide.sum()), dtype=np.uint64)
+            if hv.size > 4 and rng.random_sample() < 0.4:  # repeated tokens, anywhere
+                m = int(hv.size * rng.choice([0.02, 0.3]))
+                hv[rng.randint(0, hv.size, m)] = hv[rng.randint(0, hv.size, m)]
+            k = int(rng.choice([1, 16, 64, 65, 128, 130, 256, 300]))
+            a, b = O.np_init_permutations(k, int(rng.randint(0, 1000)))
+            init = [None, rng.randint(0, 2**32, k, dtype=np.uint64), rng.randint(0, 2**33, (n, k), dtype=np.uint64)][rng.randint(0, 3)]
+            ctx.set_option("minhash.split", int(rng.choice([0, 0, 1, 2])))
+            ctx.set_option("minhash.path", int(rng.choice([0, 0, 0, 1, 2])))
+            got = ctx.minhash_bulk((a, b), hv, off, 0, n, init)
+            want = O.c_minhash_bulk(hv, off, a, b, init)
+            assert np.array_equal(got, want), (case, n, kind, k)
+    finally:
+        ctx.set_option("minhash.split", 0)
+        ctx.set_option("minhash.path", 0)
+
+
 # ------------------------------------------------------------------ sieve path (minhash.path = 0)
 @pytest.mark.parametrize("t", [31, 32, 33, 63, 64, 65, 255, 256, 257, 287, 288, 511, 512, 513, 1000, 5000])
 @pytest.mark.parametrize("k", [64, 128])
