@@ -315,8 +315,10 @@ class Context:
 
     # -- host-buffer entry points ------------------------------------------------------------
     def minhash_bulk(self, permutations, hv: np.ndarray, offsets: Optional[np.ndarray], fixed_len: int, n_sets: int,
-                     init: Optional[np.ndarray] = None) -> np.ndarray:
-        """CSR / fixed-length corpus of pre-hashed tokens -> [n_sets, K] uint64 (host in, host out)."""
+                     init: Optional[np.ndarray] = None, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """CSR / fixed-length corpus of pre-hashed tokens -> [n_sets, K] uint64 (host in, host out).
+        ``out`` may name a C-contiguous uint64 [n_sets, K] array to fill (reusing one avoids the page
+        faults of a fresh gigabyte)."""
         perm = self.perm_handle(permutations)
         k = len(permutations[0])
         hv = np.ascontiguousarray(hv, dtype=np.uint64)
@@ -337,7 +339,10 @@ class Context:
                 stride = k
             else:
                 raise ValueError("init must have shape (K,) or (n_sets, K)")
-        out = np.empty((n_sets, k), dtype=np.uint64)
+        if out is None:
+            out = np.empty((n_sets, k), dtype=np.uint64)
+        elif out.dtype != np.uint64 or out.shape != (n_sets, k) or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous uint64 array of shape (n_sets, K)")
         check(self.lib.mhx_minhash_bulk(perm, _ptr(hv), _ptr(offsets), int(fixed_len), int(n_sets), _ptr(init), stride, _ptr(out)))
         return out
 

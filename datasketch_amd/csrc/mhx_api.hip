@@ -2,7 +2,10 @@
 // host-buffer entry points that stage through device scratch.  Product code: no oracle here.
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "mhx_internal.h"
@@ -70,6 +73,12 @@ int mhx_ctx::ensure_scratch(int slot, size_t bytes) {
                     hipGetErrorString(e));
     }
     scratch_bytes[slot] = want;
+    return MHX_OK;
+}
+
+int mhx_ctx::ensure_copy_streams() {
+    if (!copy_in) MHX_HIP_CHECK(hipStreamCreateWithFlags(&copy_in, hipStreamNonBlocking));
+    if (!copy_out) MHX_HIP_CHECK(hipStreamCreateWithFlags(&copy_out, hipStreamNonBlocking));
     return MHX_OK;
 }
 
@@ -145,6 +154,8 @@ int mhx_ctx_destroy(mhx_ctx *ctx) {
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->d_redo) (void)hipFree(ctx->d_redo);
+    if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
+    if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return MHX_OK;
@@ -175,6 +186,7 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "minhash.alias")) ctx->opt_minhash_alias = value;
     else if (!strcmp(key, "minhash.prefetch")) ctx->opt_minhash_prefetch = value;
     else if (!strcmp(key, "weighted.path")) ctx->opt_weighted_path = value;
+    else if (!strcmp(key, "host.chunk_bytes")) ctx->opt_host_chunk_bytes = value;
     else return fail(MHX_ERR_INVALID, "unknown option '%s'", key);
     return MHX_OK;
 }
@@ -346,6 +358,140 @@ int mhx_minhash_bulk_dev(mhx_perm *perm, const void *d_hv, int hv_dtype, const i
                                     d_init, init_stride, d_out, out_dtype);
 }
 
+extern "C++" {
+namespace {
+
+// One piece of a pipelined host call: sets [s0, s1) whose tokens are hv[t0, t1).
+struct Piece {
+    int64_t s0, s1, t0, t1;
+};
+
+// Cut the corpus into pieces of about `target` bytes (tokens in + signature rows out); a piece is
+// at least one set, so one enormous set still becomes one piece.
+std::vector<Piece> cut_pieces(const int64_t *offsets, int64_t fixed_len, int64_t n_sets, int64_t k, int64_t target) {
+    std::vector<Piece> pieces;
+    int64_t s0 = 0;
+    while (s0 < n_sets) {
+        int64_t s1;
+        if (offsets) {
+            // largest s1 with 8*(offsets[s1]-offsets[s0]) + 8*k*(s1-s0) <= target: the cost is increasing in s1
+            int64_t lo = s0 + 1, hi = n_sets;
+            while (lo < hi) {
+                const int64_t mid = lo + (hi - lo + 1) / 2;
+                const int64_t cost = 8 * (offsets[mid] - offsets[s0]) + 8 * k * (mid - s0);
+                if (cost <= target) lo = mid; else hi = mid - 1;
+            }
+            s1 = lo;
+        } else {
+            const int64_t per_set = 8 * (fixed_len + k);
+            s1 = std::min(n_sets, s0 + std::max<int64_t>(1, target / per_set));
+        }
+        Piece p;
+        p.s0 = s0;
+        p.s1 = s1;
+        p.t0 = offsets ? offsets[s0] : s0 * fixed_len;
+        p.t1 = offsets ? offsets[s1] : s1 * fixed_len;
+        pieces.push_back(p);
+        s0 = s1;
+    }
+    return pieces;
+}
+
+// Host corpus -> host signatures with the three legs overlapped: this thread uploads piece i+1
+// (copy_in stream) while the kernels of piece i run (ctx->stream) and a second thread downloads the
+// rows of piece i-1 (copy_out stream).  PCIe is full duplex, so a large call costs about
+// max(upload, download) instead of their sum.  Device buffers hold the whole corpus (no reuse
+// hazards); offsets stay absolute, so a piece is just a window of sets.
+int bulk_pipelined(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets, int64_t fixed_len, int64_t n_sets,
+                   const uint64_t *init, int64_t init_stride, uint64_t *out, uint64_t *d_hv, int64_t *d_off,
+                   uint64_t *d_init, uint64_t *d_out, const std::vector<Piece> &pieces) {
+    mhx_ctx *ctx = perm->ctx;
+    const int64_t k = perm->num_perm;
+    if (int rc = ctx->ensure_copy_streams()) return rc;
+    const size_t n_pieces = pieces.size();
+    std::vector<hipEvent_t> uploaded(n_pieces, nullptr), computed(n_pieces, nullptr);
+    auto destroy_events = [&]() {
+        for (hipEvent_t e : uploaded) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : computed) if (e) (void)hipEventDestroy(e);
+    };
+    for (size_t i = 0; i < n_pieces; ++i) {
+        hipError_t e = hipEventCreateWithFlags(&uploaded[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&computed[i], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            destroy_events();
+            return fail(MHX_ERR_HIP, "hipEventCreate failed: %s", hipGetErrorString(e));
+        }
+    }
+    // the download thread may only wait on an event after this thread has recorded it
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t recorded = 0;
+    bool stop = false;
+    hipError_t down_err = hipSuccess;
+    std::thread downloader([&]() {
+        hipError_t e = hipSetDevice(ctx->device);
+        for (size_t i = 0; i < n_pieces && e == hipSuccess; ++i) {
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv.wait(lock, [&] { return recorded > i || stop; });
+                if (recorded <= i) break;  // stopped before this piece was launched
+            }
+            const Piece &p = pieces[i];
+            e = hipStreamWaitEvent(ctx->copy_out, computed[i], 0);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(out + p.s0 * k, d_out + p.s0 * k, sizeof(uint64_t) * (size_t)((p.s1 - p.s0) * k),
+                                   hipMemcpyDeviceToHost, ctx->copy_out);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_out);
+        down_err = e;
+    });
+    auto finish = [&](int rc) -> int {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            stop = true;
+        }
+        cv.notify_all();
+        downloader.join();
+        (void)hipStreamSynchronize(ctx->copy_in);
+        (void)hipStreamSynchronize(ctx->stream);
+        destroy_events();
+        if (rc) return rc;
+        if (down_err != hipSuccess) return fail(MHX_ERR_HIP, "downloading signatures failed: %s", hipGetErrorString(down_err));
+        return MHX_OK;
+    };
+    for (size_t i = 0; i < n_pieces; ++i) {  // offsets stay absolute: hv[t] sits at d_hv[t]
+        const Piece &p = pieces[i];
+        hipError_t e = hipSuccess;
+        if (p.t1 > p.t0)
+            e = hipMemcpyAsync(d_hv + p.t0, hv + p.t0, sizeof(uint64_t) * (size_t)(p.t1 - p.t0), hipMemcpyHostToDevice,
+                               ctx->copy_in);
+        if (e == hipSuccess && init && init_stride)
+            e = hipMemcpyAsync(d_init + p.s0 * init_stride, init + p.s0 * init_stride,
+                               sizeof(uint64_t) * (size_t)((p.s1 - p.s0) * init_stride), hipMemcpyHostToDevice, ctx->copy_in);
+        if (e == hipSuccess) e = hipEventRecord(uploaded[i], ctx->copy_in);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, uploaded[i], 0);
+        if (e != hipSuccess) return finish(fail(MHX_ERR_HIP, "uploading tokens failed: %s", hipGetErrorString(e)));
+        const uint64_t *piece_hv = offsets ? d_hv : d_hv + p.t0;
+        const int64_t *piece_off = offsets ? d_off + p.s0 : nullptr;
+        const uint64_t *piece_init = !init ? nullptr : (init_stride ? d_init + p.s0 * init_stride : d_init);
+        const int64_t first = offsets ? p.t0 : 0, last = offsets ? p.t1 : p.t1 - p.t0;
+        if (int rc = mhx::launch_minhash_bulk(perm, piece_hv, MHX_U64, piece_off, fixed_len, p.s1 - p.s0, last,
+                                              piece_init, init_stride, d_out + p.s0 * k, MHX_U64, first))
+            return finish(rc);
+        e = hipEventRecord(computed[i], ctx->stream);
+        if (e != hipSuccess) return finish(fail(MHX_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(e)));
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            recorded = i + 1;
+        }
+        cv.notify_all();
+    }
+    return finish(MHX_OK);
+}
+
+}  // namespace
+}  // extern "C++"
+
 int mhx_minhash_bulk(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets, int64_t fixed_len,
                      int64_t n_sets, const uint64_t *init, int64_t init_stride, uint64_t *out) {
     if (!perm) return fail(MHX_ERR_INVALID, "perm is NULL");
@@ -377,6 +523,22 @@ int mhx_minhash_bulk(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets,
     int64_t *d_off = offsets ? (int64_t *)ctx->scratch[1] : nullptr;
     uint64_t *d_init = init ? (uint64_t *)((char *)ctx->scratch[1] + ((off_bytes + 255) & ~(size_t)255)) : nullptr;
     uint64_t *d_out = (uint64_t *)ctx->scratch[2];
+
+    // large corpora: upload, kernels and download overlap piece by piece
+    const int64_t chunk_opt = ctx->opt_host_chunk_bytes;
+    const int64_t target = chunk_opt > 0 ? chunk_opt : (int64_t)96 << 20;
+    const bool pipelined = chunk_opt > 0 || (chunk_opt == 0 && hv_bytes + out_bytes > ((size_t)256 << 20));
+    if (pipelined) {
+        const std::vector<Piece> pieces = cut_pieces(offsets, fixed_len, n_sets, k, target);
+        if (pieces.size() > 1) {
+            // small operands first, on the compute stream: every piece's kernels are ordered after them
+            if (off_bytes) MHX_HIP_CHECK(hipMemcpyAsync(d_off, offsets, off_bytes, hipMemcpyHostToDevice, ctx->stream));
+            if (init && !init_stride)
+                MHX_HIP_CHECK(hipMemcpyAsync(d_init, init, init_bytes, hipMemcpyHostToDevice, ctx->stream));
+            return bulk_pipelined(perm, hv, offsets, fixed_len, n_sets, init, init_stride, out, d_hv, d_off, d_init,
+                                  d_out, pieces);
+        }
+    }
     if (hv_bytes) MHX_HIP_CHECK(hipMemcpyAsync(d_hv, hv, hv_bytes, hipMemcpyHostToDevice, ctx->stream));
     if (off_bytes) MHX_HIP_CHECK(hipMemcpyAsync(d_off, offsets, off_bytes, hipMemcpyHostToDevice, ctx->stream));
     if (init_bytes) MHX_HIP_CHECK(hipMemcpyAsync(d_init, init, init_bytes, hipMemcpyHostToDevice, ctx->stream));

@@ -52,6 +52,12 @@ struct mhx_ctx {
     int64_t opt_minhash_prefetch = 1; // warm L2 with the next set's tokens (vector load per set)
     int64_t opt_minhash_alias = -1; // profiling only: >= 0 makes set i read the tokens of set (i & mask)
     int64_t opt_weighted_path = 0;  // 0 auto (reciprocal-multiply quotient + row blocks), 1 IEEE division for every element
+    int64_t opt_host_chunk_bytes = 0;  // mhx_minhash_bulk: bytes per pipelined piece; 0 auto (96 MiB, inputs > 256 MiB), < 0 never pipeline
+
+    // copy streams of the pipelined host entry point (created on first use)
+    hipStream_t copy_in = nullptr;
+    hipStream_t copy_out = nullptr;
+    int ensure_copy_streams();
 
     // device counters of the MinHash kernels (mhx_ctx_counters); nullptr until counting is enabled
     unsigned long long *d_stats = nullptr;
@@ -94,7 +100,8 @@ namespace mhx {
 // kernels' host-side launchers (defined in the .hip files)
 int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const int64_t *d_offsets,
                         int64_t fixed_len, int64_t n_sets, int64_t total_tokens,
-                        const uint64_t *d_init, int64_t init_stride, void *d_out, int out_dtype);
+                        const uint64_t *d_init, int64_t init_stride, void *d_out, int out_dtype,
+                        int64_t first_token = 0);
 int launch_sha1_tokens(mhx_ctx *ctx, const uint8_t *d_bytes, const int64_t *d_offsets, int64_t n_tokens,
                        int out_dtype, void *d_out);
 int launch_minhash_merge(mhx_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y, int64_t count,

@@ -934,8 +934,8 @@ __global__ void minhash_fill_state_kernel(const BulkArgs args) {
 }
 
 template <int P, typename TokT, typename OutT>
-__global__ __launch_bounds__(256) void minhash_split_kernel(const BulkArgs args, int64_t total_tokens,
-                                                            int64_t slice) {
+__global__ __launch_bounds__(256) void minhash_split_kernel(const BulkArgs args, int64_t first_token,
+                                                            int64_t total_tokens, int64_t slice) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_block = blockDim.x >> 6;
@@ -954,8 +954,8 @@ __global__ __launch_bounds__(256) void minhash_split_kernel(const BulkArgs args,
     const int64_t stride = (int64_t)gridDim.x * waves_per_block;
     SieveBackoff backoff;
     for (int64_t s = (int64_t)blockIdx.x * waves_per_block + wave; s < n_slices; s += stride) {
-        const int64_t s_beg = s * slice;
-        const int64_t s_end = min(s_beg + slice, total_tokens);
+        const int64_t s_beg = first_token + s * slice;  // slices tile [first_token, first_token + total_tokens)
+        const int64_t s_end = min(s_beg + slice, first_token + total_tokens);
         // first set whose range intersects [s_beg, s_end): largest i with start(i) <= s_beg
         int64_t set;
         if (args.offsets) {
@@ -1021,7 +1021,7 @@ __global__ void minhash_merge_kernel(const uint64_t *__restrict__ x, const uint6
 }
 
 template <int P, typename TokT, typename OutT>
-int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t total_tokens, bool split) {
+int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_t total_tokens, bool split) {
     const int kchunks = (args.num_perm + kWave * P - 1) / (kWave * P);
     const int blocks_per_cu = ctx->opt_blocks_per_cu > 0 ? (int)ctx->opt_blocks_per_cu : 64;  // >> residency: dispatcher evens out the tail (16: 2.40 ms, 32: 2.29, 64: 2.23)
     const int64_t max_blocks = (int64_t)ctx->num_cus * blocks_per_cu;
@@ -1054,26 +1054,29 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t total_tokens, bool 
         const int64_t want = (n_slices + 3) / 4;
         dim3 grid((unsigned)std::max<int64_t>(1, std::min(want, max_blocks)), (unsigned)kchunks);
         hipLaunchKernelGGL((minhash_split_kernel<P, TokT, OutT>), grid, dim3(256), 0, ctx->stream, args,
-                           total_tokens, slice);
+                           first_token, total_tokens, slice);
     }
     MHX_HIP_CHECK(hipGetLastError());
     return MHX_OK;
 }
 
 template <typename TokT, typename OutT>
-int launch_p(mhx_ctx *ctx, const BulkArgs &args, int64_t total_tokens, bool split) {
+int launch_p(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_t total_tokens, bool split) {
     // P permutations per lane: 1 for K <= 64, else 2 (K > 128 walks ceil(K/128) chunks per set)
-    if (args.num_perm <= 64) return launch_typed<1, TokT, OutT>(ctx, args, total_tokens, split);
-    return launch_typed<2, TokT, OutT>(ctx, args, total_tokens, split);
+    if (args.num_perm <= 64) return launch_typed<1, TokT, OutT>(ctx, args, first_token, total_tokens, split);
+    return launch_typed<2, TokT, OutT>(ctx, args, first_token, total_tokens, split);
 }
 
 }  // namespace
 
 int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const int64_t *d_offsets,
                         int64_t fixed_len, int64_t n_sets, int64_t total_tokens,
-                        const uint64_t *d_init, int64_t init_stride, void *d_out, int out_dtype) {
+                        const uint64_t *d_init, int64_t init_stride, void *d_out, int out_dtype, int64_t first_token) {
+    // the sets' tokens lie in d_hv[first_token, total_tokens): first_token is 0 for a whole corpus (tokens
+    // in front of offsets[0] are then merely never touched) and the window start for a piece of one
     mhx_ctx *ctx = perm->ctx;
     if (n_sets == 0) return MHX_OK;
+    total_tokens -= first_token;  // from here on: the number of tokens in the window
     BulkArgs args;
     args.hv = d_hv;
     args.offsets = d_offsets;
@@ -1099,10 +1102,10 @@ int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const in
         if (int rc = ctx->ensure_redo(n_sets)) return rc;
         args.redo = ctx->d_redo;
     }
-    if (hv_dtype == MHX_U64 && out_dtype == MHX_U64) return launch_p<uint64_t, uint64_t>(ctx, args, total_tokens, split);
-    if (hv_dtype == MHX_U64 && out_dtype == MHX_U32) return launch_p<uint64_t, uint32_t>(ctx, args, total_tokens, split);
-    if (hv_dtype == MHX_U32 && out_dtype == MHX_U64) return launch_p<uint32_t, uint64_t>(ctx, args, total_tokens, split);
-    if (hv_dtype == MHX_U32 && out_dtype == MHX_U32) return launch_p<uint32_t, uint32_t>(ctx, args, total_tokens, split);
+    if (hv_dtype == MHX_U64 && out_dtype == MHX_U64) return launch_p<uint64_t, uint64_t>(ctx, args, first_token, total_tokens, split);
+    if (hv_dtype == MHX_U64 && out_dtype == MHX_U32) return launch_p<uint64_t, uint32_t>(ctx, args, first_token, total_tokens, split);
+    if (hv_dtype == MHX_U32 && out_dtype == MHX_U64) return launch_p<uint32_t, uint64_t>(ctx, args, first_token, total_tokens, split);
+    if (hv_dtype == MHX_U32 && out_dtype == MHX_U32) return launch_p<uint32_t, uint32_t>(ctx, args, first_token, total_tokens, split);
     return fail(MHX_ERR_INVALID, "unknown hv_dtype/out_dtype (%d, %d)", hv_dtype, out_dtype);
 }
 

@@ -64,7 +64,9 @@ MHX_API int mhx_ctx_synchronize(mhx_ctx *ctx);
 MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus, int64_t *hbm_bytes);
 /* Tuning / test knobs: ("minhash.path", 0 = auto: sieve with full-evaluation fallback,
  * 1 = exact fold for every pair, 2 = fast fold with exact redo), ("minhash.split", 0 auto,
- * 1 wave per set, 2 split sets over waves), ("blocks_per_cu", n), ("minhash.prefetch", 0/1). */
+ * 1 wave per set, 2 split sets over waves), ("blocks_per_cu", n), ("minhash.prefetch", 0/1),
+ * ("weighted.path", 0 auto, 1 IEEE division for every element), ("host.chunk_bytes", see
+ * mhx_minhash_bulk). */
 MHX_API int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value);
 /* Kernel event counters since the last call (synchronises the stream, then resets them):
  *   out[0] sets the sieve launch left to the full launch (failed proof, or skipped by the back-off),
@@ -123,7 +125,9 @@ MHX_API int mhx_minhash_bulk_dev(mhx_perm *perm, const void *d_hv, int hv_dtype,
                                  void *d_out, int out_dtype);
 
 /* Same computation from/to host buffers (H2D, kernel, D2H; blocking).  offsets may be NULL
- * with fixed_len, init may be NULL.  out: uint64 [n_sets, K]. */
+ * with fixed_len, init may be NULL.  out: uint64 [n_sets, K].  Corpora above 256 MiB are cut
+ * into pieces of whole sets whose upload, kernels and download overlap (option
+ * "host.chunk_bytes": > 0 piece size in bytes, 0 automatic, < 0 one piece). */
 MHX_API int mhx_minhash_bulk(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets,
                              int64_t fixed_len, int64_t n_sets, const uint64_t *init,
                              int64_t init_stride, uint64_t *out);

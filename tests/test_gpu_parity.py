@@ -259,6 +259,38 @@ def test_fuzz_random_configurations(ctx):
         ctx.set_option("minhash.path", 0)
 
 
+@pytest.mark.parametrize("chunk_bytes", [4096, 70_000, 1 << 20])
+def test_host_call_pipelined_in_pieces(ctx, chunk_bytes):
+    """mhx_minhash_bulk cut into pieces (upload / kernels / download overlapped): ragged CSR with empty
+    sets, one set larger than a piece, offsets[0] > 0, every form of initial state; fixed-length too."""
+    rng = np.random.RandomState(chunk_bytes)
+    n, k = 700, 128
+    lens = rng.randint(0, 300, n)
+    lens[100] = 40_000  # larger than the smallest piece sizes
+    lens[200:230] = 0
+    off = (17 + np.concatenate([[0], np.cumsum(lens)])).astype(np.int64)  # tokens before offsets[0] are unused
+    hv = rng.randint(0, 2**32, int(off[-1]), dtype=np.uint64)
+    hv[::97] = rng.randint(2**32, 2**64, len(hv[::97]), dtype=np.uint64)
+    a, b = O.np_init_permutations(k, 5)
+    inits = [None, rng.randint(0, 2**32, k, dtype=np.uint64), rng.randint(0, 2**33, (n, k), dtype=np.uint64)]
+    try:
+        for init in inits:
+            want = O.c_minhash_bulk(hv, off, a, b, init)
+            ctx.set_option("host.chunk_bytes", -1)
+            whole = ctx.minhash_bulk((a, b), hv, off, 0, n, init)
+            ctx.set_option("host.chunk_bytes", chunk_bytes)
+            pieces = ctx.minhash_bulk((a, b), hv, off, 0, n, init)
+            assert np.array_equal(whole, want)
+            assert np.array_equal(pieces, want)
+        tok = rng.randint(0, 2**32, (3000, 64), dtype=np.uint64)
+        want = O.c_minhash_bulk_dense(tok, a, b)
+        assert np.array_equal(ctx.minhash_bulk((a, b), tok.reshape(-1), None, 64, 3000), want)
+        assert np.array_equal(ctx.minhash_bulk((a, b), tok.reshape(-1), None, 64, 3000, inits[1]),
+                              np.minimum(want, inits[1][None, :]))
+    finally:
+        ctx.set_option("host.chunk_bytes", 0)
+
+
 # ------------------------------------------------------------------ sieve path (minhash.path = 0)
 @pytest.mark.parametrize("t", [31, 32, 33, 63, 64, 65, 255, 256, 257, 287, 288, 511, 512, 513, 1000, 5000])
 @pytest.mark.parametrize("k", [64, 128])
