@@ -204,9 +204,15 @@ def main():
 
     if rank == 0 and world == 1:
         if not args.no_e2e:
+            # host numpy in -> host numpy out through mhx_minhash_bulk (pageable memory): the first call
+            # also allocates device scratch and first-touches a fresh result array; the second reuses both
             t1 = time.perf_counter()
-            ctx.minhash_bulk(perms, tokens.reshape(-1), None, t, n, None)
+            host_out = ctx.minhash_bulk(perms, tokens.reshape(-1), None, t, n, None)
+            out["pcie_inclusive_first_call_value"] = n / (time.perf_counter() - t1)
+            t1 = time.perf_counter()
+            ctx.minhash_bulk(perms, tokens.reshape(-1), None, t, n, None, out=host_out)
             out["pcie_inclusive_value"] = n / (time.perf_counter() - t1)
+            del host_out
         if args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(O, tokens, a, b, min(args.cpu_sample, n), k, t, seed=args.seed)
     if dist is not None:

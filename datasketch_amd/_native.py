@@ -68,6 +68,9 @@ _PROTOTYPES = {
     "mhx_band_digests": [_vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp],
     "mhx_lsh_sort_bands_dev": [_vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
     "mhx_lsh_sort_bands": [_vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
+    "mhx_lsh_candidate_pairs_dev": [_vp, _vp, _vp, _i64, ctypes.c_int32, _vp, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
+    "mhx_lsh_candidate_pairs": [_vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _i64,
+                                ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
     "mhx_jaccard_pairs_dev": [_vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp],
     "mhx_jaccard_pairs": [_vp, _vp, _i64, ctypes.c_int32, _vp, _i64, _vp],
     "mhx_lean_serialize_dev": [_vp, _vp, _i64, _i32, _i64, _vp],
@@ -448,6 +451,22 @@ class Context:
         rows = np.empty((bands, n), dtype=np.uint32)
         check(self.lib.mhx_lsh_sort_bands(self.handle, _ptr(sig), n, k, int(bands), int(r), _ptr(dig), _ptr(rows)))
         return dig, rows
+
+    def lsh_candidate_pairs(self, sig: np.ndarray, bands: int, r: int, capacity: Optional[int] = None):
+        """(pairs int64 [M, 2] ascending and unique, raw pair count before deduplication across bands):
+        rows i < j sharing the key of at least one band (mhx_lsh_candidate_pairs).  ``capacity`` is the
+        first guess of M; a larger answer costs one more call."""
+        sig = np.ascontiguousarray(sig, dtype=np.uint64)
+        n, k = sig.shape
+        cap = int(capacity) if capacity is not None else max(4 * n, 1 << 16)
+        while True:
+            pairs = np.empty((cap, 2), dtype=np.int64)
+            found, raw = _i64(0), _i64(0)
+            check(self.lib.mhx_lsh_candidate_pairs(self.handle, _ptr(sig), n, k, int(bands), int(r), _ptr(pairs), cap,
+                                                   ctypes.byref(found), ctypes.byref(raw)))
+            if found.value <= cap:
+                return pairs[: found.value], int(raw.value)
+            cap = int(found.value)
 
     def jaccard_pairs(self, sig: np.ndarray, pairs: np.ndarray) -> np.ndarray:
         """int32 counts of equal positions for rows (pairs[:,0], pairs[:,1]) of one signature matrix."""

@@ -5,57 +5,218 @@
 // key in at least one band.  Here the grouping is a sort: per band, the 64-bit digests of the band keys
 // (pack_kernels.hip: FNV-1a-64 of exactly the reference's key bytes) are sorted together with the row
 // numbers, so every bucket becomes a run of equal digests.  The sort is rocPRIM's device radix sort
-// (a library primitive: 8 passes of 8 bits over n 64-bit keys); the kernels around it are ours.
+// (a library primitive), ONE call over all n x bands keys ordered by (band, digest); the kernels around
+// it are ours.
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
 
 #include "mhx_internal.h"
 
 namespace mhx {
 namespace {
 
-// digests[n, bands] (row-major) -> keys[bands][n], rows[bands][n] = 0..n-1
-__global__ __launch_bounds__(256) void band_major_kernel(const uint64_t *__restrict__ digests, int64_t n, int32_t bands,
-                                                         uint64_t *__restrict__ keys, uint32_t *__restrict__ rows) {
+// One element of the sort: all bands of all rows go through ONE radix sort, ordered by (band, digest);
+// the row rides along inside the key.  (32 separate sorts of 10^6 keys are launch-bound: ~20 small
+// kernels each.)
+struct BandKey {
+    uint64_t digest;
+    uint32_t band;
+    uint32_t row;
+};
+
+struct BandKeyOrder {  // most significant field first
+    __host__ __device__ rocprim::tuple<uint32_t &, uint64_t &> operator()(BandKey &key) const {
+        return rocprim::tuple<uint32_t &, uint64_t &>(key.band, key.digest);
+    }
+};
+
+// digests[n, bands] (row-major) -> keys in the same order: rows ascend within every band, and the sort is
+// stable, so equal digests of a band keep ascending rows
+__global__ __launch_bounds__(256) void band_keys_for_sort_kernel(const uint64_t *__restrict__ digests, int64_t n, int32_t bands,
+                                                                 BandKey *__restrict__ keys) {
     const int64_t total = n * (int64_t)bands;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = idx / bands;  // coalesced read, scattered (stride n) write
-        const int band = (int)(idx - row * bands);
-        keys[(int64_t)band * n + row] = digests[idx];
-        rows[(int64_t)band * n + row] = (uint32_t)row;
+        const int64_t row = idx / bands;
+        BandKey key;
+        key.digest = digests[idx];
+        key.band = (uint32_t)(idx - row * bands);
+        key.row = (uint32_t)row;
+        keys[idx] = key;
     }
+}
+
+// sorted keys (band-major by construction) -> sorted_digests[bands][n], sorted_rows[bands][n]
+__global__ __launch_bounds__(256) void split_sorted_kernel(const BandKey *__restrict__ keys, int64_t total,
+                                                           uint64_t *__restrict__ digests, uint32_t *__restrict__ rows) {
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const BandKey key = keys[idx];
+        digests[idx] = key.digest;
+        rows[idx] = key.row;
+    }
+}
+
+// ---- candidate pairs from the sorted bands --------------------------------------------------------
+// A bucket is a run of equal digests inside one band.  Element p of a run that starts at s pairs with
+// the p - s elements in front of it, so the run of length L yields L(L-1)/2 pairs, each exactly once.
+// Most elements are alone in their bucket: only an element that equals its predecessor looks for the
+// start of its run (binary search in the sorted band, ~log2 n reads).
+
+// ahead[p] = number of earlier elements of p's run (0 for a run's first element)
+__global__ __launch_bounds__(256) void run_position_kernel(const uint64_t *__restrict__ digests, int64_t n, int64_t total,
+                                                           uint32_t *__restrict__ ahead) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t band_start = p / n * n;
+        uint32_t c = 0;
+        if (p > band_start && digests[p] == digests[p - 1]) {
+            const uint64_t d = digests[p];
+            int64_t lo = band_start, hi = p - 1;  // first index in [band_start, p-1] holding d
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (digests[mid] < d) lo = mid + 1; else hi = mid;
+            }
+            c = (uint32_t)(p - lo);
+        }
+        ahead[p] = c;
+    }
+}
+
+// raw[where[p] + q] = (min(row_p, row_q) << 32) | max(row_p, row_q) for the ahead[p] elements q in front of p
+__global__ __launch_bounds__(256) void emit_pairs_kernel(const uint32_t *__restrict__ rows, const uint32_t *__restrict__ ahead,
+                                                         const uint64_t *__restrict__ where, int64_t total,
+                                                         uint64_t *__restrict__ raw) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t c = ahead[p];
+        if (c == 0) continue;
+        const uint32_t me = rows[p];
+        uint64_t *dst = raw + where[p];
+        for (uint32_t q = 0; q < c; ++q) {
+            const uint32_t other = rows[p - c + q];
+            const uint32_t lo = me < other ? me : other, hi = me < other ? other : me;
+            dst[q] = ((uint64_t)lo << 32) | hi;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_pairs_kernel(const uint64_t *__restrict__ keys, int64_t count,
+                                                           int64_t *__restrict__ pairs) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = keys[i];
+        longlong2 v;
+        v.x = (long long)(key >> 32);
+        v.y = (long long)(key & 0xFFFFFFFFu);
+        reinterpret_cast<longlong2 *>(pairs)[i] = v;
+    }
+}
+
+unsigned grid_for(const mhx_ctx *ctx, int64_t items) {
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>((items + 255) / 256, (int64_t)ctx->num_cus * 16));
 }
 
 }  // namespace
 
+int launch_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *d_sorted_digests, const uint32_t *d_sorted_rows, int64_t n,
+                               int32_t bands, int64_t *d_pairs, int64_t capacity, int64_t *n_pairs, int64_t *n_raw) {
+    *n_pairs = 0;
+    if (n_raw) *n_raw = 0;
+    const int64_t total = n * (int64_t)bands;
+    if (total == 0) return MHX_OK;
+    // scratch[4], first part: ahead u32[total] | where u64[total] | tail u64[2] | scan temporary
+    const size_t ahead_bytes = ((sizeof(uint32_t) * (size_t)total) + 255) & ~(size_t)255;
+    const size_t where_bytes = ((sizeof(uint64_t) * (size_t)total) + 255) & ~(size_t)255;
+    size_t scan_tmp = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, scan_tmp, (const uint32_t *)nullptr, (uint64_t *)nullptr, (uint64_t)0,
+                                           (size_t)total, rocprim::plus<uint64_t>(), ctx->stream);
+    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::exclusive_scan (size query) failed: %s", hipGetErrorString(e));
+    if (int rc = ctx->ensure_scratch(4, ahead_bytes + where_bytes + 256 + scan_tmp)) return rc;
+    uint32_t *d_ahead = (uint32_t *)ctx->scratch[4];
+    uint64_t *d_where = (uint64_t *)((char *)ctx->scratch[4] + ahead_bytes);
+    void *d_scan_tmp = (char *)ctx->scratch[4] + ahead_bytes + where_bytes + 256;
+    hipLaunchKernelGGL(run_position_kernel, dim3(grid_for(ctx, total)), dim3(256), 0, ctx->stream, d_sorted_digests, n, total,
+                       d_ahead);
+    MHX_HIP_CHECK(hipGetLastError());
+    e = rocprim::exclusive_scan(d_scan_tmp, scan_tmp, (const uint32_t *)d_ahead, d_where, (uint64_t)0, (size_t)total,
+                                rocprim::plus<uint64_t>(), ctx->stream);
+    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::exclusive_scan failed: %s", hipGetErrorString(e));
+    uint64_t last_where = 0;
+    uint32_t last_ahead = 0;
+    MHX_HIP_CHECK(hipMemcpyAsync(&last_where, d_where + (total - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipMemcpyAsync(&last_ahead, d_ahead + (total - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const int64_t raw = (int64_t)(last_where + last_ahead);  // pairs before deduplication across bands
+    if (n_raw) *n_raw = raw;
+    if (raw == 0) return MHX_OK;
+    if ((size_t)raw * 16 > (size_t)ctx->hbm_bytes / 2)
+        return fail(MHX_ERR_OOM, "%lld candidate pairs before deduplication (large buckets of equal band keys) do not fit in device memory",
+                    (long long)raw);
+
+    // scratch[3]: raw u64[raw] | sorted u64[raw] | count u64 | sort / select temporary
+    const size_t raw_bytes = ((sizeof(uint64_t) * (size_t)raw) + 255) & ~(size_t)255;
+    int end_bit = 33;  // the high word holds a row number < n
+    while (end_bit < 64 && ((int64_t)1 << (end_bit - 32)) < n) ++end_bit;
+    size_t sort_tmp = 0, uniq_tmp = 0;
+    e = rocprim::radix_sort_keys(nullptr, sort_tmp, (const uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)raw, 0, end_bit,
+                                 ctx->stream);
+    if (e == hipSuccess)
+        e = rocprim::unique(nullptr, uniq_tmp, (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)raw,
+                            rocprim::equal_to<uint64_t>(), ctx->stream);
+    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim size query failed: %s", hipGetErrorString(e));
+    const size_t tmp_bytes = std::max(sort_tmp, uniq_tmp);
+    if (int rc = ctx->ensure_scratch(3, 2 * raw_bytes + 256 + tmp_bytes)) return rc;
+    uint64_t *d_raw = (uint64_t *)ctx->scratch[3];
+    uint64_t *d_sorted = (uint64_t *)((char *)ctx->scratch[3] + raw_bytes);
+    uint64_t *d_count = (uint64_t *)((char *)ctx->scratch[3] + 2 * raw_bytes);
+    void *d_tmp = (char *)ctx->scratch[3] + 2 * raw_bytes + 256;
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(grid_for(ctx, total)), dim3(256), 0, ctx->stream, d_sorted_rows, d_ahead, d_where,
+                       total, d_raw);
+    MHX_HIP_CHECK(hipGetLastError());
+    e = rocprim::radix_sort_keys(d_tmp, sort_tmp, (const uint64_t *)d_raw, d_sorted, (size_t)raw, 0, end_bit, ctx->stream);
+    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_keys failed: %s", hipGetErrorString(e));
+    e = rocprim::unique(d_tmp, uniq_tmp, (const uint64_t *)d_sorted, d_raw, d_count, (size_t)raw, rocprim::equal_to<uint64_t>(),
+                        ctx->stream);
+    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::unique failed: %s", hipGetErrorString(e));
+    uint64_t unique_count = 0;
+    MHX_HIP_CHECK(hipMemcpyAsync(&unique_count, d_count, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    *n_pairs = (int64_t)unique_count;
+    if ((int64_t)unique_count > capacity) return MHX_OK;  // caller sees n_pairs > capacity and calls again
+    hipLaunchKernelGGL(unpack_pairs_kernel, dim3(grid_for(ctx, (int64_t)unique_count)), dim3(256), 0, ctx->stream, d_raw,
+                       (int64_t)unique_count, d_pairs);
+    MHX_HIP_CHECK(hipGetLastError());
+    return MHX_OK;
+}
+
 int launch_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
                           uint64_t *d_sorted_digests, uint32_t *d_sorted_rows) {
     if (n >= ((int64_t)1 << 32)) return fail(MHX_ERR_UNSUPPORTED, "more than 2^32-1 signatures per call");
-    // scratch[3]: digests[n, bands] | keys[bands][n] | rows[bands][n] | rocPRIM temporary storage
-    const size_t dig_bytes = sizeof(uint64_t) * (size_t)n * bands;
-    const size_t rows_bytes = ((sizeof(uint32_t) * (size_t)n * bands) + 255) & ~(size_t)255;
+    // scratch[3]: digests[n, bands] | keys[n*bands] | sorted keys[n*bands] | rocPRIM temporary storage
+    const int64_t total = n * (int64_t)bands;
+    const size_t dig_bytes = ((sizeof(uint64_t) * (size_t)total) + 255) & ~(size_t)255;
+    const size_t key_bytes = sizeof(BandKey) * (size_t)total;
+    unsigned band_bits = 1;
+    while (((int64_t)1 << band_bits) < bands) ++band_bits;
     size_t tmp_bytes = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
-                                             (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0, 64, ctx->stream);
-    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_pairs (size query) failed: %s", hipGetErrorString(e));
-    if (int rc = ctx->ensure_scratch(3, 2 * dig_bytes + rows_bytes + tmp_bytes + 512)) return rc;
+    hipError_t e = rocprim::radix_sort_keys(nullptr, tmp_bytes, (const BandKey *)nullptr, (BandKey *)nullptr, (size_t)total,
+                                            BandKeyOrder{}, 0u, 64u + band_bits, ctx->stream);
+    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_keys (size query) failed: %s", hipGetErrorString(e));
+    if (int rc = ctx->ensure_scratch(3, dig_bytes + 2 * key_bytes + tmp_bytes + 512)) return rc;
     uint64_t *d_dig = (uint64_t *)ctx->scratch[3];
-    uint64_t *d_keys = (uint64_t *)((char *)ctx->scratch[3] + dig_bytes);
-    uint32_t *d_rows = (uint32_t *)((char *)ctx->scratch[3] + 2 * dig_bytes);
-    void *d_tmp = (char *)ctx->scratch[3] + 2 * dig_bytes + rows_bytes;
+    BandKey *d_keys = (BandKey *)((char *)ctx->scratch[3] + dig_bytes);
+    BandKey *d_sorted = d_keys + total;
+    void *d_tmp = (char *)ctx->scratch[3] + dig_bytes + 2 * key_bytes;
     if (int rc = launch_band_digests(ctx, d_sig, n, k, bands, r, d_dig)) return rc;
-    const int64_t want = (n * bands + 255) / 256;
-    dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * 16)));
-    hipLaunchKernelGGL(band_major_kernel, grid, dim3(256), 0, ctx->stream, d_dig, n, bands, d_keys, d_rows);
+    hipLaunchKernelGGL(band_keys_for_sort_kernel, dim3(grid_for(ctx, total)), dim3(256), 0, ctx->stream, d_dig, n, bands, d_keys);
     MHX_HIP_CHECK(hipGetLastError());
-    for (int32_t j = 0; j < bands; ++j) {
-        e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys + (int64_t)j * n, d_sorted_digests + (int64_t)j * n,
-                                      d_rows + (int64_t)j * n, d_sorted_rows + (int64_t)j * n, (size_t)n, 0, 64,
-                                      ctx->stream);
-        if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
-    }
+    e = rocprim::radix_sort_keys(d_tmp, tmp_bytes, (const BandKey *)d_keys, d_sorted, (size_t)total, BandKeyOrder{}, 0u,
+                                 64u + band_bits, ctx->stream);
+    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_keys failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(split_sorted_kernel, dim3(grid_for(ctx, total)), dim3(256), 0, ctx->stream, d_sorted, total, d_sorted_digests,
+                       d_sorted_rows);
+    MHX_HIP_CHECK(hipGetLastError());
     return MHX_OK;
 }
 

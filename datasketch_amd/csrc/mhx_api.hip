@@ -150,7 +150,7 @@ int mhx_ctx_destroy(mhx_ctx *ctx) {
     if (!ctx) return MHX_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 5; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->d_redo) (void)hipFree(ctx->d_redo);
@@ -816,6 +816,46 @@ int mhx_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, 
     if (int rc = mhx::launch_lsh_sort_bands(ctx, (const uint64_t *)ctx->scratch[0], n, k, bands, r, d_dig, d_rows)) return rc;
     MHX_HIP_CHECK(hipMemcpyAsync(sorted_digests, d_dig, dig_bytes, hipMemcpyDeviceToHost, ctx->stream));
     MHX_HIP_CHECK(hipMemcpyAsync(sorted_rows, d_rows, row_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MHX_OK;
+}
+
+int mhx_lsh_candidate_pairs_dev(mhx_ctx *ctx, const uint64_t *d_sorted_digests, const uint32_t *d_sorted_rows, int64_t n,
+                                int32_t bands, int64_t *d_pairs, int64_t capacity, int64_t *n_pairs, int64_t *n_raw) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_REQUIRE(n_pairs, "n_pairs is NULL");
+    MHX_REQUIRE(bands > 0 && n >= 0 && capacity >= 0, "bad shape");
+    MHX_REQUIRE(n < ((int64_t)1 << 32), "more than 2^32-1 signatures per call");
+    *n_pairs = 0;
+    if (n_raw) *n_raw = 0;
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(d_sorted_digests && d_sorted_rows && (d_pairs || capacity == 0), "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_lsh_candidate_pairs(ctx, d_sorted_digests, d_sorted_rows, n, bands, d_pairs, capacity, n_pairs, n_raw);
+}
+
+int mhx_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int32_t bands, int32_t r,
+                            int64_t *pairs, int64_t capacity, int64_t *n_pairs, int64_t *n_raw) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_REQUIRE(n_pairs, "n_pairs is NULL");
+    MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
+    MHX_REQUIRE(n >= 0 && capacity >= 0, "bad shape");
+    *n_pairs = 0;
+    if (n_raw) *n_raw = 0;
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(sig && (pairs || capacity == 0), "NULL host pointer");
+    // scratch[2]: sorted digests | sorted rows | pairs
+    const size_t dig_bytes = ((sizeof(uint64_t) * (size_t)n * bands) + 255) & ~(size_t)255;
+    const size_t row_bytes = ((sizeof(uint32_t) * (size_t)n * bands) + 255) & ~(size_t)255;
+    const size_t pair_bytes = sizeof(int64_t) * 2 * (size_t)capacity;
+    if (int rc = stage_sig(ctx, sig, n, k, dig_bytes + row_bytes + pair_bytes)) return rc;
+    uint64_t *d_dig = (uint64_t *)ctx->scratch[2];
+    uint32_t *d_rows = (uint32_t *)((char *)ctx->scratch[2] + dig_bytes);
+    int64_t *d_pairs = (int64_t *)((char *)ctx->scratch[2] + dig_bytes + row_bytes);
+    if (int rc = mhx::launch_lsh_sort_bands(ctx, (const uint64_t *)ctx->scratch[0], n, k, bands, r, d_dig, d_rows)) return rc;
+    if (int rc = mhx::launch_lsh_candidate_pairs(ctx, d_dig, d_rows, n, bands, d_pairs, capacity, n_pairs, n_raw)) return rc;
+    if (*n_pairs > 0 && *n_pairs <= capacity)
+        MHX_HIP_CHECK(hipMemcpyAsync(pairs, d_pairs, sizeof(int64_t) * 2 * (size_t)*n_pairs, hipMemcpyDeviceToHost, ctx->stream));
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return MHX_OK;
 }

@@ -43,8 +43,8 @@ struct mhx_ctx {
     int64_t hbm_bytes = 0;
     char name[128] = {0};
     // grow-only scratch used by the host entry points (device staging of inputs/outputs)
-    void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    void *scratch[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[5] = {0, 0, 0, 0, 0};
     // options (mhx_ctx_set_option)
     int64_t opt_minhash_path = 0;   // 0 auto (sieve + fallbacks), 1 exact fold everywhere, 2 fast fold (+exact redo)
     int64_t opt_minhash_split = 0;  // 0 auto, 1 force wave-per-set, 2 force split-sets (atomic combine)
@@ -118,6 +118,8 @@ int launch_band_digests(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t 
                         uint64_t *d_out);
 int launch_jaccard_pairs(mhx_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, int32_t k, const int64_t *d_pairs,
                          int64_t m, int32_t *d_counts);
+int launch_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *d_sorted_digests, const uint32_t *d_sorted_rows, int64_t n,
+                               int32_t bands, int64_t *d_pairs, int64_t capacity, int64_t *n_pairs, int64_t *n_raw);
 int launch_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
                           uint64_t *d_sorted_digests, uint32_t *d_sorted_rows);
 int launch_lean_serialize(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int64_t seed,

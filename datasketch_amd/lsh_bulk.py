@@ -11,7 +11,8 @@ Python round trips:
   index's own storage API, leaving it in exactly the state the per-key loop would;
 * :func:`sorted_bands` / :func:`candidate_pairs` -- LSH bucketing by sort: per band the digests in
   ascending order with their rows (device radix sort), and from that the pairs of rows that share at
-  least one band (what ``query`` would find), without probing dictionaries;
+  least one band (what ``query`` would find), without probing dictionaries -- on the device the
+  whole chain (digests, sorts, run detection, pair emission, sort + unique) is one call;
 * :func:`jaccard_pairs` -- ``MinHash.jaccard`` for a list of pairs (ref: datasketch/minhash.py:299-324).
 """
 from __future__ import annotations
@@ -142,8 +143,13 @@ def sorted_bands(signatures, b: int, r: int, gpu_mode: str = "detect"):
 
 def candidate_pairs(signatures, b: int, r: int, gpu_mode: str = "detect") -> np.ndarray:
     """``[M, 2]`` int64, sorted, unique pairs ``i < j`` of rows that share the key of at least one band
-    -- the pairs ``MinHashLSH(params=(b, r))`` would report for each other."""
-    dig, rows = sorted_bands(signatures, b, r, gpu_mode=gpu_mode)
+    -- the pairs ``MinHashLSH(params=(b, r))`` would report for each other.  On the device: digests,
+    per-band sort, run detection, pair emission, sort + unique in one call (mhx_lsh_candidate_pairs)."""
+    sig = _matrix(signatures)
+    _check_params(sig.shape[1], b, r)
+    if _use_gpu(gpu_mode) and sig.shape[0]:
+        return _native.context().lsh_candidate_pairs(sig, b, r)[0]
+    dig, rows = sorted_bands(sig, b, r, gpu_mode=gpu_mode)
     n = dig.shape[1]
     found: List[np.ndarray] = []
     for j in range(b):

@@ -227,6 +227,21 @@ MHX_API int mhx_lsh_sort_bands_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t 
                                    uint32_t *d_sorted_rows);
 MHX_API int mhx_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs, int32_t num_perm,
                                int32_t bands, int32_t r, uint64_t *sorted_digests, uint32_t *sorted_rows);
+/* Candidate pairs: every pair of rows i < j that share the digest of at least one band -- the rows
+ * MinHashLSH.query (ref: datasketch/lsh.py:370-400) would return for each other -- from the output of
+ * mhx_lsh_sort_bands.  pairs: int64[capacity, 2], ascending by (i, j), unique.  *n_pairs receives the
+ * number of unique pairs; when it exceeds capacity nothing is written and the caller calls again with
+ * a larger buffer.  *n_raw (may be NULL) receives the pair count before deduplication across bands.
+ * A bucket of L equal keys holds L(L-1)/2 pairs: MHX_ERR_OOM when they do not fit in device memory.
+ * Blocking (the counts come back to the host). */
+MHX_API int mhx_lsh_candidate_pairs_dev(mhx_ctx *ctx, const uint64_t *d_sorted_digests,
+                                        const uint32_t *d_sorted_rows, int64_t n_sigs, int32_t bands,
+                                        int64_t *d_pairs, int64_t capacity, int64_t *n_pairs,
+                                        int64_t *n_raw);
+/* signatures (host) -> band digests -> per-band sort -> candidate pairs (host), one call */
+MHX_API int mhx_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs, int32_t num_perm,
+                                    int32_t bands, int32_t r, int64_t *pairs, int64_t capacity,
+                                    int64_t *n_pairs, int64_t *n_raw);
 /* Batched MinHash.jaccard numerators (ref: datasketch/minhash.py:299-324): counts[p] = number of equal
  * positions of rows pairs[p][0] of sig_a and pairs[p][1] of sig_b (both [*, num_perm] uint64; may be the
  * same matrix); the estimate is counts / num_perm.  pairs int64[n_pairs, 2]. */

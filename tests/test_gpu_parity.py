@@ -813,3 +813,68 @@ def test_band_digests_candidates_and_jaccard_on_device(ctx):
         assert np.array_equal(LB.jaccard_pairs(s2, p2, gpu_mode="always"), LB.jaccard_pairs(s2, p2, gpu_mode="disable")), k
     with pytest.raises(ValueError):
         ctx.jaccard_pairs(sig, np.array([[0, 3000]]))
+
+
+@pytest.mark.parametrize("n,b,r,clusters", [(1, 4, 2, 0), (2, 4, 2, 1), (500, 8, 4, 0), (5000, 32, 4, 40), (20000, 16, 8, 300), (3000, 1, 16, 30)])
+def test_candidate_pairs_on_device(ctx, n, b, r, clusters):
+    """mhx_lsh_candidate_pairs against the numpy bucketing: near-duplicates sharing a few bands, clusters
+    of identical rows (quadratic buckets), no pairs at all, the capacity protocol and the raw count."""
+    from datasketch_amd import lsh_bulk as LB
+
+    rng = np.random.RandomState(n + b)
+    k = b * r + 3
+    sig = rng.randint(0, 2**32, (n, k), dtype=np.uint64)
+    for c in range(clusters):  # copy whole rows (all bands shared) or single bands onto other rows
+        src, size = rng.randint(0, n), rng.randint(2, 9)
+        members = rng.randint(0, n, size)
+        if c % 2 == 0:
+            sig[members] = sig[src]
+        else:
+            j = rng.randint(0, b)
+            sig[members, j * r:(j + 1) * r] = sig[src, j * r:(j + 1) * r]
+    if n == 2:
+        sig[1] = sig[0]
+    want = LB.candidate_pairs(sig, b, r, gpu_mode="disable")
+    got, raw = ctx.lsh_candidate_pairs(sig, b, r)
+    assert got.dtype == np.int64 and np.array_equal(got, want)
+    assert raw >= len(want)
+    if clusters == 0:
+        assert len(want) == 0 and raw == 0
+    else:
+        assert len(want) > 0
+        tight, raw2 = ctx.lsh_candidate_pairs(sig, b, r, capacity=1)  # too small: the call is repeated with the answer
+        assert np.array_equal(tight, want) and raw2 == raw
+    # the raw count is the sum over buckets of L(L-1)/2
+    dig = LB.band_digests(sig, b, r, gpu_mode="disable")
+    expect_raw = 0
+    for j in range(b):
+        _, counts = np.unique(dig[:, j], return_counts=True)
+        expect_raw += int((counts * (counts - 1) // 2).sum())
+    assert raw == expect_raw
+    assert np.array_equal(LB.candidate_pairs(sig, b, r, gpu_mode="always"), want)
+
+
+def test_candidate_pairs_device_entry(ctx):
+    """The _dev entry point on the output of mhx_lsh_sort_bands_dev, buffers owned by the caller."""
+    from datasketch_amd import lsh_bulk as LB
+
+    rng = np.random.RandomState(77)
+    n, b, r = 4000, 20, 5
+    sig = rng.randint(0, 2**32, (n, b * r), dtype=np.uint64)
+    sig[rng.randint(0, n, 600)] = sig[rng.randint(0, n, 600)]
+    want = LB.candidate_pairs(sig, b, r, gpu_mode="disable")
+    d_sig = ctx.to_device(sig)
+    d_dig, d_rows = ctx.alloc(8 * n * b), ctx.alloc(4 * n * b)
+    cap = len(want) + 10
+    d_pairs = ctx.alloc(16 * cap)
+    _native.check(ctx.lib.mhx_lsh_sort_bands_dev(ctx.handle, d_sig.ptr, n, b * r, b, r, d_dig.ptr, d_rows.ptr))
+    found, raw = ctypes.c_int64(0), ctypes.c_int64(0)
+    _native.check(ctx.lib.mhx_lsh_candidate_pairs_dev(ctx.handle, d_dig.ptr, d_rows.ptr, n, b, d_pairs.ptr, cap,
+                                                      ctypes.byref(found), ctypes.byref(raw)))
+    ctx.synchronize()
+    assert found.value == len(want) and raw.value >= found.value
+    assert np.array_equal(d_pairs.download((cap, 2), np.int64)[: found.value], want)
+    # capacity 0 with a NULL buffer only counts
+    _native.check(ctx.lib.mhx_lsh_candidate_pairs_dev(ctx.handle, d_dig.ptr, d_rows.ptr, n, b, None, 0,
+                                                      ctypes.byref(found), None))
+    assert found.value == len(want)

@@ -194,6 +194,47 @@ def sha1(ctx):
                           "checksum": int(sig.sum() % (1 << 61))}), flush=True)
 
 
+def lsh(ctx, n):
+    """Candidate pairs by sort (rows f1/f4): a corpus with near-duplicate rows, K=128, (b, r) = (32, 4)."""
+    from datasketch_amd import lsh_bulk as LB
+
+    rng = np.random.RandomState(21)
+    k, b, r = 128, 32, 4
+    sig = rng.randint(0, 2**32, (n, k), dtype=np.uint64)
+    dup = rng.randint(0, n, n // 10)           # 10% of the rows share about half of their positions with another row
+    src = rng.randint(0, n, n // 10)
+    keep = rng.random_sample((n // 10, k)) < 0.5
+    sig[dup] = np.where(keep, sig[src], sig[dup])
+    d_sig = ctx.to_device(sig)
+    d_dig, d_rows = ctx.alloc(8 * n * b), ctx.alloc(4 * n * b)
+    cap = 4 * n
+    d_pairs = ctx.alloc(16 * cap)
+    found, raw = ctypes.c_int64(0), ctypes.c_int64(0)
+
+    def chain():
+        _native.check(ctx.lib.mhx_lsh_sort_bands_dev(ctx.handle, d_sig.ptr, n, k, b, r, d_dig.ptr, d_rows.ptr))
+        _native.check(ctx.lib.mhx_lsh_candidate_pairs_dev(ctx.handle, d_dig.ptr, d_rows.ptr, n, b, d_pairs.ptr, cap,
+                                                          ctypes.byref(found), ctypes.byref(raw)))
+
+    ms = timed(ctx, chain)
+    ms_sort = timed(ctx, lambda: _native.check(ctx.lib.mhx_lsh_sort_bands_dev(ctx.handle, d_sig.ptr, n, k, b, r, d_dig.ptr, d_rows.ptr)))
+    pairs = d_pairs.download((cap, 2), np.int64)[: found.value]
+    d_counts = ctx.alloc(4 * max(1, found.value))
+    ms_j = timed(ctx, lambda: _native.check(ctx.lib.mhx_jaccard_pairs_dev(ctx.handle, d_sig.ptr, d_sig.ptr, k, d_pairs.ptr, found.value, d_counts.ptr)))
+    report(f"lsh candidate pairs (sort {b} bands + runs + emit + sort/unique) N={n}", ms, n, "signatures", n * k * 8,
+           sort_bands_ms=round(ms_sort, 4), unique_pairs=int(found.value), raw_pairs=int(raw.value), jaccard_pairs_ms=round(ms_j, 4))
+    m = min(n, 100_000)  # the numpy bucketing on a sample, and equality of the two on it
+    t0 = time.perf_counter()
+    want = LB.candidate_pairs(sig[:m], b, r, gpu_mode="disable")
+    dt = time.perf_counter() - t0
+    got = LB.candidate_pairs(sig[:m], b, r, gpu_mode="always")
+    assert np.array_equal(got, want)
+    print(json.dumps({"name": f"candidate_pairs numpy path N={m}", "seconds": round(dt, 3), "pairs": int(len(want))}), flush=True)
+    t0 = time.perf_counter()
+    LB.candidate_pairs(sig[:m], b, r, gpu_mode="always")
+    print(json.dumps({"name": f"candidate_pairs device path host->host N={m}", "seconds": round(time.perf_counter() - t0, 4)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--weighted-rows", type=int, default=20000)
@@ -210,6 +251,8 @@ def main():
         sha1(ctx)
     if args.only in ("", "packing"):
         packing(ctx, args.sigs, 256)
+    if args.only in ("", "lsh"):
+        lsh(ctx, args.sigs)
     if args.only in ("", "weighted"):
         weighted(ctx, args.weighted_rows, 4096, 128, 1.0)
         weighted(ctx, args.weighted_rows * 4, 4096, 128, 0.01)
