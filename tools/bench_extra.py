@@ -194,6 +194,31 @@ def sha1(ctx):
                           "checksum": int(sig.sum() % (1 << 61))}), flush=True)
 
 
+def reference_gpu_benchmark(ctx):
+    """The reference's own GPU benchmark (benchmark/sketches/minhash_gpu_benchmark.py: one update_batch of
+    n byte tokens "token-i", seed 7, SHA-1 included, mean of 5 after a warm-up) -- the only numbers the
+    reference publishes for this path (CPU 163/258/485 ms, CuPy GPU 60/63/72 ms at
+    n = 50 000 and num_perm = 128/256/512, hardware unstated)."""
+    from datasketch_amd import MinHash
+
+    for n in (1000, 10_000, 50_000):
+        data = [f"token-{i}".encode("utf-8") for i in range(n)]
+        for k in (128, 256, 512):
+            row = {"name": f"update_batch of {n} byte tokens, num_perm={k} (reference GPU benchmark shape)"}
+            digests = {}
+            for mode in ("always", "disable"):
+                times = []
+                for rep in range(6):
+                    m = MinHash(num_perm=k, seed=7, gpu_mode=mode)
+                    t0 = time.perf_counter()
+                    m.update_batch(data)
+                    times.append((time.perf_counter() - t0) * 1e3)
+                row[f"ms_gpu_mode_{mode}"] = round(float(np.mean(times[1:])), 3)
+                digests[mode] = m.hashvalues
+            assert np.array_equal(digests["always"], digests["disable"])
+            print(json.dumps(row), flush=True)
+
+
 def lsh(ctx, n):
     """Candidate pairs by sort (rows f1/f4): a corpus with near-duplicate rows, K=128, (b, r) = (32, 4)."""
     from datasketch_amd import lsh_bulk as LB
@@ -251,6 +276,8 @@ def main():
         sha1(ctx)
     if args.only in ("", "packing"):
         packing(ctx, args.sigs, 256)
+    if args.only in ("", "refbench"):
+        reference_gpu_benchmark(ctx)
     if args.only in ("", "lsh"):
         lsh(ctx, args.sigs)
     if args.only in ("", "weighted"):
