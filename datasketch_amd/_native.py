@@ -85,6 +85,12 @@ _RESTYPE = {"mhx_last_error": ctypes.c_char_p, "mhx_version": ctypes.c_char_p}
 EXPORTED_SYMBOLS = sorted(list(_PROTOTYPES) + list(_RESTYPE))
 
 
+try:  # CPython helper (csrc/pack_module.c): ~10 ns per token instead of ~180 in the interpreter
+    from datasketch_amd import _mhxpack
+except ImportError:  # not built: the pure-Python packer below does the same job
+    _mhxpack = None
+
+
 class MhxError(RuntimeError):
     """A libmhx call failed (HIP / RCCL / allocation)."""
 
@@ -352,7 +358,10 @@ class Context:
     @staticmethod
     def pack_tokens(tokens) -> tuple:
         """Byte tokens (bytes / bytearray / memoryview) -> (packed uint8 array, int64 offsets[n+1]).
-        ``b"".join`` raises the TypeError hashlib would raise for a str token."""
+        A str token raises the TypeError hashlib would raise for it."""
+        if _mhxpack is not None:
+            data, offs = _mhxpack.pack_tokens(tokens)
+            return np.frombuffer(data, dtype=np.uint8), np.frombuffer(offs, dtype=np.int64)
         tokens = tokens if isinstance(tokens, (list, tuple)) else list(tokens)
         lens = np.fromiter(map(len, tokens), dtype=np.int64, count=len(tokens))
         offsets = np.zeros(len(tokens) + 1, dtype=np.int64)
@@ -361,6 +370,18 @@ class Context:
         if buf.size != int(offsets[-1]):
             raise TypeError("tokens must be bytes-like objects of single bytes")
         return buf, offsets
+
+    @staticmethod
+    def pack_sets(sets) -> tuple:
+        """Sets of byte tokens -> (packed uint8 array, int64 byte offsets[T+1], int64 set offsets[N+1])."""
+        if _mhxpack is not None:
+            data, offs, set_offs = _mhxpack.pack_sets(sets)
+            return np.frombuffer(data, dtype=np.uint8), np.frombuffer(offs, dtype=np.int64), np.frombuffer(set_offs, dtype=np.int64)
+        sets = [s if isinstance(s, (list, tuple)) else list(s) for s in sets]
+        set_offsets = np.zeros(len(sets) + 1, dtype=np.int64)
+        np.cumsum(np.fromiter(map(len, sets), dtype=np.int64, count=len(sets)), out=set_offsets[1:])
+        buf, byte_offsets = Context.pack_tokens([t for s in sets for t in s])
+        return buf, byte_offsets, set_offsets
 
     def sha1_tokens(self, buf: np.ndarray, byte_offsets: np.ndarray, bits: int = 32) -> np.ndarray:
         """sha1_hash32 / sha1_hash64 of every token of a packed byte corpus (host in, host out)."""

@@ -21,3 +21,7 @@ for p in "${pids[@]:-}"; do [[ -n "${p}" ]] && wait "${p}"; done
 "${HIPCC}" --offload-arch=gfx950 -shared -fPIC -o "${OUT}" "${OBJ}"/mhx_api.o "${OBJ}"/minhash_kernels.o \
   "${OBJ}"/weighted_kernels.o "${OBJ}"/pack_kernels.o "${OBJ}"/sha1_kernels.o "${OBJ}"/lsh_kernels.o "${OBJ}"/comm.o -ldl
 echo "built ${OUT}"
+# CPython helper that packs Python byte tokens (host glue, plain C)
+PYINC="$(python3 -c 'import sysconfig; print(sysconfig.get_paths()["include"])')"
+gcc -O2 -shared -fPIC -Wall -I"${PYINC}" "${HERE}/pack_module.c" -o "${HERE}/../_mhxpack.so"
+echo "built ${HERE}/../_mhxpack.so"

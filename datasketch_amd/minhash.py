@@ -165,7 +165,11 @@ class MinHash:
             if not b:
                 return
             buf, offs = _native.Context.pack_tokens(b)
-            hv_list = _native.context().sha1_tokens(buf, offs, 32 if self.hashfunc is sha1_hash32 else 64)
+            if self.hashfunc is sha1_hash32:  # one call: bytes up, SHA-1 + permutations + min on the device, K values back
+                one_set = np.array([0, len(b)], dtype=np.int64)
+                self.hashvalues = _native.context().minhash_bulk_bytes(self.permutations, buf, offs, one_set, self.hashvalues)[0]
+                return
+            hv_list = _native.context().sha1_tokens(buf, offs, 64)
         else:
             hv_list = [self.hashfunc(_b) for _b in b]
             if not hv_list:  # empty batch is a no-op (minhash.py:265-266)
@@ -312,9 +316,7 @@ class MinHash:
         # default hashfunc + device: pack the byte tokens once, SHA-1 and MinHash both on the device
         # (repeated tokens are left in: dropping them here costs more host time per set -- a dict per set --
         # than the kernel's slow path for such sets costs on the device)
-        set_offsets = np.zeros(len(sets) + 1, dtype=np.int64)
-        np.cumsum(np.fromiter(map(len, sets), dtype=np.int64, count=len(sets)), out=set_offsets[1:])
-        buf, byte_offsets = _native.Context.pack_tokens([t for s in sets for t in s])
+        buf, byte_offsets, set_offsets = _native.Context.pack_sets(sets)
         return _native.context().minhash_bulk_bytes(self.permutations, buf, byte_offsets, set_offsets, init)
 
     def _signatures_csr(self, hv, offsets, fixed_len, n_sets, init) -> np.ndarray:

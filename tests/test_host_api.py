@@ -396,6 +396,34 @@ def test_pack_tokens_and_sha1_hash_many_on_the_host():
         sha1_hash_many(tokens, 16, gpu_mode="disable")
 
 
+@pytest.mark.parametrize("helper", ["c", "python"])
+def test_pack_sets_c_helper_and_python_packer_agree(helper, monkeypatch):
+    """csrc/pack_module.c and the pure-Python packer: same arrays, same TypeErrors (those hashlib raises)."""
+    from datasketch_amd import _native
+
+    if helper == "c" and _native._mhxpack is None:
+        pytest.skip("_mhxpack.so not built")
+    if helper == "python":
+        monkeypatch.setattr(_native, "_mhxpack", None)
+    rng = np.random.RandomState(3)
+    sets = [[b"w%d" % v for v in rng.randint(0, 1000, rng.randint(0, 9))] for _ in range(200)]
+    sets += [[], {b"solo"}, (bytearray(b"bc"), memoryview(b"def"), b""), iter([b"g", b"\x00\xff"])]
+    sets = [list(s) if not isinstance(s, (list, tuple, set)) else s for s in sets]
+    buf, byte_offs, set_offs = _native.Context.pack_sets(sets)
+    flat = [bytes(t) for s in sets for t in s]
+    assert buf.dtype == np.uint8 and byte_offs.dtype == np.int64 and set_offs.dtype == np.int64
+    assert bytes(buf) == b"".join(flat)
+    assert byte_offs.tolist() == [0] + np.cumsum([len(t) for t in flat]).tolist()
+    assert set_offs.tolist() == [0] + np.cumsum([len(s) for s in sets]).tolist()
+    b2, o2 = _native.Context.pack_tokens(flat)
+    assert bytes(b2) == bytes(buf) and o2.tolist() == byte_offs.tolist()
+    empty = _native.Context.pack_sets([])
+    assert empty[0].size == 0 and empty[1].tolist() == [0] and empty[2].tolist() == [0]
+    for bad in ([["text"]], [[b"ok", 7]], [[b"ok"], 5]):
+        with pytest.raises(TypeError):
+            _native.Context.pack_sets(bad)
+
+
 def test_bulk_with_repeated_tokens_equals_update_batch():
     """bulk() may drop repeated tokens of a set before hashing them: the signatures must not change."""
     rng = np.random.RandomState(3)
