@@ -764,9 +764,21 @@ __device__ __forceinline__ void load_perms(const BulkArgs &args, int kbase, int 
 //   MODE_FULL   the full evaluation (fast fold + exact redo, or the exact fold with path 1) for the
 //               listed sets -- or for every set when the sieve is switched off.
 enum { MODE_SIEVE = 0, MODE_FULL = 1 };
+enum { SHAPE_GENERAL = 0, SHAPE_PLAIN = 1, SHAPE_PLAIN_FIXED = 2 };
 
-template <int P, typename TokT, typename OutT, int MODE>
-__global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args) {
+template <int P, typename TokT, typename OutT, int MODE, int SHAPE>
+__global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_in) {
+    // SHAPE_PLAIN: no initial state, no counters, no aliasing; SHAPE_PLAIN_FIXED: and fixed-length sets.  The
+    // fields become compile-time constants, so their SGPRs (the kernel spills 49 of them, 32 when plain)
+    // and address arithmetic leave the per-set path: 2 % of the headline launch.
+    BulkArgs args = args_in;
+    if (SHAPE != SHAPE_GENERAL) {
+        args.init = nullptr;
+        args.init_stride = 0;
+        args.stats = nullptr;
+        args.alias_mask = -1;
+    }
+    if (SHAPE == SHAPE_PLAIN_FIXED) args.offsets = nullptr;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_block = blockDim.x >> 6;
@@ -1031,14 +1043,20 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_
         if (args.path == 0) {
             // sieve launch (writes a flag per set), then the full evaluation of the flagged sets (usually a
             // handful: that launch reads n_sets bytes and returns)
-            hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE>), grid, dim3(256), 0, ctx->stream, args);
+            const bool plain = !args.init && !args.stats && args.alias_mask < 0;
+            if (plain && !args.offsets)
+                hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN_FIXED>), grid, dim3(256), 0, ctx->stream, args);
+            else if (plain)
+                hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN>), grid, dim3(256), 0, ctx->stream, args);
+            else
+                hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_GENERAL>), grid, dim3(256), 0, ctx->stream, args);
             const int64_t flag_groups = (args.n_sets + kWave - 1) / kWave;  // a workgroup scans 64 flags at a time
             dim3 full_grid((unsigned)std::max<int64_t>(1, std::min(flag_groups, max_blocks)), 1u);
-            hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_FULL>), full_grid, dim3(256), 0, ctx->stream, args);
+            hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_FULL, SHAPE_GENERAL>), full_grid, dim3(256), 0, ctx->stream, args);
         } else {
             BulkArgs all = args;
             all.redo = nullptr;  // every set
-            hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_FULL>), grid, dim3(256), 0, ctx->stream, all);
+            hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_FULL, SHAPE_GENERAL>), grid, dim3(256), 0, ctx->stream, all);
         }
     } else {
         const int64_t total_out = args.n_sets * (int64_t)args.num_perm;
