@@ -416,41 +416,42 @@ __device__ __forceinline__ bool sieve_range(const TokT MHX_CONST_AS *hv, const T
         Two rows[P];
         // Scalar loads return out of order, so the only wait is lgkmcnt(0): wait for the current
         // chunk (a use BEFORE the next prefetch is issued), THEN issue the prefetch, then hash.
-        for (int r = 0; r < rb; r += 2) {
-            uint32_t row0[P], row1[P];
-            a.arrived();
-            b.load(chunk_ptr(ci + 1));
-            __builtin_amdgcn_sched_barrier(0);
-            sieve_chunk<P, TokT, true>(a, sp, row0);
-            b.arrived();
-            a.load(chunk_ptr(ci + 2));
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (CPR == 2) {
-                sieve_chunk<P, TokT, false>(b, sp, row0);  // second half of row r
-            } else {
-                sieve_chunk<P, TokT, true>(b, sp, row1);   // row r + 1 (uint32 tokens: a row is one chunk)
-            }
-            ci += 2;
-            const bool second = r + 1 < rb;  // wave-uniform
-            if constexpr (CPR == 2) {
-                if (second) {
-                    a.arrived();
-                    b.load(chunk_ptr(ci + 1));
-                    __builtin_amdgcn_sched_barrier(0);
-                    sieve_chunk<P, TokT, true>(a, sp, row1);
-                    b.arrived();
-                    a.load(chunk_ptr(ci + 2));
-                    __builtin_amdgcn_sched_barrier(0);
-                    sieve_chunk<P, TokT, false>(b, sp, row1);
-                    ci += 2;
-                }
-            } else {
-                if (!second) ci -= 1;  // odd row count: chunk `b` was the clamped prefetch, not a row
-            }
+        if constexpr (CPR == 2) {
+            // uint64 tokens: a row is the chunk pair (a, b); one row per iteration, nothing conditional
+            for (int r = 0; r < rb; ++r) {
+                uint32_t row0[P];
+                a.arrived();
+                b.load(chunk_ptr(ci + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                sieve_chunk<P, TokT, true>(a, sp, row0);
+                b.arrived();
+                a.load(chunk_ptr(ci + 2));
+                __builtin_amdgcn_sched_barrier(0);
+                sieve_chunk<P, TokT, false>(b, sp, row0);
+                ci += 2;
 #pragma unroll
-            for (int q = 0; q < P; ++q) {
-                rows[q].add(tag16(row0[q], (uint32_t)r));
-                if (second) rows[q].add(tag16(row1[q], (uint32_t)(r + 1)));
+                for (int q = 0; q < P; ++q) rows[q].add(tag16(row0[q], (uint32_t)r));
+            }
+        } else {
+            // uint32 tokens: a row is one chunk; two rows per iteration keep the (a, b) ping-pong
+            for (int r = 0; r < rb; r += 2) {
+                uint32_t row0[P], row1[P];
+                a.arrived();
+                b.load(chunk_ptr(ci + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                sieve_chunk<P, TokT, true>(a, sp, row0);
+                b.arrived();
+                a.load(chunk_ptr(ci + 2));
+                __builtin_amdgcn_sched_barrier(0);
+                sieve_chunk<P, TokT, true>(b, sp, row1);  // row r + 1
+                ci += 2;
+                const bool second = r + 1 < rb;  // wave-uniform
+                if (!second) ci -= 1;  // odd row count: chunk `b` was the clamped prefetch, not a row
+#pragma unroll
+                for (int q = 0; q < P; ++q) {
+                    rows[q].add(tag16(row0[q], (uint32_t)r));
+                    if (second) rows[q].add(tag16(row1[q], (uint32_t)(r + 1)));
+                }
             }
         }
         // block complete: tile -> LDS (wave-private, so program order is enough: no barrier), then
