@@ -161,7 +161,9 @@ def main():
         del sig
 
     out = {
-        "metric": "MinHash signatures/sec (1M sets x 256 tokens, num_perm=128)",
+        # BASELINE.json's metric at the default shape; any other shape is named as what it is
+        "metric": "MinHash signatures/sec (1M sets x 256 tokens, num_perm=128)" if (n, t, k) == (1_000_000, 256, 128)
+        else f"MinHash signatures/sec ({n} sets x {t} tokens, num_perm={k})",
         "value": world * n * args.steps / elapsed,
         "unit": "signatures/s",
         "n_gpus": world,

@@ -1033,7 +1033,8 @@ __global__ void minhash_merge_kernel(const uint64_t *__restrict__ x, const uint6
         out[count - 1] = x[count - 1] < y[count - 1] ? x[count - 1] : y[count - 1];
 }
 
-template <int P, typename TokT, typename OutT>
+// P permutations per lane in the sieve (and split) launch, PF in the full launch
+template <int P, typename TokT, typename OutT, int PF = P>
 int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_t total_tokens, bool split) {
     const int kchunks = (args.num_perm + kWave * P - 1) / (kWave * P);
     const int blocks_per_cu = ctx->opt_blocks_per_cu > 0 ? (int)ctx->opt_blocks_per_cu : 64;  // >> residency: dispatcher evens out the tail (16: 2.40 ms, 32: 2.29, 64: 2.23)
@@ -1053,11 +1054,11 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_
                 hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_GENERAL>), grid, dim3(256), 0, ctx->stream, args);
             const int64_t flag_groups = (args.n_sets + kWave - 1) / kWave;  // a workgroup scans 64 flags at a time
             dim3 full_grid((unsigned)std::max<int64_t>(1, std::min(flag_groups, max_blocks)), 1u);
-            hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_FULL, SHAPE_GENERAL>), full_grid, dim3(256), 0, ctx->stream, args);
+            hipLaunchKernelGGL((minhash_bulk_kernel<PF, TokT, OutT, MODE_FULL, SHAPE_GENERAL>), full_grid, dim3(256), 0, ctx->stream, args);
         } else {
             BulkArgs all = args;
             all.redo = nullptr;  // every set
-            hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_FULL, SHAPE_GENERAL>), grid, dim3(256), 0, ctx->stream, all);
+            hipLaunchKernelGGL((minhash_bulk_kernel<PF, TokT, OutT, MODE_FULL, SHAPE_GENERAL>), grid, dim3(256), 0, ctx->stream, all);
         }
     } else {
         const int64_t total_out = args.n_sets * (int64_t)args.num_perm;
@@ -1081,8 +1082,13 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_
 
 template <typename TokT, typename OutT>
 int launch_p(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_t total_tokens, bool split) {
-    // P permutations per lane: 1 for K <= 64, else 2 (K > 128 walks ceil(K/128) chunks per set)
+    // P permutations per lane: 1 for K <= 64, 2 up to 128; beyond that the sieve launch takes 4 (a set's
+    // tokens are walked ceil(K/256) times instead of ceil(K/128): 4.00 -> 3.90 ms per 1M sets at K = 256,
+    // 122 VGPRs) while the full launch stays at 2 (with 4 it would need 220 VGPRs)
     if (args.num_perm <= 64) return launch_typed<1, TokT, OutT>(ctx, args, first_token, total_tokens, split);
+    const int slots4 = (args.num_perm + 255) / 256 * 256, slots2 = (args.num_perm + 127) / 128 * 128;  // lanes x P x passes
+    if (args.num_perm > 128 && !split && slots4 <= slots2)
+        return launch_typed<4, TokT, OutT, 2>(ctx, args, first_token, total_tokens, split);
     return launch_typed<2, TokT, OutT>(ctx, args, first_token, total_tokens, split);
 }
 
