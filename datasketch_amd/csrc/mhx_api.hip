@@ -5,6 +5,7 @@
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -361,6 +362,8 @@ int mhx_minhash_bulk_dev(mhx_perm *perm, const void *d_hv, int hv_dtype, const i
 extern "C++" {
 namespace {
 
+constexpr int kNoSecondThread = -1000;  // internal: bulk_pipelined could not start its download thread
+
 // One piece of a pipelined host call: sets [s0, s1) whose tokens are hv[t0, t1).
 struct Piece {
     int64_t s0, s1, t0, t1;
@@ -428,7 +431,7 @@ int bulk_pipelined(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets, i
     size_t recorded = 0;
     bool stop = false;
     hipError_t down_err = hipSuccess;
-    std::thread downloader([&]() {
+    auto download = [&]() {
         hipError_t e = hipSetDevice(ctx->device);
         for (size_t i = 0; i < n_pieces && e == hipSuccess; ++i) {
             {
@@ -444,7 +447,14 @@ int bulk_pipelined(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets, i
         }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_out);
         down_err = e;
-    });
+    };
+    std::thread downloader;
+    try {
+        downloader = std::thread(download);
+    } catch (const std::system_error &) {  // no thread to be had: the caller runs the call in one piece
+        destroy_events();
+        return kNoSecondThread;
+    }
     auto finish = [&](int rc) -> int {
         {
             std::lock_guard<std::mutex> lock(mu);
@@ -535,8 +545,9 @@ int mhx_minhash_bulk(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets,
             if (off_bytes) MHX_HIP_CHECK(hipMemcpyAsync(d_off, offsets, off_bytes, hipMemcpyHostToDevice, ctx->stream));
             if (init && !init_stride)
                 MHX_HIP_CHECK(hipMemcpyAsync(d_init, init, init_bytes, hipMemcpyHostToDevice, ctx->stream));
-            return bulk_pipelined(perm, hv, offsets, fixed_len, n_sets, init, init_stride, out, d_hv, d_off, d_init,
-                                  d_out, pieces);
+            const int rc = bulk_pipelined(perm, hv, offsets, fixed_len, n_sets, init, init_stride, out, d_hv, d_off, d_init,
+                                          d_out, pieces);
+            if (rc != kNoSecondThread) return rc;
         }
     }
     if (hv_bytes) MHX_HIP_CHECK(hipMemcpyAsync(d_hv, hv, hv_bytes, hipMemcpyHostToDevice, ctx->stream));

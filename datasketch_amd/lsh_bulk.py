@@ -14,6 +14,10 @@ Python round trips:
   least one band (what ``query`` would find), without probing dictionaries -- on the device the
   whole chain (digests, sorts, run detection, pair emission, sort + unique) is one call;
 * :func:`jaccard_pairs` -- ``MinHash.jaccard`` for a list of pairs (ref: datasketch/minhash.py:299-324).
+
+Every helper except :func:`jaccard_pairs` also takes a WeightedMinHash matrix ``[N, S, 2]`` int64
+(``WeightedMinHashGenerator.minhash_many_arrays``): its band keys are the reference's too
+(16*r bytes per band); :func:`weighted_jaccard_pairs` is ``WeightedMinHash.jaccard`` for pairs.
 """
 from __future__ import annotations
 
@@ -46,10 +50,22 @@ def _use_gpu(gpu_mode: str) -> bool:
 
 
 def _matrix(signatures) -> np.ndarray:
-    sig = np.ascontiguousarray(signatures, dtype=np.uint64)
+    """``[N, K]`` uint64 view of a signature matrix.  A WeightedMinHash matrix ``[N, S, 2]`` int64 (rows of
+    ``(k, t)`` pairs, ref: weighted_minhash.py:11-30) is viewed as ``[N, 2S]`` words: the reference's band
+    key of ``hashvalues[i*r:(i+1)*r]`` is then the key of ``2r`` consecutive words (see :func:`_words`)."""
+    sig = np.asarray(signatures)
+    if sig.ndim == 3 and sig.shape[2] == 2:
+        sig = np.ascontiguousarray(sig, dtype=np.int64).view(np.uint64).reshape(sig.shape[0], 2 * sig.shape[1])
+        return sig
+    sig = np.ascontiguousarray(sig, dtype=np.uint64)
     if sig.ndim != 2:
-        raise ValueError("signatures must be an [N, K] matrix")
+        raise ValueError("signatures must be an [N, K] matrix (or [N, S, 2] for WeightedMinHash)")
     return sig
+
+
+def _words(signatures) -> int:
+    """uint64 words per hash value: 2 for a WeightedMinHash matrix ``[N, S, 2]``, else 1."""
+    return 2 if np.ndim(signatures) == 3 else 1
 
 
 def _check_params(k: int, b: int, r: int) -> None:
@@ -61,7 +77,7 @@ def band_keys(signatures, b: int, r: int, gpu_mode: str = "detect") -> np.ndarra
     """``[N, b]`` array of ``numpy.void`` items of ``8*r`` bytes: item ``[i, j]`` holds exactly
     ``MinHashLSH._H(hashvalues[j*r:(j+1)*r])`` of row ``i`` (big-endian words, ref: lsh.py:537-538).
     ``.tolist()`` gives nested lists of ``bytes``; ``bytes(out[i, j])`` one key."""
-    sig = _matrix(signatures)
+    sig, r = _matrix(signatures), r * _words(signatures)
     n, k = sig.shape
     _check_params(k, b, r)
     if _use_gpu(gpu_mode):
@@ -74,7 +90,7 @@ def band_keys(signatures, b: int, r: int, gpu_mode: str = "detect") -> np.ndarra
 
 def band_digests(signatures, b: int, r: int, gpu_mode: str = "detect") -> np.ndarray:
     """``[N, b]`` uint64: FNV-1a-64 of every band key (equal digests <=> same bucket)."""
-    sig = _matrix(signatures)
+    sig, r = _matrix(signatures), r * _words(signatures)
     n, k = sig.shape
     _check_params(k, b, r)
     if _use_gpu(gpu_mode):
@@ -94,10 +110,10 @@ def insert_bulk(lsh, keys: Iterable[Hashable], signatures, check_duplication: bo
     hashtables, prepickle, hashfunc``).  Validation, key pickling, duplicate check and the storage
     calls are those of ref: datasketch/lsh.py:326-347; only the ``b`` band keys per signature come
     from one pass over the matrix instead of ``b`` numpy slices per object."""
-    sig = _matrix(signatures)
+    sig, words = _matrix(signatures), _words(signatures)
     n, k = sig.shape
-    if k != lsh.h:
-        raise ValueError("Expecting minhash with length %d, got %d" % (lsh.h, k))
+    if k != lsh.h * words:
+        raise ValueError("Expecting minhash with length %d, got %d" % (lsh.h, k // words))
     keys = list(keys)
     if len(keys) != n:
         raise ValueError("keys and signatures must have the same length")
@@ -116,7 +132,7 @@ def insert_bulk(lsh, keys: Iterable[Hashable], signatures, check_duplication: bo
             if key in seen or key in lsh.keys:
                 raise ValueError("The given key already exists")
             seen.add(key)
-    columns = band_keys(sig, lsh.b, lsh.r, gpu_mode=gpu_mode).T.tolist()  # b lists of N bytes objects
+    columns = band_keys(sig, lsh.b, lsh.r * words, gpu_mode=gpu_mode).T.tolist()  # b lists of N bytes objects
     hashfunc = getattr(lsh, "hashfunc", None)
     if hashfunc is not None:
         columns = [[hashfunc(h) for h in col] for col in columns]
@@ -131,7 +147,7 @@ def sorted_bands(signatures, b: int, r: int, gpu_mode: str = "detect"):
     """``(digests [b, N] uint64 ascending per band, rows [b, N] uint32 in the same order)``: every LSH
     bucket of band ``j`` is a run of equal values in ``digests[j]``.  On the device this is one digest
     pass plus ``b`` radix sorts (mhx_lsh_sort_bands); the numpy fallback is ``argsort`` per band."""
-    sig = _matrix(signatures)
+    sig, r = _matrix(signatures), r * _words(signatures)
     n, k = sig.shape
     _check_params(k, b, r)
     if _use_gpu(gpu_mode) and n:
@@ -145,7 +161,7 @@ def candidate_pairs(signatures, b: int, r: int, gpu_mode: str = "detect") -> np.
     """``[M, 2]`` int64, sorted, unique pairs ``i < j`` of rows that share the key of at least one band
     -- the pairs ``MinHashLSH(params=(b, r))`` would report for each other.  On the device: digests,
     per-band sort, run detection, pair emission, sort + unique in one call (mhx_lsh_candidate_pairs)."""
-    sig = _matrix(signatures)
+    sig, r = _matrix(signatures), r * _words(signatures)
     _check_params(sig.shape[1], b, r)
     if _use_gpu(gpu_mode) and sig.shape[0]:
         return _native.context().lsh_candidate_pairs(sig, b, r)[0]
@@ -171,7 +187,10 @@ def candidate_pairs(signatures, b: int, r: int, gpu_mode: str = "detect") -> np.
 
 
 def jaccard_pairs(signatures, pairs, gpu_mode: str = "detect") -> np.ndarray:
-    """``MinHash.jaccard`` of rows ``pairs[:, 0]`` and ``pairs[:, 1]``: float64, equal positions / K."""
+    """``MinHash.jaccard`` of rows ``pairs[:, 0]`` and ``pairs[:, 1]``: float64, equal positions / K.
+    (For a WeightedMinHash matrix use :func:`weighted_jaccard_pairs`: a position is a ``(k, t)`` pair.)"""
+    if np.ndim(signatures) == 3:
+        raise ValueError("jaccard_pairs takes an [N, K] matrix; use weighted_jaccard_pairs for [N, S, 2]")
     sig = _matrix(signatures)
     pairs = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
     if pairs.size and (pairs.min() < 0 or pairs.max() >= sig.shape[0]):
@@ -181,3 +200,16 @@ def jaccard_pairs(signatures, pairs, gpu_mode: str = "detect") -> np.ndarray:
     else:
         counts = np.count_nonzero(sig[pairs[:, 0]] == sig[pairs[:, 1]], axis=1)
     return counts.astype(np.float64) / float(sig.shape[1])
+
+
+def weighted_jaccard_pairs(signatures, pairs) -> np.ndarray:
+    """``WeightedMinHash.jaccard`` (ref: weighted_minhash.py:41-60) of rows ``pairs[:, 0]`` and ``pairs[:, 1]`` of an
+    ``[N, S, 2]`` matrix: the fraction of samples whose ``(k, t)`` pairs are equal."""
+    sig = np.asarray(signatures, dtype=np.int64)
+    if sig.ndim != 3 or sig.shape[2] != 2:
+        raise ValueError("signatures must be [N, S, 2]")
+    pairs = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+    if pairs.size and (pairs.min() < 0 or pairs.max() >= sig.shape[0]):
+        raise ValueError("pair index out of range")
+    same = np.all(sig[pairs[:, 0]] == sig[pairs[:, 1]], axis=2)
+    return np.count_nonzero(same, axis=1).astype(np.float64) / float(sig.shape[1])

@@ -854,6 +854,23 @@ def test_candidate_pairs_on_device(ctx, n, b, r, clusters):
     assert np.array_equal(LB.candidate_pairs(sig, b, r, gpu_mode="always"), want)
 
 
+def test_weighted_signatures_through_the_lsh_helpers_on_device(ctx):
+    """[N, S, 2] int64 WeightedMinHash matrices are [N, 2S] words to the band kernels (keys of 2r words)."""
+    from datasketch_amd import lsh_bulk as LB
+
+    rng = np.random.RandomState(8)
+    g = WeightedMinHashGenerator(64, 32, seed=5, gpu_mode="always")
+    x = rng.uniform(0, 9, (800, 64)).astype(np.float32)
+    x[rng.randint(0, 800, 200)] = x[rng.randint(0, 800, 200)]
+    sig, nonempty = g.minhash_many_arrays(x)
+    assert sig.shape == (800, 32, 2) and nonempty.all()
+    for b, r in ((8, 4), (32, 1), (3, 7)):
+        assert LB.band_keys(sig, b, r, gpu_mode="always").tobytes() == LB.band_keys(sig, b, r, gpu_mode="disable").tobytes()
+        assert np.array_equal(LB.band_digests(sig, b, r, gpu_mode="always"), LB.band_digests(sig, b, r, gpu_mode="disable"))
+        dev, host = LB.candidate_pairs(sig, b, r, gpu_mode="always"), LB.candidate_pairs(sig, b, r, gpu_mode="disable")
+        assert np.array_equal(dev, host) and len(host) > 50
+
+
 def test_candidate_pairs_device_entry(ctx):
     """The _dev entry point on the output of mhx_lsh_sort_bands_dev, buffers owned by the caller."""
     from datasketch_amd import lsh_bulk as LB

@@ -92,3 +92,56 @@ def test_insert_bulk_leaves_the_reference_index_in_the_same_state(prepickle, use
     if use_hashfunc:  # the digests are what the index stores
         dig = LB.band_digests(sig, one.b, one.r, gpu_mode="disable")
         assert set(one.hashtables[0]._dict) == set(int(x) for x in dig[:, 0])
+
+
+def _weighted_signatures(n=60, dim=32, s=16):
+    from datasketch_amd import WeightedMinHashGenerator
+
+    g = WeightedMinHashGenerator(dim, s, seed=3, gpu_mode="disable")
+    x = np.random.RandomState(0).uniform(0, 5, (n, dim)).astype(np.float32)
+    x[7] = x[3]
+    x[11, :4] += 1.0
+    wm = g.minhash_many(x)
+    return wm, np.stack([w.hashvalues for w in wm])
+
+
+def test_weighted_signatures_go_through_the_same_helpers():
+    """An [N, S, 2] int64 WeightedMinHash matrix: a band key is the 16*r bytes the reference builds from
+    hashvalues[i*r:(i+1)*r] (lsh.py:537-538 on an [r, 2] int64 slice)."""
+    wm, sig = _weighted_signatures()
+    assert sig.shape == (60, 16, 2) and sig.dtype == np.int64
+    keys = LB.band_keys(sig, 4, 4, gpu_mode="disable")
+    for i in (0, 5, 59):
+        for j in range(4):
+            assert bytes(keys[i, j]) == bytes(sig[i, j * 4 : (j + 1) * 4].byteswap().data)
+    dig = LB.band_digests(sig, 4, 4, gpu_mode="disable")
+    assert int(dig[5, 2]) == LB.fnv1a_64(bytes(keys[5, 2]))
+    pairs = LB.candidate_pairs(sig, 4, 4, gpu_mode="disable")
+    assert [3, 7] in pairs.tolist()
+    jac = LB.weighted_jaccard_pairs(sig, pairs)
+    for (i, j), est in zip(pairs.tolist(), jac):
+        assert est == wm[i].jaccard(wm[j])
+    with pytest.raises(ValueError):
+        LB.jaccard_pairs(sig, pairs, gpu_mode="disable")
+    with pytest.raises(ValueError):
+        LB.band_keys(sig, 5, 4, gpu_mode="disable")  # 5 * 4 > 16 samples
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference repository not mounted")
+def test_insert_bulk_of_weighted_signatures_matches_the_reference_index():
+    sys.path.insert(0, REFERENCE)
+    try:
+        import datasketch as ref
+    finally:
+        sys.path.remove(REFERENCE)
+    wm, sig = _weighted_signatures()
+    one, bulk = ref.MinHashLSH(threshold=0.5, num_perm=16), ref.MinHashLSH(threshold=0.5, num_perm=16)
+    for i, w in enumerate(wm):
+        one.insert(i, ref.WeightedMinHash(3, w.hashvalues))
+    LB.insert_bulk(bulk, list(range(len(wm))), sig, gpu_mode="disable")
+    for t1, t2 in zip(one.hashtables, bulk.hashtables):
+        assert dict(t1._dict) == dict(t2._dict)
+    probe = ref.WeightedMinHash(3, wm[3].hashvalues)
+    assert sorted(one.query(probe)) == sorted(bulk.query(probe)) and 7 in bulk.query(probe)
+    with pytest.raises(ValueError):
+        LB.insert_bulk(bulk, ["x"], sig[:1, :8], gpu_mode="disable")  # wrong sample count
