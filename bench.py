@@ -65,6 +65,8 @@ def main():
     from datasketch_amd import _native
     from datasketch_amd.minhash import MinHash
 
+    if args.allgather:  # RCCL must enter the process before torch's own ROCm runtime does (mhx_ctx_create loads it)
+        os.environ.setdefault("MHX_PRELOAD_RCCL", "1")
     ctx = _native.Context(local_rank)
     for kv in args.opt:
         key, _, val = kv.partition("=")

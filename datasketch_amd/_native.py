@@ -75,6 +75,7 @@ _PROTOTYPES = {
     "mhx_jaccard_pairs": [_vp, _vp, _i64, ctypes.c_int32, _vp, _i64, _vp],
     "mhx_lean_serialize_dev": [_vp, _vp, _i64, _i32, _i64, _vp],
     "mhx_lean_serialize": [_vp, _vp, _i64, _i32, _i64, _vp],
+    "mhx_comm_preload": [],
     "mhx_comm_unique_id": [_vp],
     "mhx_comm_create": [_vp, _vp, _int, _int, ctypes.POINTER(_vp)],
     "mhx_comm_destroy": [_vp],

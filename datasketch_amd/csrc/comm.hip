@@ -80,6 +80,8 @@ static_assert(sizeof(ncclUniqueId) == MHX_COMM_ID_BYTES, "RCCL unique id size ch
 
 extern "C" {
 
+int mhx_comm_preload(void) { return rccl_ready(); }
+
 int mhx_comm_unique_id(uint8_t id[MHX_COMM_ID_BYTES]) {
     if (!id) return mhx::fail(MHX_ERR_INVALID, "id is NULL");
     if (int rc = rccl_ready()) return rc;

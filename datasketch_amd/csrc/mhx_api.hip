@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <system_error>
@@ -142,7 +143,13 @@ int mhx_ctx_create(int device, mhx_ctx **out) {
         delete ctx;
         return fail(MHX_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
-    mhx::preload_rccl();
+    // RCCL has to be loaded before another HIP runtime enters the process (a PyTorch-ROCm wheel brings its
+    // own); loading it costs ~1 s, so it is done up front only for multi-process jobs (WORLD_SIZE > 1, as
+    // torchrun sets it) or on request (MHX_PRELOAD_RCCL=1), otherwise at the first mhx_comm_* call
+    {
+        const char *force = getenv("MHX_PRELOAD_RCCL"), *world = getenv("WORLD_SIZE");
+        if (force ? atoi(force) != 0 : (world && atoi(world) > 1)) mhx::preload_rccl();
+    }
     *out = ctx;
     return MHX_OK;
 }

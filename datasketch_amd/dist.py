@@ -15,7 +15,13 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
+
+# A program that imports this module means to use the RCCL path: libmhx then loads RCCL when the context
+# is created (before a PyTorch-ROCm wheel brings its own ROCm runtime into the process) instead of lazily.
+os.environ.setdefault("MHX_PRELOAD_RCCL", "1")
 
 
 def shard_rows(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -82,6 +88,9 @@ _COMM_CACHE = {}
 def communicator(ctx, group=None):
     """The RCCL communicator of this rank's context for ``group`` (created once: rank 0 makes the
     id, a gloo broadcast hands it out)."""
+    from datasketch_amd import _native
+
+    _native.check(_native.load().mhx_comm_preload())  # RCCL before torch's own ROCm runtime enters the process
     import torch.distributed as dist
 
     key = (id(ctx), id(group))

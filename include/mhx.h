@@ -260,6 +260,11 @@ MHX_API int mhx_lean_serialize(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs
 /* ---- Multi-GPU: assemble the signature matrix (RCCL over xGMI) ----------------------------- */
 /* 128-byte RCCL unique id, created on rank 0 and distributed by the caller (env, file, socket). */
 #define MHX_COMM_ID_BYTES 128
+/* Load RCCL now.  It must enter the process before any other ROCm runtime does (a PyTorch-ROCm wheel ships
+ * its own and RCCL loaded after it finds no device); loading takes about a second, so mhx_ctx_create does
+ * it up front only when WORLD_SIZE > 1 or MHX_PRELOAD_RCCL=1 is set; otherwise the first mhx_comm_* call
+ * (or this one) does. */
+MHX_API int mhx_comm_preload(void);
 MHX_API int mhx_comm_unique_id(uint8_t id[MHX_COMM_ID_BYTES]);
 MHX_API int mhx_comm_create(mhx_ctx *ctx, const uint8_t id[MHX_COMM_ID_BYTES], int rank,
                             int world_size, mhx_comm **comm);

@@ -871,6 +871,22 @@ def test_weighted_signatures_through_the_lsh_helpers_on_device(ctx):
         assert np.array_equal(dev, host) and len(host) > 50
 
 
+def test_near_duplicates_example_same_answer_on_device(ctx):
+    """examples/near_duplicates.py: byte tokens -> signatures -> candidate pairs -> Jaccard, device vs numpy."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "near_duplicates.py")
+    spec = importlib.util.spec_from_file_location("near_duplicates", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    dev = mod.main(["--docs", "1500", "--gpu-mode", "always"])
+    host = mod.main(["--docs", "1500", "--gpu-mode", "disable"])
+    for key in ("signatures", "pairs", "kept"):
+        assert np.array_equal(dev[key], host[key]), key
+    assert dev["recall"] > 0.9
+
+
 def test_candidate_pairs_device_entry(ctx):
     """The _dev entry point on the output of mhx_lsh_sort_bands_dev, buffers owned by the caller."""
     from datasketch_amd import lsh_bulk as LB

@@ -433,3 +433,16 @@ def test_bulk_with_repeated_tokens_equals_update_batch():
         m = MinHash(num_perm=32, seed=2, gpu_mode="disable")
         m.update_batch(s)
         assert np.array_equal(row, m.hashvalues)
+
+
+def test_near_duplicates_example_runs_on_the_numpy_paths():
+    """examples/near_duplicates.py end to end with gpu_mode='disable': planted near-duplicates are found."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "near_duplicates.py")
+    spec = importlib.util.spec_from_file_location("near_duplicates", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = mod.main(["--docs", "1200", "--gpu-mode", "disable"])
+    assert out["signatures"].shape == (1200, 128) and out["recall"] > 0.9 and len(out["kept"]) >= 100
