@@ -106,7 +106,7 @@ def packing(ctx, n, k):
     ms = timed(ctx, lambda: _native.check(lib.mhx_lsh_sort_bands_dev(ctx.handle, d_sig.ptr, n, k, 32, 8, d_sd.ptr, d_sr.ptr)), reps=3)
     sd = d_sd.download((32, n), np.uint64)
     assert np.all(sd[:, 1:] >= sd[:, :-1])
-    report(f"lsh_sort_bands bands=32 r=8 K={k} (digests + 32 radix sorts of {n} keys)", ms, n, "signatures", n * (8 * k + 12 * 32))
+    report(f"lsh_sort_bands bands=32 r=8 K={k} (digests + one radix sort of 32 x {n} keys by (band, digest))", ms, n, "signatures", n * (8 * k + 12 * 32))
     m = 4_000_000
     pairs = rng.randint(0, n, (m, 2)).astype(np.int64)
     d_pairs, d_cnt = ctx.to_device(pairs), ctx.alloc(m * 4)
