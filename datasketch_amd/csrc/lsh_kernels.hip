@@ -5,8 +5,8 @@
 // key in at least one band.  Here the grouping is a sort: per band, the 64-bit digests of the band keys
 // (pack_kernels.hip: FNV-1a-64 of exactly the reference's key bytes) are sorted together with the row
 // numbers, so every bucket becomes a run of equal digests.  The sort is rocPRIM's device radix sort
-// (a library primitive), ONE call over all n x bands keys ordered by (band, digest); the kernels around
-// it are ours.
+// (a library primitive), ONE call over all n x bands keys ordered by (band, digest prefix); the kernels
+// around it -- which also make the order exact -- are ours.
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -18,45 +18,70 @@
 namespace mhx {
 namespace {
 
-// One element of the sort: all bands of all rows go through ONE radix sort, ordered by (band, digest);
-// the row rides along inside the key.  (32 separate sorts of 10^6 keys are launch-bound: ~20 small
-// kernels each.)
-struct BandKey {
-    uint64_t digest;
-    uint32_t band;
-    uint32_t row;
-};
+// All bands of all rows go through ONE radix sort (32 separate sorts of 10^6 keys are launch-bound: ~20
+// small kernels each).  The sort key is the band and a prefix of the digest (40 bits in all at n = 10^6:
+// five 8-bit passes over 12-byte pairs) with the row as the value; sorting 64 + band_bits bits of a 16-byte
+// key took nine passes: 3.5 ms instead of 2.5 for 32 x 10^6 keys.  Exactness does not rest on the prefix:
+// after the sort the full digests are gathered in order and every run of equal prefixes whose digests are
+// not all equal is put in (digest, row) order in place.  Option "lsh.sort_bits" overrides the key length
+// (tests use short ones so that mixed runs abound).
 
-struct BandKeyOrder {  // most significant field first
-    __host__ __device__ rocprim::tuple<uint32_t &, uint64_t &> operator()(BandKey &key) const {
-        return rocprim::tuple<uint32_t &, uint64_t &>(key.band, key.digest);
-    }
-};
+// the top sort_bits bits of (band, digest), right-aligned: the radix sort runs over bits [0, sort_bits)
+__device__ __host__ __forceinline__ uint64_t prefix_key(uint64_t digest, uint32_t band, int band_bits, int sort_bits) {
+    const uint64_t whole = ((uint64_t)band << (64 - band_bits)) | (digest >> band_bits);
+    return whole >> (64 - sort_bits);
+}
 
-// digests[n, bands] (row-major) -> keys in the same order: rows ascend within every band, and the sort is
-// stable, so equal digests of a band keep ascending rows
+// digests[n, bands] (row-major) -> (key, row) in the same order: rows ascend within every band and the
+// sort is stable, so equal keys of a band keep ascending rows
 __global__ __launch_bounds__(256) void band_keys_for_sort_kernel(const uint64_t *__restrict__ digests, int64_t n, int32_t bands,
-                                                                 BandKey *__restrict__ keys) {
+                                                                 int band_bits, int sort_bits, uint64_t *__restrict__ keys,
+                                                                 uint32_t *__restrict__ rows) {
     const int64_t total = n * (int64_t)bands;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = idx / bands;
-        BandKey key;
-        key.digest = digests[idx];
-        key.band = (uint32_t)(idx - row * bands);
-        key.row = (uint32_t)row;
-        keys[idx] = key;
+        keys[idx] = prefix_key(digests[idx], (uint32_t)(idx - row * bands), band_bits, sort_bits);
+        rows[idx] = (uint32_t)row;
     }
 }
 
-// sorted keys (band-major by construction) -> sorted_digests[bands][n], sorted_rows[bands][n]
-__global__ __launch_bounds__(256) void split_sorted_kernel(const BandKey *__restrict__ keys, int64_t total,
-                                                           uint64_t *__restrict__ digests, uint32_t *__restrict__ rows) {
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const BandKey key = keys[idx];
-        digests[idx] = key.digest;
-        rows[idx] = key.row;
+// position p of the sorted order belongs to band p / n (every band has n entries): fetch its full digest
+__global__ __launch_bounds__(256) void gather_digests_kernel(const uint64_t *__restrict__ digests, const uint32_t *__restrict__ rows,
+                                                             int64_t n, int32_t bands, int64_t total,
+                                                             uint64_t *__restrict__ sorted_digests) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x)
+        sorted_digests[p] = digests[(int64_t)rows[p] * bands + p / n];
+}
+
+// The thread at the head of a run of equal sort keys checks the run's full digests; a mixed run (different
+// digests sharing the sorted prefix) is insertion-sorted by digest -- stable, so rows stay ascending
+// within equal digests.  Runs of equal digests (the LSH buckets) are left alone.
+__global__ __launch_bounds__(256) void order_mixed_runs_kernel(const uint64_t *__restrict__ keys, int64_t n, int64_t total,
+                                                               uint64_t *__restrict__ digests, uint32_t *__restrict__ rows) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = keys[p];  // the band sits in the key: a run never crosses bands
+        if (p % n != 0 && keys[p - 1] == key) continue;  // not a head
+        const int64_t band_end = (p / n + 1) * n;
+        int64_t end = p + 1;
+        bool mixed = false;
+        while (end < band_end && keys[end] == key) {
+            mixed |= digests[end] != digests[p];
+            ++end;
+        }
+        if (!mixed) continue;
+        for (int64_t i = p + 1; i < end; ++i) {
+            const uint64_t d = digests[i];
+            const uint32_t r = rows[i];
+            int64_t j = i;
+            while (j > p && digests[j - 1] > d) {
+                digests[j] = digests[j - 1];
+                rows[j] = rows[j - 1];
+                --j;
+            }
+            digests[j] = d;
+            rows[j] = r;
+        }
     }
 }
 
@@ -193,28 +218,41 @@ int launch_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *d_sorted_digests, c
 int launch_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
                           uint64_t *d_sorted_digests, uint32_t *d_sorted_rows) {
     if (n >= ((int64_t)1 << 32)) return fail(MHX_ERR_UNSUPPORTED, "more than 2^32-1 signatures per call");
-    // scratch[3]: digests[n, bands] | keys[n*bands] | sorted keys[n*bands] | rocPRIM temporary storage
+    // scratch[3]: digests[n, bands] | keys u64[total] | sorted keys u64[total] | rows u32[total] | rocPRIM temporary
     const int64_t total = n * (int64_t)bands;
     const size_t dig_bytes = ((sizeof(uint64_t) * (size_t)total) + 255) & ~(size_t)255;
-    const size_t key_bytes = sizeof(BandKey) * (size_t)total;
-    unsigned band_bits = 1;
+    const size_t row_bytes = ((sizeof(uint32_t) * (size_t)total) + 255) & ~(size_t)255;
+    int band_bits = 1;
     while (((int64_t)1 << band_bits) < bands) ++band_bits;
+    if (band_bits > 16) return fail(MHX_ERR_UNSUPPORTED, "more than 65536 bands");
+    // bits handed to the radix sort: band + a digest prefix of about 2 log2(n) - 8 bits, rounded up to whole
+    // 8-bit passes -- at most ~2^7 pairs of different digests per band then share a prefix and are left to the
+    // clean-up kernel (n = 10^6, 32 bands: 40 bits, 2.5 ms; 48 bits 2.8 ms; 64 bits 3.4 ms; 24 bits 2.9 ms)
+    int log_n = 1;
+    while (((int64_t)1 << log_n) < n) ++log_n;
+    const int auto_bits = std::min(64, (band_bits + std::max(16, 2 * log_n - 8) + 7) / 8 * 8);
+    const int sort_bits = (int)std::min<int64_t>(64, std::max<int64_t>(band_bits, ctx->opt_lsh_sort_bits > 0 ? ctx->opt_lsh_sort_bits : auto_bits));
     size_t tmp_bytes = 0;
-    hipError_t e = rocprim::radix_sort_keys(nullptr, tmp_bytes, (const BandKey *)nullptr, (BandKey *)nullptr, (size_t)total,
-                                            BandKeyOrder{}, 0u, 64u + band_bits, ctx->stream);
-    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_keys (size query) failed: %s", hipGetErrorString(e));
-    if (int rc = ctx->ensure_scratch(3, dig_bytes + 2 * key_bytes + tmp_bytes + 512)) return rc;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                             (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)total, 0, sort_bits,
+                                             ctx->stream);
+    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_pairs (size query) failed: %s", hipGetErrorString(e));
+    if (int rc = ctx->ensure_scratch(3, 3 * dig_bytes + row_bytes + tmp_bytes + 512)) return rc;
     uint64_t *d_dig = (uint64_t *)ctx->scratch[3];
-    BandKey *d_keys = (BandKey *)((char *)ctx->scratch[3] + dig_bytes);
-    BandKey *d_sorted = d_keys + total;
-    void *d_tmp = (char *)ctx->scratch[3] + dig_bytes + 2 * key_bytes;
+    uint64_t *d_keys = (uint64_t *)((char *)ctx->scratch[3] + dig_bytes);
+    uint64_t *d_keys_sorted = (uint64_t *)((char *)ctx->scratch[3] + 2 * dig_bytes);
+    uint32_t *d_rows = (uint32_t *)((char *)ctx->scratch[3] + 3 * dig_bytes);
+    void *d_tmp = (char *)ctx->scratch[3] + 3 * dig_bytes + row_bytes;
     if (int rc = launch_band_digests(ctx, d_sig, n, k, bands, r, d_dig)) return rc;
-    hipLaunchKernelGGL(band_keys_for_sort_kernel, dim3(grid_for(ctx, total)), dim3(256), 0, ctx->stream, d_dig, n, bands, d_keys);
+    const dim3 grid(grid_for(ctx, total));
+    hipLaunchKernelGGL(band_keys_for_sort_kernel, grid, dim3(256), 0, ctx->stream, d_dig, n, bands, band_bits, sort_bits, d_keys, d_rows);
     MHX_HIP_CHECK(hipGetLastError());
-    e = rocprim::radix_sort_keys(d_tmp, tmp_bytes, (const BandKey *)d_keys, d_sorted, (size_t)total, BandKeyOrder{}, 0u,
-                                 64u + band_bits, ctx->stream);
-    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_keys failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(split_sorted_kernel, dim3(grid_for(ctx, total)), dim3(256), 0, ctx->stream, d_sorted, total, d_sorted_digests,
+    e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, (const uint64_t *)d_keys, d_keys_sorted, (const uint32_t *)d_rows,
+                                  d_sorted_rows, (size_t)total, 0, sort_bits, ctx->stream);
+    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(gather_digests_kernel, grid, dim3(256), 0, ctx->stream, d_dig, d_sorted_rows, n, bands, total,
+                       d_sorted_digests);
+    hipLaunchKernelGGL(order_mixed_runs_kernel, grid, dim3(256), 0, ctx->stream, d_keys_sorted, n, total, d_sorted_digests,
                        d_sorted_rows);
     MHX_HIP_CHECK(hipGetLastError());
     return MHX_OK;

@@ -66,7 +66,8 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * 1 = exact fold for every pair, 2 = fast fold with exact redo), ("minhash.split", 0 auto,
  * 1 wave per set, 2 split sets over waves), ("blocks_per_cu", n), ("minhash.prefetch", 0/1),
  * ("weighted.path", 0 auto, 1 IEEE division for every element), ("host.chunk_bytes", see
- * mhx_minhash_bulk). */
+ * mhx_minhash_bulk), ("lsh.sort_bits", bits of (band, digest) mhx_lsh_sort_bands hands to the radix sort,
+ * 0 = chosen from n; the order is exact for any value, fewer bits leave more to the clean-up pass). */
 MHX_API int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value);
 /* Kernel event counters since the last call (synchronises the stream, then resets them):
  *   out[0] sets the sieve launch left to the full launch (failed proof, or skipped by the back-off),

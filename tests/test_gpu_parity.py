@@ -887,6 +887,30 @@ def test_near_duplicates_example_same_answer_on_device(ctx):
     assert dev["recall"] > 0.9
 
 
+@pytest.mark.parametrize("sort_bits", [0, 6, 12, 20, 33, 64])
+def test_sorted_bands_exact_for_any_radix_prefix(ctx, sort_bits):
+    """mhx_lsh_sort_bands sorts a (band, digest-prefix) key and repairs runs of equal prefixes afterwards:
+    digests and rows must equal the stable host sort whatever the prefix length (short prefixes make
+    nearly every run a mixed one)."""
+    from datasketch_amd import lsh_bulk as LB
+
+    rng = np.random.RandomState(sort_bits)
+    n, b, r = 2500, 24, 3
+    sig = rng.randint(0, 2**32, (n, b * r + 5), dtype=np.uint64)
+    sig[rng.randint(0, n, 500)] = sig[rng.randint(0, n, 500)]          # buckets of equal keys
+    sig[rng.randint(0, n, 300), :r] = sig[rng.randint(0, n, 300), :r]  # ... and of single bands
+    want_dig, want_rows = LB.sorted_bands(sig, b, r, gpu_mode="disable")
+    try:
+        ctx.set_option("lsh.sort_bits", sort_bits)
+        got_dig, got_rows = LB.sorted_bands(sig, b, r, gpu_mode="always")
+        pairs = LB.candidate_pairs(sig, b, r, gpu_mode="always")
+    finally:
+        ctx.set_option("lsh.sort_bits", 0)
+    assert np.array_equal(got_dig, want_dig)
+    assert np.array_equal(got_rows, want_rows)
+    assert np.array_equal(pairs, LB.candidate_pairs(sig, b, r, gpu_mode="disable"))
+
+
 def test_candidate_pairs_device_entry(ctx):
     """The _dev entry point on the output of mhx_lsh_sort_bands_dev, buffers owned by the caller."""
     from datasketch_amd import lsh_bulk as LB
