@@ -54,22 +54,32 @@ __global__ __launch_bounds__(256) void gather_digests_kernel(const uint64_t *__r
         sorted_digests[p] = digests[(int64_t)rows[p] * bands + p / n];
 }
 
-// The thread at the head of a run of equal sort keys checks the run's full digests; a mixed run (different
-// digests sharing the sorted prefix) is insertion-sorted by digest -- stable, so rows stay ascending
-// within equal digests.  Runs of equal digests (the LSH buckets) are left alone.
-__global__ __launch_bounds__(256) void order_mixed_runs_kernel(const uint64_t *__restrict__ keys, int64_t n, int64_t total,
-                                                               uint64_t *__restrict__ digests, uint32_t *__restrict__ rows) {
+// Runs of equal sort keys whose full digests are NOT all equal (different digests sharing the sorted
+// prefix) have to be put in digest order.  Found in parallel: an element that has its predecessor's key but
+// not its digest walks back to the head of its run and marks it; buckets of equal digests -- however large
+// -- are never walked.
+__global__ __launch_bounds__(256) void mark_mixed_runs_kernel(const uint64_t *__restrict__ keys, const uint64_t *__restrict__ digests,
+                                                              int64_t n, int64_t total, uint8_t *__restrict__ mixed) {
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        if (p % n == 0 || keys[p - 1] != keys[p] || digests[p - 1] == digests[p]) continue;
         const uint64_t key = keys[p];  // the band sits in the key: a run never crosses bands
-        if (p % n != 0 && keys[p - 1] == key) continue;  // not a head
+        const int64_t band_start = p / n * n;
+        int64_t head = p - 1;
+        while (head > band_start && keys[head - 1] == key) --head;
+        mixed[head] = 1;
+    }
+}
+
+// The head of a marked run insertion-sorts it by digest -- stable, so rows stay ascending within equal digests.
+__global__ __launch_bounds__(256) void order_mixed_runs_kernel(const uint64_t *__restrict__ keys, const uint8_t *__restrict__ mixed,
+                                                               int64_t n, int64_t total, uint64_t *__restrict__ digests,
+                                                               uint32_t *__restrict__ rows) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        if (!mixed[p]) continue;
+        const uint64_t key = keys[p];
         const int64_t band_end = (p / n + 1) * n;
         int64_t end = p + 1;
-        bool mixed = false;
-        while (end < band_end && keys[end] == key) {
-            mixed |= digests[end] != digests[p];
-            ++end;
-        }
-        if (!mixed) continue;
+        while (end < band_end && keys[end] == key) ++end;
         for (int64_t i = p + 1; i < end; ++i) {
             const uint64_t d = digests[i];
             const uint32_t r = rows[i];
@@ -218,7 +228,8 @@ int launch_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *d_sorted_digests, c
 int launch_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
                           uint64_t *d_sorted_digests, uint32_t *d_sorted_rows) {
     if (n >= ((int64_t)1 << 32)) return fail(MHX_ERR_UNSUPPORTED, "more than 2^32-1 signatures per call");
-    // scratch[3]: digests[n, bands] | keys u64[total] | sorted keys u64[total] | rows u32[total] | rocPRIM temporary
+    // scratch[3]: digests[n, bands] | keys u64[total] | sorted keys u64[total] | rows u32[total] | marks u8[total] |
+    // rocPRIM temporary
     const int64_t total = n * (int64_t)bands;
     const size_t dig_bytes = ((sizeof(uint64_t) * (size_t)total) + 255) & ~(size_t)255;
     const size_t row_bytes = ((sizeof(uint32_t) * (size_t)total) + 255) & ~(size_t)255;
@@ -237,12 +248,14 @@ int launch_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_
                                              (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)total, 0, sort_bits,
                                              ctx->stream);
     if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_pairs (size query) failed: %s", hipGetErrorString(e));
-    if (int rc = ctx->ensure_scratch(3, 3 * dig_bytes + row_bytes + tmp_bytes + 512)) return rc;
+    const size_t mark_bytes = ((size_t)total + 255) & ~(size_t)255;
+    if (int rc = ctx->ensure_scratch(3, 3 * dig_bytes + row_bytes + mark_bytes + tmp_bytes + 512)) return rc;
     uint64_t *d_dig = (uint64_t *)ctx->scratch[3];
     uint64_t *d_keys = (uint64_t *)((char *)ctx->scratch[3] + dig_bytes);
     uint64_t *d_keys_sorted = (uint64_t *)((char *)ctx->scratch[3] + 2 * dig_bytes);
     uint32_t *d_rows = (uint32_t *)((char *)ctx->scratch[3] + 3 * dig_bytes);
-    void *d_tmp = (char *)ctx->scratch[3] + 3 * dig_bytes + row_bytes;
+    uint8_t *d_mixed = (uint8_t *)((char *)ctx->scratch[3] + 3 * dig_bytes + row_bytes);
+    void *d_tmp = (char *)ctx->scratch[3] + 3 * dig_bytes + row_bytes + mark_bytes;
     if (int rc = launch_band_digests(ctx, d_sig, n, k, bands, r, d_dig)) return rc;
     const dim3 grid(grid_for(ctx, total));
     hipLaunchKernelGGL(band_keys_for_sort_kernel, grid, dim3(256), 0, ctx->stream, d_dig, n, bands, band_bits, sort_bits, d_keys, d_rows);
@@ -252,8 +265,10 @@ int launch_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_
     if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
     hipLaunchKernelGGL(gather_digests_kernel, grid, dim3(256), 0, ctx->stream, d_dig, d_sorted_rows, n, bands, total,
                        d_sorted_digests);
-    hipLaunchKernelGGL(order_mixed_runs_kernel, grid, dim3(256), 0, ctx->stream, d_keys_sorted, n, total, d_sorted_digests,
-                       d_sorted_rows);
+    MHX_HIP_CHECK(hipMemsetAsync(d_mixed, 0, (size_t)total, ctx->stream));
+    hipLaunchKernelGGL(mark_mixed_runs_kernel, grid, dim3(256), 0, ctx->stream, d_keys_sorted, d_sorted_digests, n, total, d_mixed);
+    hipLaunchKernelGGL(order_mixed_runs_kernel, grid, dim3(256), 0, ctx->stream, d_keys_sorted, d_mixed, n, total,
+                       d_sorted_digests, d_sorted_rows);
     MHX_HIP_CHECK(hipGetLastError());
     return MHX_OK;
 }

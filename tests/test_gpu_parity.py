@@ -911,6 +911,24 @@ def test_sorted_bands_exact_for_any_radix_prefix(ctx, sort_bits):
     assert np.array_equal(pairs, LB.candidate_pairs(sig, b, r, gpu_mode="disable"))
 
 
+def test_sorted_bands_with_huge_buckets(ctx):
+    """Tens of thousands of identical rows (one bucket per band) next to ordinary rows, default and short keys."""
+    from datasketch_amd import lsh_bulk as LB
+
+    rng = np.random.RandomState(31)
+    n, b, r = 60_000, 8, 4
+    sig = rng.randint(0, 2**32, (n, b * r), dtype=np.uint64)
+    sig[rng.permutation(n)[:25_000]] = sig[0]
+    want_dig, want_rows = LB.sorted_bands(sig, b, r, gpu_mode="disable")
+    try:
+        for bits in (0, 16):
+            ctx.set_option("lsh.sort_bits", bits)
+            got_dig, got_rows = LB.sorted_bands(sig, b, r, gpu_mode="always")
+            assert np.array_equal(got_dig, want_dig) and np.array_equal(got_rows, want_rows), bits
+    finally:
+        ctx.set_option("lsh.sort_bits", 0)
+
+
 def test_candidate_pairs_device_entry(ctx):
     """The _dev entry point on the output of mhx_lsh_sort_bands_dev, buffers owned by the caller."""
     from datasketch_amd import lsh_bulk as LB
