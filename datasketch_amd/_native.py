@@ -32,6 +32,7 @@ _PROTOTYPES = {
     "mhx_ctx_create": [_int, ctypes.POINTER(_vp)],
     "mhx_ctx_destroy": [_vp],
     "mhx_ctx_synchronize": [_vp],
+    "mhx_ctx_release_scratch": [_vp],
     "mhx_ctx_device_info": [_vp, ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_i64)],
     "mhx_ctx_set_option": [_vp, ctypes.c_char_p, _i64],
     "mhx_ctx_counters": [_vp, _int, ctypes.POINTER(ctypes.c_uint64)],
@@ -278,6 +279,10 @@ class Context:
 
     def synchronize(self) -> None:
         check(self.lib.mhx_ctx_synchronize(self.handle))
+
+    def release_scratch(self) -> None:
+        """Give back the device staging buffers the host entry points grew (re-created on demand)."""
+        check(self.lib.mhx_ctx_release_scratch(self.handle))
 
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)

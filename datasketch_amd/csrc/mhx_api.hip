@@ -175,6 +175,23 @@ int mhx_ctx_synchronize(mhx_ctx *ctx) {
     return MHX_OK;
 }
 
+int mhx_ctx_release_scratch(mhx_ctx *ctx) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    if (int rc = ctx->activate()) return rc;
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 5; ++i) {
+        if (ctx->scratch[i]) MHX_HIP_CHECK(hipFree(ctx->scratch[i]));
+        ctx->scratch[i] = nullptr;
+        ctx->scratch_bytes[i] = 0;
+    }
+    if (ctx->d_redo) {
+        MHX_HIP_CHECK(hipFree(ctx->d_redo));
+        ctx->d_redo = nullptr;
+        ctx->redo_capacity = 0;
+    }
+    return MHX_OK;
+}
+
 int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus, int64_t *hbm_bytes) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
     if (name && name_len > 0) {

@@ -60,6 +60,8 @@ MHX_API int mhx_device_count(int *count);
 MHX_API int mhx_ctx_create(int device, mhx_ctx **ctx);
 MHX_API int mhx_ctx_destroy(mhx_ctx *ctx);
 MHX_API int mhx_ctx_synchronize(mhx_ctx *ctx);
+/* Free the grow-only device staging buffers of the host entry points (they are re-created on demand). */
+MHX_API int mhx_ctx_release_scratch(mhx_ctx *ctx);
 /* name: caller buffer (may be NULL); cus: compute units; hbm_bytes: total device memory */
 MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus, int64_t *hbm_bytes);
 /* Tuning / test knobs: ("minhash.path", 0 = auto: sieve with full-evaluation fallback,

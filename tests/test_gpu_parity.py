@@ -929,6 +929,22 @@ def test_sorted_bands_with_huge_buckets(ctx):
         ctx.set_option("lsh.sort_bits", 0)
 
 
+def test_release_scratch_and_regrow(ctx):
+    """mhx_ctx_release_scratch frees the staging buffers; the next host calls re-create them."""
+    rng = np.random.RandomState(2)
+    tok = rng.randint(0, 2**32, (500, 40), dtype=np.uint64)
+    a, b = O.np_init_permutations(64, 9)
+    want = O.c_minhash_bulk_dense(tok, a, b)
+    assert np.array_equal(ctx.minhash_bulk((a, b), tok.reshape(-1), None, 40, 500), want)
+    ctx.release_scratch()
+    ctx.release_scratch()  # idempotent
+    assert np.array_equal(ctx.minhash_bulk((a, b), tok.reshape(-1), None, 40, 500), want)
+    sig = want
+    from datasketch_amd import lsh_bulk as LB
+    ctx.release_scratch()
+    assert np.array_equal(LB.candidate_pairs(sig, 16, 4, gpu_mode="always"), LB.candidate_pairs(sig, 16, 4, gpu_mode="disable"))
+
+
 def test_candidate_pairs_device_entry(ctx):
     """The _dev entry point on the output of mhx_lsh_sort_bands_dev, buffers owned by the caller."""
     from datasketch_amd import lsh_bulk as LB
