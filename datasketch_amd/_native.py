@@ -59,6 +59,8 @@ _PROTOTYPES = {
     "mhx_wgen_create": [_vp, _vp, _vp, _vp, _i32, _i32, ctypes.POINTER(_vp)],
     "mhx_wgen_destroy": [_vp],
     "mhx_weighted_minhash_many": [_vp, _vp, _vp, _vp, _int, _i64, _vp, _vp],
+    "mhx_weighted_minhash_many_dense": [_vp, _vp, _int, _i64, _vp, _vp],
+    "mhx_weighted_minhash_many_dense_dev": [_vp, _vp, _int, _i64, _vp, _vp],
     "mhx_weighted_minhash_many_dev": [_vp, _vp, _vp, _vp, _int, _i64, _i64, _vp, _vp],
     "mhx_bbit_num_blocks": [_i32, _i32, ctypes.POINTER(_i32)],
     "mhx_bbit_pack_dev": [_vp, _vp, _i64, _i32, _i32, _vp],
@@ -443,6 +445,15 @@ class Context:
         out = np.zeros((n, int(sample_size), 2), dtype=np.int64)
         nonempty = np.zeros(n, dtype=np.uint8)
         check(self.lib.mhx_weighted_minhash_many(h, _ptr(indptr), _ptr(indices), _ptr(values), int(bool(values_are_logs)), n, _ptr(out), _ptr(nonempty)))
+        return out, nonempty.astype(bool)
+
+    def weighted_minhash_many_dense(self, h: int, sample_size: int, x: np.ndarray, values_are_logs: bool):
+        """Dense [N, dim] float32 rows (values, or logs with -inf for absent entries) -> (out, nonempty)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.shape[0]
+        out = np.zeros((n, int(sample_size), 2), dtype=np.int64)
+        nonempty = np.zeros(n, dtype=np.uint8)
+        check(self.lib.mhx_weighted_minhash_many_dense(h, _ptr(x), int(bool(values_are_logs)), n, _ptr(out), _ptr(nonempty)))
         return out, nonempty.astype(bool)
 
     def bbit_pack(self, sig: np.ndarray, b: int) -> np.ndarray:

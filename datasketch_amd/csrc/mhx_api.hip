@@ -1046,4 +1046,38 @@ int mhx_weighted_minhash_many(mhx_wgen *gen, const int64_t *indptr, const int32_
     return MHX_OK;
 }
 
+int mhx_weighted_minhash_many_dense_dev(mhx_wgen *gen, const float *d_x, int values_are_logs, int64_t n_rows,
+                                        int64_t *d_out, uint8_t *d_nonempty) {
+    if (!gen) return fail(MHX_ERR_INVALID, "gen is NULL");
+    MHX_REQUIRE(n_rows >= 0, "bad shape");
+    if (n_rows == 0) return MHX_OK;
+    MHX_REQUIRE(d_x && d_out && d_nonempty, "NULL device pointer");
+    if (int rc = gen->ctx->activate()) return rc;
+    return mhx::launch_weighted_dense(gen, d_x, values_are_logs, n_rows, d_out, d_nonempty);
+}
+
+int mhx_weighted_minhash_many_dense(mhx_wgen *gen, const float *x, int values_are_logs, int64_t n_rows, int64_t *out,
+                                    uint8_t *nonempty) {
+    if (!gen) return fail(MHX_ERR_INVALID, "gen is NULL");
+    MHX_REQUIRE(n_rows >= 0, "bad shape");
+    if (n_rows == 0) return MHX_OK;
+    MHX_REQUIRE(x && out && nonempty, "NULL host pointer");
+    mhx_ctx *ctx = gen->ctx;
+    if (int rc = ctx->activate()) return rc;
+    const size_t x_bytes = sizeof(float) * (size_t)n_rows * (size_t)gen->dim;
+    const size_t out_bytes = sizeof(int64_t) * 2 * (size_t)gen->sample_size * (size_t)n_rows;
+    const size_t ne_off = (out_bytes + 255) & ~(size_t)255;
+    if (int rc = ctx->ensure_scratch(0, x_bytes)) return rc;
+    if (int rc = ctx->ensure_scratch(2, ne_off + (size_t)n_rows)) return rc;
+    float *d_x = (float *)ctx->scratch[0];
+    int64_t *d_out = (int64_t *)ctx->scratch[2];
+    uint8_t *d_ne = (uint8_t *)ctx->scratch[2] + ne_off;
+    MHX_HIP_CHECK(hipMemcpyAsync(d_x, x, x_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = mhx::launch_weighted_dense(gen, d_x, values_are_logs, n_rows, d_out, d_ne)) return rc;
+    MHX_HIP_CHECK(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipMemcpyAsync(nonempty, d_ne, (size_t)n_rows, hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MHX_OK;
+}
+
 }  // extern "C"

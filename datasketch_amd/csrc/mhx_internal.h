@@ -119,6 +119,8 @@ int launch_band_digests(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t 
                         uint64_t *d_out);
 int launch_jaccard_pairs(mhx_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, int32_t k, const int64_t *d_pairs,
                          int64_t m, int32_t *d_counts);
+int launch_weighted_dense(mhx_wgen *gen, const float *d_x, int values_are_logs, int64_t n_rows, int64_t *d_out,
+                          uint8_t *d_nonempty);
 int launch_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *d_sorted_digests, const uint32_t *d_sorted_rows, int64_t n,
                                int32_t bands, int64_t *d_pairs, int64_t capacity, int64_t *n_pairs, int64_t *n_raw);
 int launch_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,

@@ -38,6 +38,8 @@
 // bound by L2 bandwidth, not arithmetic.  Blocks of 8 consecutive rows that share one column
 // list (every block of a dense matrix) are hashed together: table entries are loaded once per
 // column and used for 8 rows from registers.
+#include <rocprim/device/device_scan.hpp>
+
 #include "mhx_internal.h"
 
 #pragma clang fp contract(off)
@@ -344,6 +346,91 @@ int launch_wgen_transpose(mhx_wgen *gen, const float *d_rs, const float *d_lncs,
                        d_betas, gen->sample_size, gen->dim, gen->s_pad, gen->d_params);
     MHX_HIP_CHECK(hipGetLastError());
     return MHX_OK;
+}
+
+// ---- dense rows: CSR built on the device ------------------------------------------------------------
+// The reference turns a dense [N, dim] input into CSR with scipy on one host core (seconds for 10^5 x 4096);
+// here the dense matrix is uploaded as it is and compacted by two kernels.  An entry is stored iff its value
+// is not zero (what scipy's nonzero() keeps: NaN stays); when the host passes logs, ln(0) = -inf marks the
+// absent entries (no stored value has that log).
+__device__ __forceinline__ bool dense_present(float v, int values_are_logs) {
+    return values_are_logs ? !(v == -INFINITY) : (v != 0.0f);
+}
+
+// counts[row] = stored entries of the row; one wave per row
+__global__ __launch_bounds__(256) void dense_count_kernel(const float *__restrict__ x, int64_t n_rows, int32_t dim,
+                                                          int values_are_logs, int64_t *__restrict__ counts) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t row = wave; row < n_rows; row += n_waves) {
+        const float *src = x + row * dim;
+        int count = 0;
+        for (int c0 = 0; c0 < dim; c0 += kWave) {
+            const int c = c0 + lane;
+            const bool keep = c < dim && dense_present(src[c], values_are_logs);
+            count += __popcll(__ballot(keep));
+        }
+        if (lane == 0) counts[row] = count;
+    }
+}
+
+// indices / values of the stored entries, in column order, at indptr[row]
+__global__ __launch_bounds__(256) void dense_compact_kernel(const float *__restrict__ x, int64_t n_rows, int32_t dim,
+                                                            int values_are_logs, const int64_t *__restrict__ indptr,
+                                                            int32_t *__restrict__ indices, float *__restrict__ values) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t row = wave; row < n_rows; row += n_waves) {
+        const float *src = x + row * dim;
+        int64_t at = indptr[row];
+        for (int c0 = 0; c0 < dim; c0 += kWave) {
+            const int c = c0 + lane;
+            const float v = c < dim ? src[c] : 0.0f;
+            const bool keep = c < dim && dense_present(v, values_are_logs);
+            const unsigned long long mask = __ballot(keep);
+            if (keep) {
+                const int below = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                indices[at + below] = c;
+                values[at + below] = v;
+            }
+            at += __popcll(mask);
+        }
+    }
+}
+
+int launch_weighted_dense(mhx_wgen *gen, const float *d_x, int values_are_logs, int64_t n_rows, int64_t *d_out,
+                          uint8_t *d_nonempty) {
+    mhx_ctx *ctx = gen->ctx;
+    const int32_t dim = gen->dim;
+    // scratch[4]: counts i64[n+1] | indptr i64[n+1] | scan temporary | indices i32[n*dim] | values f32[n*dim]
+    const size_t ptr_bytes = ((sizeof(int64_t) * (size_t)(n_rows + 1)) + 255) & ~(size_t)255;
+    const size_t cell_bytes = ((sizeof(float) * (size_t)n_rows * (size_t)dim) + 255) & ~(size_t)255;
+    size_t scan_tmp = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, scan_tmp, (const int64_t *)nullptr, (int64_t *)nullptr, (int64_t)0,
+                                           (size_t)(n_rows + 1), rocprim::plus<int64_t>(), ctx->stream);
+    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::exclusive_scan (size query) failed: %s", hipGetErrorString(e));
+    scan_tmp = (scan_tmp + 255) & ~(size_t)255;
+    if (int rc = ctx->ensure_scratch(4, 2 * ptr_bytes + scan_tmp + 2 * cell_bytes)) return rc;
+    char *base = (char *)ctx->scratch[4];
+    int64_t *d_counts = (int64_t *)base;
+    int64_t *d_indptr = (int64_t *)(base + ptr_bytes);
+    void *d_tmp = base + 2 * ptr_bytes;
+    int32_t *d_indices = (int32_t *)(base + 2 * ptr_bytes + scan_tmp);
+    float *d_values = (float *)(base + 2 * ptr_bytes + scan_tmp + cell_bytes);
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_rows + 3) / 4, (int64_t)ctx->num_cus * 32));
+    MHX_HIP_CHECK(hipMemsetAsync(d_counts + n_rows, 0, sizeof(int64_t), ctx->stream));  // the scan's last input
+    hipLaunchKernelGGL(dense_count_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_x, n_rows, dim, values_are_logs, d_counts);
+    MHX_HIP_CHECK(hipGetLastError());
+    e = rocprim::exclusive_scan(d_tmp, scan_tmp, (const int64_t *)d_counts, d_indptr, (int64_t)0, (size_t)(n_rows + 1),
+                                rocprim::plus<int64_t>(), ctx->stream);
+    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::exclusive_scan failed: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(dense_compact_kernel, dim3(blocks), dim3(256), 0, ctx->stream, d_x, n_rows, dim, values_are_logs, d_indptr,
+                       d_indices, d_values);
+    MHX_HIP_CHECK(hipGetLastError());
+    // nnz only sizes the device-log buffer of launch_weighted: n_rows * dim bounds it without a read-back
+    return launch_weighted(gen, d_indptr, d_indices, d_values, values_are_logs, n_rows, n_rows * (int64_t)dim, d_out, d_nonempty);
 }
 
 int launch_weighted(mhx_wgen *gen, const int64_t *d_indptr, const int32_t *d_indices, const float *d_values,

@@ -146,6 +146,16 @@ class WeightedMinHashGenerator:
 
     def minhash_many_arrays(self, X):
         """Like :meth:`minhash_many` but returns ``(hashvalues[N, S, 2] int64, nonempty[N] bool)``."""
+        if isinstance(X, np.ndarray) and X.ndim == 2 and self._use_gpu():
+            # dense rows go to the device as they are: the CSR form (scipy on one host core in the
+            # reference: seconds for 10^5 x 4096) is built there.  ln(0) = -inf marks the absent entries.
+            ctx, handle = self._device_handle()
+            x32 = np.ascontiguousarray(X, dtype=np.float32)
+            if self._device_log:
+                return ctx.weighted_minhash_many_dense(handle, self.sample_size, x32, False)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                logs = np.log(x32)
+            return ctx.weighted_minhash_many_dense(handle, self.sample_size, logs, True)
         X = sparse.csr_matrix(X, dtype=np.float32, copy=True)
         X.sort_indices()
         X.eliminate_zeros()  # explicit zeros are not part of a row (the reference's nonzero() skips them too)

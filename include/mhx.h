@@ -198,6 +198,15 @@ MHX_API int mhx_weighted_minhash_many_dev(mhx_wgen *gen, const int64_t *d_indptr
                                           int values_are_logs, int64_t n_rows, int64_t nnz,
                                           int64_t *d_out, uint8_t *d_nonempty);
 
+/* The same for DENSE rows x[n_rows, dim] float32 (what the reference first converts with scipy on the host):
+ * an entry counts as stored iff its value is not 0 (NaN counts, as for scipy's nonzero()); with
+ * values_are_logs != 0 the caller passes ln(x) and ln(0) = -inf marks the absent entries.  The CSR form is
+ * built on the device. */
+MHX_API int mhx_weighted_minhash_many_dense(mhx_wgen *gen, const float *x, int values_are_logs,
+                                            int64_t n_rows, int64_t *out, uint8_t *nonempty);
+MHX_API int mhx_weighted_minhash_many_dense_dev(mhx_wgen *gen, const float *d_x, int values_are_logs,
+                                                int64_t n_rows, int64_t *d_out, uint8_t *d_nonempty);
+
 /* ---- Packing for downstream consumers ----------------------------------------------------- */
 /* Number of uint64 blocks bBitMinHash uses for num_perm values of b bits
  * (ref: datasketch/b_bit_minhash.py:147-172). */

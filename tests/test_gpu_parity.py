@@ -854,6 +854,36 @@ def test_candidate_pairs_on_device(ctx, n, b, r, clusters):
     assert np.array_equal(LB.candidate_pairs(sig, b, r, gpu_mode="always"), want)
 
 
+@pytest.mark.parametrize("n,dim,s", [(1, 1, 1), (37, 100, 20), (300, 257, 64), (70, 4096, 128)])
+def test_weighted_dense_rows_are_compacted_on_device(ctx, n, dim, s):
+    """A dense ndarray goes up as it is (mhx_weighted_minhash_many_dense builds the CSR form on the device): same
+    (k, t) as the scipy CSR route and the oracle -- all-zero rows, -0.0, NaN, inf, negative and denormal values."""
+    rng = np.random.RandomState(n + dim)
+    x = rng.uniform(0, 50, (n, dim)).astype(np.float32)
+    x[rng.random_sample(x.shape) < 0.6] = 0
+    if n > 3:
+        x[3] = 0
+        x[5, : dim // 2] = -0.0
+        x[7, rng.randint(0, dim)] = np.nan
+        x[8, rng.randint(0, dim)] = np.inf
+        x[9, rng.randint(0, dim)] = -3.5
+        x[10, rng.randint(0, dim)] = 1e-42  # float32 denormal: stored, finite log
+    g = WeightedMinHashGenerator(dim, s, seed=11, gpu_mode="always")
+    dense_out, dense_ne = g.minhash_many_arrays(x)
+    csr = sp.csr_matrix(x)
+    csr_out, csr_ne = g.minhash_many_arrays(csr)
+    assert np.array_equal(dense_ne, csr_ne)
+    assert np.array_equal(dense_out, csr_out)
+    clean = np.nan_to_num(np.abs(x), nan=1.0, posinf=1.0)  # the oracle on well-defined input
+    c = sp.csr_matrix(clean)
+    c.sort_indices()
+    want, want_ne = O.c_weighted_minhash_many(c.indptr, c.indices, c.data, g.rs, g.ln_cs, g.betas)
+    got, got_ne = g.minhash_many_arrays(clean)
+    assert np.array_equal(got, want) and np.array_equal(got_ne, want_ne)
+    objs = g.minhash_many(x)
+    assert [o is None for o in objs] == [not v for v in dense_ne]
+
+
 def test_weighted_signatures_through_the_lsh_helpers_on_device(ctx):
     """[N, S, 2] int64 WeightedMinHash matrices are [N, 2S] words to the band kernels (keys of 2r words)."""
     from datasketch_amd import lsh_bulk as LB

@@ -260,6 +260,25 @@ def lsh(ctx, n):
     print(json.dumps({"name": f"candidate_pairs device path host->host N={m}", "seconds": round(time.perf_counter() - t0, 4)}), flush=True)
 
 
+def weighted_python_level(ctx, n, dim, s):
+    """WeightedMinHashGenerator.minhash_many_arrays from Python on a dense matrix: the device-built CSR (dense
+    entry point) against the scipy CSR the reference route needs first."""
+    import scipy.sparse as sp
+
+    rng = np.random.RandomState(42)
+    x = rng.uniform(0, 100, (n, dim)).astype(np.float32)
+    g = WeightedMinHashGenerator(dim, s, seed=1, gpu_mode="always")
+    g.minhash_many_arrays(x[:64])
+    t0 = time.perf_counter()
+    dense = g.minhash_many_arrays(x)
+    t1 = time.perf_counter()
+    csr = g.minhash_many_arrays(sp.csr_matrix(x))
+    t2 = time.perf_counter()
+    assert np.array_equal(dense[0], csr[0])
+    print(json.dumps({"name": f"minhash_many_arrays from Python, dense {n} x {dim}, S={s}", "dense_entry_seconds": round(t1 - t0, 3),
+                      "scipy_csr_route_seconds": round(t2 - t1, 3), "vectors_per_s_dense_entry": n / (t1 - t0)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--weighted-rows", type=int, default=20000)
@@ -280,6 +299,8 @@ def main():
         reference_gpu_benchmark(ctx)
     if args.only in ("", "lsh"):
         lsh(ctx, args.sigs)
+    if args.only in ("", "weighted", "weighted_py"):
+        weighted_python_level(ctx, args.weighted_rows, 4096, 128)
     if args.only in ("", "weighted"):
         weighted(ctx, args.weighted_rows, 4096, 128, 1.0)
         weighted(ctx, args.weighted_rows * 4, 4096, 128, 0.01)
