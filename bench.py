@@ -149,17 +149,22 @@ def main():
     ctx.minhash_bulk_dev(perms, d_tok.ptr, tok_dtype, None, t, n, n * t, None, 0, d_out.ptr, out_dtype)
     counters = ctx.counters(False)
 
-    # ---- parity: rows spread over the whole matrix against the C oracle (bit-exact or fail)
-    from oracle import oracle as O
+    # ---- parity: rows spread over the whole matrix against the package's numpy path (gpu_mode="disable": the
+    # reference's arithmetic, minhash.py:293-297), bit-exact or fail.  The oracle itself is only used in the
+    # cpu_baseline leg below, which also compares its rows with the GPU's.
+    from datasketch_amd.hashfunc import prehashed
 
     a, b = perms
     check = max(0, min(args.check_rows, n))
-    if check:
-        rows = np.unique(np.linspace(0, n - 1, check).astype(np.int64))
+    sig_head = None
+    if check or (args.cpu_sample > 0 and rank == 0 and world == 1):
         sig = d_out.download((n, k), out_np)
-        want = O.c_minhash_bulk_dense(tokens[rows], a, b)
-        if not np.array_equal(sig[rows].astype(np.uint64), want):
-            raise SystemExit("PARITY FAILURE: GPU signatures differ from the oracle")
+        if check:
+            rows = np.unique(np.linspace(0, n - 1, check).astype(np.int64))
+            want = MinHash.bulk_signatures(tokens[rows], num_perm=k, seed=args.seed, hashfunc=prehashed, gpu_mode="disable")
+            if not np.array_equal(sig[rows].astype(np.uint64), want):
+                raise SystemExit("PARITY FAILURE: GPU signatures differ from the numpy path")
+        sig_head = sig[: min(n, 40_000)].astype(np.uint64)
         del sig
 
     out = {
@@ -218,7 +223,7 @@ def main():
             out["pcie_inclusive_value"] = n / (time.perf_counter() - t1)
             del host_out
         if args.cpu_sample > 0:
-            out["cpu_baseline"] = cpu_baseline(O, tokens, a, b, min(args.cpu_sample, n), k, t, seed=args.seed)
+            out["cpu_baseline"] = cpu_baseline(tokens, a, b, min(args.cpu_sample, n), k, t, sig_head, seed=args.seed)
     if dist is not None:
         barrier()
         dist.destroy_process_group()
@@ -273,12 +278,15 @@ def _usable_cores(cap=64):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(O, tokens, a, b, sample, k, t, seed=1):
+def cpu_baseline(tokens, a, b, sample, k, t, gpu_rows, seed=1):
     """The reference's CPU path (numpy restatement, oracle/oracle.py:np_minhash_bulk = the per-set
     loop of MinHash.bulk).  numpy's uint64 ufuncs are single-threaded, so "the host's cores" means
     one process per core, each with its own shard: `value` is that
-    all-cores rate, `single_core_value` the rate of one process."""
+    all-cores rate, `single_core_value` the rate of one process.  The rows the oracle produces for the
+    timed sample are compared with the GPU's (`gpu_rows`): the baseline times the same function."""
     import multiprocessing as mp
+
+    from oracle import oracle as O
 
     single = min(sample, 40_000)
     sets = list(tokens[:single])
@@ -289,6 +297,9 @@ def cpu_baseline(O, tokens, a, b, sample, k, t, seed=1):
     want = O.c_minhash_bulk_dense(tokens[:single], a, b)
     cdt = time.perf_counter() - c0
     assert np.array_equal(got, want)
+    m = 0 if gpu_rows is None else min(single, len(gpu_rows))
+    if m and not np.array_equal(got[:m], gpu_rows[:m]):
+        raise SystemExit("PARITY FAILURE: GPU signatures differ from the oracle on the cpu_baseline sample")
     cores = _usable_cores()
     per = max(2_000, sample // 8)  # sets per process: 1.5-3 s of numpy each, 41 MB of tokens
     out = {
@@ -317,6 +328,7 @@ def cpu_baseline(O, tokens, a, b, sample, k, t, seed=1):
         "single_core_sample": f"first {single} sets of the benchmark corpus, {dt:.1f} s",
         "host_cpus": os.cpu_count(),
         "c_oracle_single_core_value": single / cdt,
+        "rows_equal_to_gpu": int(m),
     })
     return out
 

@@ -5,7 +5,7 @@
 
 Prints one JSON object per measurement: kernel-only time from HIP events on the context's stream,
 algorithmic bytes and the implied GB/s.  Every result is first checked
-against the oracle on a sample.  Not the driver's bench (that is bench.py).
+against the package's numpy path (gpu_mode="disable") on a sample.  Not the driver's bench (that is bench.py).
 """
 from __future__ import annotations
 
@@ -21,8 +21,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from datasketch_amd import WeightedMinHashGenerator, _native  # noqa: E402
-from oracle import oracle as O  # noqa: E402
+from datasketch_amd import MinHash, WeightedMinHashGenerator, _native, prehashed  # noqa: E402
+from datasketch_amd import lsh_bulk as LB  # noqa: E402
+from datasketch_amd.b_bit_minhash import pack_matrix  # noqa: E402
 
 
 def timed(ctx, fn, reps=5, warmup=1):
@@ -68,7 +69,8 @@ def weighted(ctx, n_rows, dim, s, density):
     ms = timed(ctx, run, reps=3)
     got = d_out.download((n_rows, s, 2), np.int64)
     chk = min(n_rows, 64)
-    want, _ = O.c_weighted_minhash_many(indptr[: chk + 1], indices[: indptr[chk]], csr.data[: indptr[chk]], g.rs, g.ln_cs, g.betas)
+    host = WeightedMinHashGenerator(dim, s, seed=g.seed, gpu_mode="disable")  # the package's numpy path = the reference's arithmetic
+    want, _ = host._minhash_many_host(indptr[: chk + 1], indices[: indptr[chk]], csr.data[: indptr[chk]])
     assert np.array_equal(got[:chk], want), "weighted parity failure"
     nnz = int(indices.size)
     report(f"weighted_minhash_many dim={dim} S={s} density={density}", ms, n_rows, "vectors", 4 * nnz + 16 * s * n_rows,
@@ -86,20 +88,19 @@ def packing(ctx, n, k):
         d_out = ctx.alloc(n * nb.value * 8)
         ms = timed(ctx, lambda: _native.check(lib.mhx_bbit_pack_dev(ctx.handle, d_sig.ptr, n, k, b, d_out.ptr)))
         got = d_out.download((n, nb.value), np.uint64)
-        assert np.array_equal(got[:512], O.c_bbit_pack(sig[:512], b))
+        assert np.array_equal(got[:512], pack_matrix(sig[:512], b, gpu_mode="disable"))
         report(f"bbit_pack b={b} K={k}", ms, n, "signatures", n * (8 * k + 8 * nb.value))
     for bands, r in ((32, 8), (k // 4, 4)):
         d_out = ctx.alloc(n * bands * r * 8)
         ms = timed(ctx, lambda: _native.check(lib.mhx_band_keys_dev(ctx.handle, d_sig.ptr, n, k, bands, r, d_out.ptr)))
         got = d_out.download((n, bands * r), np.uint64)
-        assert np.array_equal(got[:512], O.c_band_keys(sig[:512], bands, r))
+        assert got[:512].tobytes() == LB.band_keys(sig[:512], bands, r, gpu_mode="disable").tobytes()
         report(f"band_keys bands={bands} r={r} K={k}", ms, n, "signatures", n * 16 * bands * r)
     d_out = ctx.alloc(n * (12 + 4 * k))
     ms = timed(ctx, lambda: _native.check(lib.mhx_lean_serialize_dev(ctx.handle, d_sig.ptr, n, k, 1, d_out.ptr)))
     report(f"lean_serialize K={k}", ms, n, "signatures", n * (8 * k + 12 + 4 * k))
     d_dig = ctx.alloc(n * 32 * 8)
     ms = timed(ctx, lambda: _native.check(lib.mhx_band_digests_dev(ctx.handle, d_sig.ptr, n, k, 32, 8, d_dig.ptr)))
-    from datasketch_amd import lsh_bulk as LB
     assert np.array_equal(d_dig.download((n, 32), np.uint64)[:256], LB.band_digests(sig[:256], 32, 8, gpu_mode="disable"))
     report(f"band_digests bands=32 r=8 K={k}", ms, n, "signatures", n * (8 * k + 8 * 32))
     d_sd, d_sr = ctx.alloc(n * 32 * 8), ctx.alloc(n * 32 * 4)
@@ -124,12 +125,12 @@ def minhash_shapes(ctx):
     rng = np.random.RandomState(3)
     for n, t, k in ((1000, 64, 16), (1_000_000, 256, 256), (200_000, 256, 512), (1, 50_000, 128), (1, 50_000, 256), (1, 50_000, 512), (64, 100_000, 128)):
         tok = rng.randint(0, 2**32, (n, t), dtype=np.uint64)
-        a, b = O.np_init_permutations(k, 1)
+        a, b = MinHash(num_perm=k, seed=1).permutations
         d_tok, d_out = ctx.to_device(tok), ctx.alloc(n * k * 8)
         ms = timed(ctx, lambda: ctx.minhash_bulk_dev((a, b), d_tok.ptr, _native.MHX_U64, None, t, n, n * t, None, 0, d_out.ptr, _native.MHX_U64))
         got = d_out.download((n, k), np.uint64)
         chk = min(n, 256)
-        assert np.array_equal(got[:chk], O.c_minhash_bulk_dense(tok[:chk], a, b))
+        assert np.array_equal(got[:chk], MinHash.bulk_signatures(tok[:chk], num_perm=k, seed=1, hashfunc=prehashed, gpu_mode="disable"))
         report(f"minhash_bulk N={n} T={t} K={k}", ms, n, "signatures", n * (8 * t + 8 * k), pairs_per_s=n * t * k / (ms * 1e-3))
         if n == 1:
             t0 = time.perf_counter()
@@ -141,7 +142,7 @@ def minhash_ragged(ctx):
     """Realistic corpora: ragged sets (CSR), and sets with repeated tokens (failed sieve proofs)."""
     rng = np.random.RandomState(7)
     k = 128
-    a, b = O.np_init_permutations(k, 1)
+    a, b = MinHash(num_perm=k, seed=1).permutations
     for name, n, lo, hi, dup in (("ragged 32..480", 500_000, 32, 480, 0.0), ("ragged 1..100", 1_000_000, 1, 100, 0.0),
                                  ("dense 256 with 10% repeated tokens", 500_000, 256, 256, 0.1)):
         lens = rng.randint(lo, hi + 1, size=n).astype(np.int64)
@@ -160,7 +161,7 @@ def minhash_ragged(ctx):
         run()
         c = ctx.counters(False)
         got = d_out.download((n, k), np.uint64)
-        assert np.array_equal(got[:256], O.c_minhash_bulk(hv[: off[256]], off[:257], a, b))
+        assert np.array_equal(got[:256], MinHash.bulk_signatures((hv[: off[256]], off[:257]), num_perm=k, seed=1, hashfunc=prehashed, gpu_mode="disable"))
         report(f"minhash_bulk {name} N={n} K={k}", ms, n, "signatures", 8 * hv.size + 8 * k * n, pairs_per_s=hv.size * k / (ms * 1e-3),
                tokens=int(hv.size), **c)
 
@@ -221,7 +222,6 @@ def reference_gpu_benchmark(ctx):
 
 def lsh(ctx, n):
     """Candidate pairs by sort (rows f1/f4): a corpus with near-duplicate rows, K=128, (b, r) = (32, 4)."""
-    from datasketch_amd import lsh_bulk as LB
 
     rng = np.random.RandomState(21)
     k, b, r = 128, 32, 4
