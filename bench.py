@@ -67,7 +67,12 @@ def main():
 
     if args.allgather:  # RCCL must enter the process before torch's own ROCm runtime does (mhx_ctx_create loads it)
         os.environ.setdefault("MHX_PRELOAD_RCCL", "1")
-    ctx = _native.Context(local_rank)
+    visible = _native.device_count()
+    if visible < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    # one GPU per rank: LOCAL_RANK indexes the visible devices; a launcher that already narrowed the
+    # visibility to one device per process (HIP_VISIBLE_DEVICES) leaves device 0
+    ctx = _native.Context(local_rank if local_rank < visible else local_rank % visible)
     for kv in args.opt:
         key, _, val = kv.partition("=")
         ctx.set_option(key, int(val))
