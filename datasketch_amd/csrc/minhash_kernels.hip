@@ -653,7 +653,7 @@ __device__ __forceinline__ Minima<P> full_minima(const TokT *hv_vec, int64_t beg
 // Sieve over the full 16-token rows of [beg,end) plus fast fold for the ragged tail.  Returns true
 // (wave-uniform) when a proof failed or a tail minimum is ambiguous: the caller then redoes the
 // range with full_minima.
-template <int P, typename TokT>
+template <int P, typename TokT, bool TAIL = true>
 __device__ __forceinline__ bool sieve_minima(const TokT MHX_CONST_AS *hv, const TokT *hv_vec, int64_t beg,
                                              int64_t end, const Perms<P> &pm, const Perms<P> &pm_biased,
                                              const SievePerms<P> &sp, unsigned long long *stats, int lane,
@@ -669,7 +669,7 @@ __device__ __forceinline__ bool sieve_minima(const TokT MHX_CONST_AS *hv, const 
         if (stats && lane == 0) atomicAdd(stats + 2, (unsigned long long)nblocks);
     }
     const int64_t tail = beg + (int64_t)nrows * kRowTokens;
-    if (tail < end) {
+    if (TAIL && tail < end) {  // TAIL == false: the caller guarantees whole rows (no fast-fold code, 48 instead of 73 VGPRs)
         uint32_t acc[P];
 #pragma unroll
         for (int p = 0; p < P; ++p) acc[p] = kMaxHash;
@@ -765,13 +765,14 @@ __device__ __forceinline__ void load_perms(const BulkArgs &args, int kbase, int 
 //   MODE_FULL   the full evaluation (fast fold + exact redo, or the exact fold with path 1) for the
 //               listed sets -- or for every set when the sieve is switched off.
 enum { MODE_SIEVE = 0, MODE_FULL = 1 };
-enum { SHAPE_GENERAL = 0, SHAPE_PLAIN = 1, SHAPE_PLAIN_FIXED = 2 };
+enum { SHAPE_GENERAL = 0, SHAPE_PLAIN = 1, SHAPE_PLAIN_FIXED = 2, SHAPE_PLAIN_FIXED_ROWS = 3 };
 
 template <int P, typename TokT, typename OutT, int MODE, int SHAPE>
 __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_in) {
-    // SHAPE_PLAIN: no initial state, no counters, no aliasing; SHAPE_PLAIN_FIXED: and fixed-length sets.  The
-    // fields become compile-time constants, so their SGPRs (the kernel spills 49 of them, 32 when plain)
-    // and address arithmetic leave the per-set path: 2 % of the headline launch.
+    // SHAPE_PLAIN: no initial state, no counters, no aliasing; SHAPE_PLAIN_FIXED: and fixed-length sets;
+    // SHAPE_PLAIN_FIXED_ROWS: and the length is a multiple of 16, so the fast-fold code for a ragged tail is
+    // not compiled in at all.  The fields become compile-time constants, so their SGPRs and address arithmetic
+    // leave the per-set path (spilled SGPRs 49 -> 32 -> 4, VGPRs 78 -> 73 -> 53): 3 % of the headline launch.
     BulkArgs args = args_in;
     if (SHAPE != SHAPE_GENERAL) {
         args.init = nullptr;
@@ -779,7 +780,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
         args.stats = nullptr;
         args.alias_mask = -1;
     }
-    if (SHAPE == SHAPE_PLAIN_FIXED) args.offsets = nullptr;
+    if (SHAPE == SHAPE_PLAIN_FIXED || SHAPE == SHAPE_PLAIN_FIXED_ROWS) args.offsets = nullptr;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_block = blockDim.x >> 6;
@@ -853,7 +854,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
             if (MODE == MODE_SIEVE) {
                 if (kchunks > 1) load_perms<P>(args, kc * (kWave * P), lane, pm, pm_biased, sp, kidx);
                 if (end > beg) {
-                    defer = sieve_minima<P, TokT>(hv, hv_vec, beg, end, pm, pm_biased, sp, args.stats, lane, lds, res);
+                    defer = sieve_minima<P, TokT, SHAPE != SHAPE_PLAIN_FIXED_ROWS>(hv, hv_vec, beg, end, pm, pm_biased, sp, args.stats, lane, lds, res);
                     if (defer) {
                         backoff.failed();
                         break;
@@ -1046,7 +1047,9 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_
             // sieve launch (writes a flag per set), then the full evaluation of the flagged sets (usually a
             // handful: that launch reads n_sets bytes and returns)
             const bool plain = !args.init && !args.stats && args.alias_mask < 0;
-            if (plain && !args.offsets)
+            if (plain && !args.offsets && args.fixed_len % kRowTokens == 0)  // whole 16-token rows: no tail code in the kernel
+                hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN_FIXED_ROWS>), grid, dim3(256), 0, ctx->stream, args);
+            else if (plain && !args.offsets)
                 hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN_FIXED>), grid, dim3(256), 0, ctx->stream, args);
             else if (plain)
                 hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN>), grid, dim3(256), 0, ctx->stream, args);
@@ -1087,7 +1090,8 @@ int launch_p(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_t to
     // 122 VGPRs) while the full launch stays at 2 (with 4 it would need 220 VGPRs)
     if (args.num_perm <= 64) return launch_typed<1, TokT, OutT>(ctx, args, first_token, total_tokens, split);
     const int slots4 = (args.num_perm + 255) / 256 * 256, slots2 = (args.num_perm + 127) / 128 * 128;  // lanes x P x passes
-    if (args.num_perm > 128 && !split && slots4 <= slots2)
+    // (uint64 tokens only: with uint32 tokens -- a row per chunk, two rows per loop body -- four permutations need 207 VGPRs)
+    if (args.num_perm > 128 && !split && slots4 <= slots2 && sizeof(TokT) == 8)
         return launch_typed<4, TokT, OutT, 2>(ctx, args, first_token, total_tokens, split);
     return launch_typed<2, TokT, OutT>(ctx, args, first_token, total_tokens, split);
 }
