@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- MinHash signatures/sec on MI355X (BASELINE.json metric), one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          # N > 1: spawns its own N ranks
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -9,19 +9,29 @@ Workload (BASELINE.json configs[1]): 1M sets x 256 tokens, num_perm=128 per GPU,
 pre-hashed tokens ``RandomState(42+rank).randint(0, 2**32, (N, T), uint64)``, seed=1.  A "step"
 is one pass of the hot path (``mhx_minhash_bulk_dev``) over the whole resident corpus, producing
 the [N, K] uint64 signature matrix in HBM.  Inputs are in HBM before the timed region starts.
-Weak scaling: every rank hashes its own 1M-set shard; there is no collective in the data path
-(``--allgather`` adds the RCCL all-gather of the shards after every step, the config-3 shape).
+Weak scaling: every rank hashes its own 1M-set shard; there is no collective in the data path, so
+``value`` is the compute-only rate.  At N > 1 the config-3 exchange step -- one RCCL all-gather of the
+uint32 shards over xGMI -- is measured on its own after the timed region and reported under
+``allgather`` (ms, bytes, ranks RCCL itself counts); ``--allgather`` puts it inside every step.
+
+No PyTorch anywhere: ranks find each other over datasketch_amd.rendezvous (TCP; MASTER_ADDR /
+MASTER_PORT of the launcher, or the port the self-spawning parent picked), which carries the
+barriers, the max-over-ranks reduction and the 128-byte RCCL id.
 
 Prints ONE JSON line on rank 0.  ``roofline.achieved`` = algorithmic bytes (8*T + 8*K per
 signature) / average launch duration measured with HIP events on the
 kernel's own stream.  ``cpu_baseline`` = the numpy restatement of the reference's CPU path
-(oracle/, kind "port") timed on a bounded sample on this host, rank 0, N=1 only.
+(oracle/, kind "port") timed on a bounded sample on this host, rank 0, N=1 only.  ``extra`` (N=1)
+holds the other BASELINE configs at their per-GPU shapes, each HIP-event timed and parity-gated:
+``c3`` (1.25M x 256, K=256 + LSH band digests + sort), ``c4`` (weighted, 100k x 4096, S=128),
+``c5`` (b=1 packing + band digests of the 1.25M x 256 matrix).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,9 +41,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic_minhash_bulk.json")
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -42,64 +53,75 @@ def parse_args():
     ap.add_argument("--tokens", type=int, default=256)
     ap.add_argument("--num-perm", type=int, default=128)
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--allgather", action="store_true", help="RCCL all-gather of the shards inside every step")
-    ap.add_argument("--check-rows", type=int, default=4096, help="rows verified against the oracle")
+    ap.add_argument("--allgather", action="store_true", help="RCCL all-gather of the uint32 shards inside every step")
+    ap.add_argument("--no-allgather-probe", action="store_true", help="N > 1: skip the separate all-gather measurement")
+    ap.add_argument("--check-rows", type=int, default=4096, help="rows verified against the numpy path")
     ap.add_argument("--cpu-sample", type=int, default=160_000, help="sets timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive host->host measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the config 3/4/5 entries (N=1 only anyway)")
+    ap.add_argument("--extra-only", default="", help="comma list out of c3,c4,c5 (default: all)")
     ap.add_argument("--u32", action="store_true", help="compact variant: uint32 tokens in, uint32 signatures out")
+    ap.add_argument("--share-devices", action="store_true", help="testing only: let several ranks use one GPU (no RCCL then)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="libmhx tuning knob (mhx_ctx_set_option), e.g. blocks_per_cu=4")
-    return ap.parse_args()
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: this process spawns the ranks (plain subprocesses, LOCAL_RANK -> device,
+# HIP_VISIBLE_DEVICES untouched) and hands them a rendezvous port; rank 0 prints the JSON line.
+def spawn_ranks(args) -> int:
+    from datasketch_amd import rendezvous
+
+    port = rendezvous.free_port()
+    procs = []
+    for rank in range(args.gpus):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MHX_RDZV_ADDR=f"127.0.0.1:{port}")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    deadline = time.time() + float(os.environ.get("MHX_BENCH_TIMEOUT", "1500"))
+    for p in procs:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+        rc = rc or p.returncode
+    return rc
 
 
 def main():
     args = parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N`")
+    if "RANK" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
 
-    # libmhx (system ROCm runtime) is loaded before torch so that both share one HIP runtime.
-    from datasketch_amd import _native
+    from datasketch_amd import _native, rendezvous
     from datasketch_amd.minhash import MinHash
 
-    if args.allgather:  # RCCL must enter the process before torch's own ROCm runtime does (mhx_ctx_create loads it)
-        os.environ.setdefault("MHX_PRELOAD_RCCL", "1")
+    group = rendezvous.from_env()
+    world, rank = group.world, group.rank
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     visible = _native.device_count()
     if visible < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     # one GPU per rank: LOCAL_RANK indexes the visible devices; a launcher that already narrowed the
     # visibility to one device per process (HIP_VISIBLE_DEVICES) leaves device 0
-    ctx = _native.Context(local_rank if local_rank < visible else local_rank % visible)
+    shared = local_world > visible and visible != 1
+    if local_world > visible and visible == 1 and "HIP_VISIBLE_DEVICES" not in os.environ and "ROCR_VISIBLE_DEVICES" not in os.environ:
+        shared = True
+    if shared and not args.share_devices:
+        raise SystemExit(f"{local_world} ranks on this node but only {visible} visible GPU(s): one GPU per rank "
+                         "(--share-devices lets ranks share a GPU for plumbing tests; the numbers then mean nothing)")
+    ctx = _native.Context(local_rank % visible)
     for kv in args.opt:
         key, _, val = kv.partition("=")
         ctx.set_option(key, int(val))
 
-    dist = None
-    torch = None
-    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
-        import torch  # noqa: F811  (plumbing only: rendezvous, barrier, max-over-ranks)
-        import torch.distributed as dist  # noqa: F811
-
-        # gloo: PyTorch never touches the GPU here; RCCL traffic (--allgather) goes through libmhx
-        backend = os.environ.get("MHX_BENCH_BACKEND", "gloo")
-        if backend == "nccl":
-            torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
-
-    def barrier():
-        if dist is not None:
-            if dist.get_backend() == "nccl":
-                dist.barrier(device_ids=[local_rank])
-            else:
-                dist.barrier()
-
     def sync():
         ctx.synchronize()
-        if torch is not None and torch.cuda.is_initialized():
-            torch.cuda.synchronize()
 
     n, t, k = args.sets, args.tokens, args.num_perm
     proto = MinHash(num_perm=k, seed=args.seed, hashfunc=lambda x: x)
@@ -118,13 +140,19 @@ def main():
     ctx.perm_handle(perms)
 
     gather = None
-    if args.allgather:
-        gather = setup_allgather(ctx, dist, torch, d_out, n * k * out_bytes, world, rank)
+    gather_error = None
+    if args.allgather and world > 1:
+        try:
+            gather = AllGather(ctx, group, n, k)
+        except Exception as e:  # noqa: BLE001 -- RCCL trouble must not take the compute numbers down with it
+            gather_error = repr(e)
+        if any(group.allgather(b"\x01" if gather is None else b"\x00")[r] == b"\x01" for r in range(world)):
+            gather = None  # all ranks or none
 
     def step():
         ctx.minhash_bulk_dev(perms, d_tok.ptr, tok_dtype, None, t, n, n * t, None, 0, d_out.ptr, out_dtype)
         if gather is not None:
-            gather()
+            gather.step(perms, d_tok, tok_dtype, t)
 
     for _ in range(args.warmup):
         step()
@@ -132,7 +160,7 @@ def main():
 
     # ---- timed region: exactly K steps, barrier + sync on both sides, max over ranks
     evs = [ctx.event() for _ in range(args.steps + 1)]
-    barrier()
+    group.barrier()
     sync()
     t0 = time.perf_counter()
     evs[0].record()
@@ -140,14 +168,13 @@ def main():
         step()
         evs[i + 1].record()
     sync()
-    elapsed = time.perf_counter() - t0  # this rank's K steps, device work complete
-    barrier()                           # closing barrier; the job's time is the MAX over ranks below
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed_rank = time.perf_counter() - t0  # this rank's K steps, device work complete
+    group.barrier()                          # closing barrier; the job's time is the MAX over ranks below
+    per_rank = [float(np.frombuffer(p, dtype=np.float64)[0]) for p in group.allgather(np.float64(elapsed_rank).tobytes())]
+    elapsed = max(per_rank)
     launch_ms = [evs[i].elapsed_ms(evs[i + 1]) for i in range(args.steps)]
     kernel_ms = float(np.mean(launch_ms))
+    kernel_ms_ranks = [float(np.frombuffer(p, dtype=np.float64)[0]) for p in group.allgather(np.float64(kernel_ms).tobytes())]
 
     # ---- one counted launch outside the timed region: how often the sieve's proof failed
     ctx.counters(True)
@@ -194,12 +221,21 @@ def main():
             "num_perm": k,
             "token_dtype": "uint32" if args.u32 else "uint64",
             "signature_dtype": "uint32" if args.u32 else "uint64",
-            "parallelism": f"shard{world}" + ("+allgather" if args.allgather else ""),
+            "parallelism": f"shard{world}" + ("+allgather" if gather is not None else ""),
+            "launcher": "torch.distributed.run env" if "TORCHELASTIC_RUN_ID" in os.environ else ("self-spawned ranks" if world > 1 else "single process"),
+            "rendezvous": "datasketch_amd.rendezvous (TCP, no PyTorch)",
             "parity_rows_checked": int(check),
             "sets_redone_by_full_evaluation": counters["sieve_sets_redone"],
             "sets_redone_by_exact_fold": counters["exact_sets_redone"],
         },
+        "per_rank": {
+            "ms_per_step": [1e3 * x / args.steps for x in per_rank],
+            "kernel_ms": kernel_ms_ranks,
+            "devices": [p.decode() for p in group.allgather(("%d:%s" % (ctx.device, ctx.info()["name"])).encode())],
+        },
     }
+    if gather_error:
+        out["allgather_error"] = gather_error
     alg_bytes = n * (tok_bytes * t + out_bytes * k)  # 8*T + 8*K per signature
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
     pair_rate = n * t * k / (kernel_ms * 1e-3)
@@ -216,6 +252,10 @@ def main():
         "note": "integer-VALU-bound kernel: (token,perm) pair evaluations/s = %.3e" % pair_rate,
     }
 
+    # ---- N > 1: the exchange step of config 3 on its own (uint32 shards, RCCL over xGMI)
+    if world > 1 and not args.no_allgather_probe:
+        out["allgather"] = allgather_probe(ctx, group, gather, perms, d_tok, tok_dtype, n, t, k)
+
     if rank == 0 and world == 1:
         if not args.no_e2e:
             # host numpy in -> host numpy out through mhx_minhash_bulk (pageable memory): the first call
@@ -227,25 +267,117 @@ def main():
             ctx.minhash_bulk(perms, tokens.reshape(-1), None, t, n, None, out=host_out)
             out["pcie_inclusive_value"] = n / (time.perf_counter() - t1)
             del host_out
+            # uint32 tokens in, uint32 signatures out (the range sha1_hash32 produces): half the bytes on the link
+            tok32 = tokens.astype(np.uint32).reshape(-1)
+            host32 = np.empty((n, k), dtype=np.uint32)
+            ctx.minhash_bulk(perms, tok32, None, t, n, None, out=host32)
+            t1 = time.perf_counter()
+            ctx.minhash_bulk(perms, tok32, None, t, n, None, out=host32)
+            out["pcie_inclusive_u32_value"] = n / (time.perf_counter() - t1)
+            if sig_head is not None and not np.array_equal(host32[: len(sig_head)], sig_head.astype(np.uint32)):
+                raise SystemExit("PARITY FAILURE: uint32 host entry differs from the uint64 device path")
+            del tok32, host32
+            ctx.release_scratch()
         if args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(tokens, a, b, min(args.cpu_sample, n), k, t, sig_head, seed=args.seed)
-    if dist is not None:
-        barrier()
-        dist.destroy_process_group()
+        if not args.no_extra:
+            d_out.free()
+            only = [x for x in args.extra_only.split(",") if x] or ["c3", "c5", "c4"]
+            out["extra"] = extra_configs(ctx, tokens, d_tok, args.seed, only)
+    group.barrier()
+    group.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
 
 
 def measured_traffic(n, t, k, args):
     """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_traffic_minhash_bulk.json); None for any other shape."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic_minhash_bulk.json")
-    if (n, t, k) != (1_000_000, 256, 128) or args.u32 or not os.path.exists(path):
+    (profiles/r02_traffic_minhash_bulk.json); None for any other shape."""
+    if (n, t, k) != (1_000_000, 256, 128) or args.u32 or not os.path.exists(TRAFFIC_FILE):
         return None
-    with open(path) as f:
+    with open(TRAFFIC_FILE) as f:
         return json.load(f).get("traffic_bytes_per_launch")
 
 
+# ------------------------------------------------------------------------------------------------
+class AllGather:
+    """RCCL all-gather of this rank's uint32 [n, k] signature shard into a [world, n, k] device buffer, through
+    libmhx's own binding (mhx_comm_*): enqueued on the kernel's stream.  The 128-byte RCCL id travels over the
+    rendezvous group."""
+
+    def __init__(self, ctx, group, n, k):
+        from datasketch_amd import dist
+
+        self.ctx, self.group, self.n, self.k = ctx, group, n, k
+        self.comm = dist.communicator(ctx, group)
+        self.shard_bytes = n * k * 4
+        self.d_shard = ctx.alloc(self.shard_bytes)
+        self.d_all = ctx.alloc(self.shard_bytes * group.world)
+
+    def step(self, perms, d_tok, tok_dtype, t):
+        from datasketch_amd import _native
+
+        self.ctx.minhash_bulk_dev(perms, d_tok.ptr, tok_dtype, None, t, self.n, self.n * t, None, 0, self.d_shard.ptr, _native.MHX_U32)
+        self.comm.allgather_dev(self.d_shard.ptr, self.d_all.ptr, self.shard_bytes)
+
+    def gather_only(self):
+        self.comm.allgather_dev(self.d_shard.ptr, self.d_all.ptr, self.shard_bytes)
+
+
+def allgather_probe(ctx, group, gather, perms, d_tok, tok_dtype, n, t, k, reps=5):
+    """The exchange step alone: every rank's uint32 shard to every rank.  Reports what RCCL itself says about the
+    communicator and checks the gathered matrix: row 0 of every rank's block must be that rank's row 0."""
+    from datasketch_amd import _native
+
+    res = {"wire_dtype": "uint32", "bytes_per_rank": n * k * 4, "bytes_received_per_gpu": n * k * 4 * (group.world - 1)}
+    err = None
+    try:
+        if gather is None:
+            gather = AllGather(ctx, group, n, k)
+        ctx.minhash_bulk_dev(perms, d_tok.ptr, tok_dtype, None, t, n, n * t, None, 0, gather.d_shard.ptr, _native.MHX_U32)
+        gather.gather_only()  # warm-up (RCCL builds its rings / channels on first use)
+        ctx.synchronize()
+    except Exception as e:  # noqa: BLE001
+        err = repr(e)
+    flags = group.allgather((err or "").encode())
+    if any(flags):
+        res["error"] = [f.decode() for f in flags]
+        return res
+    group.barrier()
+    evs = [ctx.event() for _ in range(reps + 1)]
+    evs[0].record()
+    for i in range(reps):
+        gather.gather_only()
+        evs[i + 1].record()
+    ctx.synchronize()
+    ms = [evs[i].elapsed_ms(evs[i + 1]) for i in range(reps)]
+    all_ms = [float(np.frombuffer(p, dtype=np.float64)[0]) for p in group.allgather(np.float64(np.mean(ms)).tobytes())]
+    info = gather.comm.info()
+    seen = group.allgather_ints([info["ranks_seen"], info["rank"], info["device"]])
+    my_row0 = gather.d_shard.download((k,), np.uint32)
+    rows0 = [np.frombuffer(p, dtype=np.uint32) for p in group.allgather(my_row0.tobytes())]
+    ok = True
+    for r in range(group.world):
+        got = gather.d_all.download((k,), np.uint32, offset=r * gather.shard_bytes)
+        ok = ok and np.array_equal(got, rows0[r])
+    oks = group.allgather(b"\x01" if ok else b"\x00")
+    if not all(o == b"\x01" for o in oks):
+        raise SystemExit("PARITY FAILURE: the all-gathered matrix does not hold every rank's shard")
+    worst = max(all_ms)
+    res.update({
+        "ms": worst,
+        "ms_per_rank": all_ms,
+        "rccl_ranks_seen": [s[0] for s in seen],
+        "rccl_rank_device": [[s[1], s[2]] for s in seen],
+        "rccl_version": info["rccl_version"],
+        "received_GBps_per_gpu": res["bytes_received_per_gpu"] / (worst * 1e-3) / 1e9,
+        "signatures_per_s_with_allgather_after_compute": None,
+        "checked": "row 0 of every rank's block on every rank",
+    })
+    return res
+
+
+# ------------------------------------------------------------------------------------------------
 def _cpu_worker(args):
     """One host core of the all-cores baseline: the numpy per-set loop of MinHash.bulk on its own
     shard (generated in the worker: nothing but a checksum travels)."""
@@ -281,6 +413,25 @@ def _usable_cores(cap=64):
         except (OSError, ValueError, IndexError):
             continue
     return max(1, min(n, cap))
+
+
+def cpu_model() -> str:
+    """`lscpu`'s model name (SURVEY.md section 8d asks for it next to the CPU number)."""
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        for line in txt.splitlines():
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except (OSError, subprocess.SubprocessError):
+        pass
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(tokens, a, b, sample, k, t, gpu_rows, seed=1):
@@ -332,30 +483,247 @@ def cpu_baseline(tokens, a, b, sample, k, t, gpu_rows, seed=1):
         "single_core_value": single / dt,
         "single_core_sample": f"first {single} sets of the benchmark corpus, {dt:.1f} s",
         "host_cpus": os.cpu_count(),
+        "cpu_model": cpu_model(),
         "c_oracle_single_core_value": single / cdt,
         "rows_equal_to_gpu": int(m),
     })
     return out
 
 
-def setup_allgather(ctx, dist, torch, d_out, shard_bytes, world, rank):
-    """All-gather of the signature shards with RCCL through libmhx's own binding (mhx_comm_*,
-    include/mhx.h): enqueued on the kernel's stream, so it starts the moment the shard is complete.
-    torch.distributed (gloo, CPU) only carries the 128-byte RCCL id from rank 0 to the others."""
-    if dist is None:
-        raise SystemExit("--allgather needs a torch.distributed launch (torchrun), also for 1 GPU")
+# ------------------------------------------------------------------------------------------------
+def _timed(ctx, fn, reps=3):
+    """Average HIP-event time of `fn` (enqueues on ctx's stream) over `reps` runs after one warm-up, in ms."""
+    fn()
+    evs = [ctx.event() for _ in range(reps + 1)]
+    evs[0].record()
+    for i in range(reps):
+        fn()
+        evs[i + 1].record()
+    ctx.synchronize()
+    return float(np.mean([evs[i].elapsed_ms(evs[i + 1]) for i in range(reps)]))
+
+
+def _roof(alg_bytes, ms):
+    ach = alg_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": int(alg_bytes), "kernel_ms": ms}
+
+
+def extra_configs(ctx, tokens, d_tok, seed, only):
+    """BASELINE.json configs 3, 4, 5 at their per-GPU shapes (the 8-GPU configs divide by 8), each timed with HIP
+    events and parity-gated on a sample: a wrong result aborts the bench."""
+    import ctypes
+
     from datasketch_amd import _native
+    from datasketch_amd.minhash import MinHash
+    from oracle import oracle as O
 
-    box = [_native.Communicator.unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0)
-    comm = _native.Communicator(ctx, box[0], rank, world)
-    d_all = ctx.alloc(shard_bytes * world)
+    lib = ctx.lib
+    res = {}
+    n3, t, k3, bands, r = 1_250_000, tokens.shape[1], 256, 32, 8
+    state = {}
 
-    def gather():
-        comm.allgather_dev(d_out.ptr, d_all.ptr, shard_bytes)
+    def c3_corpus():
+        # the config-2 corpus (already resident) + 250k more rows = one rank's 1.25M-set shard of config 3
+        if "d_tok3" not in state:
+            more = np.random.RandomState(4242).randint(0, 2**32, size=(n3 - tokens.shape[0], t), dtype=np.uint64)
+            d = ctx.alloc(n3 * t * 8)
+            ctx.copy_dev(d.ptr, d_tok.ptr, tokens.size * 8)
+            d.upload(more, offset=tokens.size * 8)
+            state["d_tok3"], state["more"] = d, more
+            p3 = MinHash(num_perm=k3, seed=seed, hashfunc=lambda x: x).permutations
+            state["perms3"] = p3
+            state["d_sig3"] = ctx.alloc(n3 * k3 * 4)
+            ctx.minhash_bulk_dev(p3, d.ptr, _native.MHX_U64, None, t, n3, n3 * t, None, 0, state["d_sig3"].ptr, _native.MHX_U32)
+        return state
 
-    gather.keepalive = (comm, d_all)
-    return gather
+    def sample_rows():
+        rows = np.unique(np.concatenate([np.linspace(0, tokens.shape[0] - 1, 384).astype(np.int64),
+                                         np.arange(tokens.shape[0], tokens.shape[0] + 128)]))
+        tok = np.concatenate([tokens[rows[rows < tokens.shape[0]]], state["more"][: 128]])
+        return rows, tok
+
+    if "c3" in only:
+        st = c3_corpus()
+        p3, d3, dsig = st["perms3"], st["d_tok3"], st["d_sig3"]
+        ms_sig = _timed(ctx, lambda: ctx.minhash_bulk_dev(p3, d3.ptr, _native.MHX_U64, None, t, n3, n3 * t, None, 0, dsig.ptr, _native.MHX_U32))
+        d_dig = ctx.alloc(n3 * bands * 8)
+        d_sd = ctx.alloc(n3 * bands * 8)
+        d_sr = ctx.alloc(n3 * bands * 4)
+        ms_dig = _timed(ctx, lambda: _native.check(lib.mhx_band_digests_dev_typed(ctx.handle, dsig.ptr, _native.MHX_U32, n3, k3, bands, r, d_dig.ptr)))
+        ms_sort = _timed(ctx, lambda: _native.check(lib.mhx_lsh_sort_bands_dev_typed(ctx.handle, dsig.ptr, _native.MHX_U32, n3, k3, bands, r, d_sd.ptr, d_sr.ptr)))
+        # parity: signature rows against the C oracle, digests against FNV-1a of the reference's key bytes, order of the sort
+        rows, tok = sample_rows()
+        a3, b3 = p3
+        want = O.c_minhash_bulk_dense(tok, a3, b3)
+        sig = dsig.download((n3, k3), np.uint32)
+        if not np.array_equal(sig[rows].astype(np.uint64), want):
+            raise SystemExit("PARITY FAILURE (extra.c3): K=256 signatures differ from the oracle")
+        keys = O.c_band_keys(want[:64], bands, r)
+        dig = d_dig.download((n3, bands), np.uint64)
+        for i in range(64):
+            for j in range(bands):
+                if int(dig[rows[i], j]) != _fnv1a64(keys[i, j * r:(j + 1) * r].tobytes()):
+                    raise SystemExit("PARITY FAILURE (extra.c3): band digest differs from FNV-1a-64 of the reference's key bytes")
+        sd = d_sd.download((bands, n3), np.uint64)
+        sr = d_sr.download((bands, n3), np.uint32)
+        for j in (0, bands - 1):
+            if np.any(sd[j, 1:] < sd[j, :-1]) or not np.array_equal(dig[sr[j].astype(np.int64), j], sd[j]):
+                raise SystemExit("PARITY FAILURE (extra.c3): sorted bands are not the digests in ascending order")
+        del sig, dig, sd, sr
+        res["c3"] = {
+            "workload": f"config 3 per-GPU shard: {n3} sets x {t} tokens, num_perm={k3} (uint64 tokens in, uint32 signatures out = the all-gather's wire format), then LSH band digests ({bands} bands x {r}) and the bucketing sort",
+            "signatures": dict(_roof(n3 * (8 * t + 4 * k3), ms_sig), signatures_per_s=n3 / (ms_sig * 1e-3),
+                               note="algorithmic bytes 8*T + 4*K per signature (uint32 out); SURVEY 8d's 4096 B/sig assumes uint64 out"),
+            "band_digests": _roof(n3 * (4 * k3 + 8 * bands), ms_dig),
+            "lsh_sort_bands": dict(_roof(n3 * (4 * k3 + 12 * bands), ms_sort), keys_per_s=n3 * bands / (ms_sort * 1e-3),
+                                   note="digests + one radix sort of (band, digest prefix, row) + exact clean-up; bytes = signatures in, (digest, row) out"),
+            "pipeline_ms": ms_sig + ms_sort,
+            "parity": f"{len(rows)} signature rows vs the C oracle, 64 x {bands} digests vs FNV-1a-64 of the reference's key bytes, 2 bands' order",
+        }
+        for d in (d_dig, d_sd, d_sr):
+            d.free()
+
+    if "c5" in only:
+        st = c3_corpus()
+        dsig = st["d_sig3"]
+        nb = k3 // 64
+        d_pack = ctx.alloc(n3 * nb * 8)
+        d_dig = ctx.alloc(n3 * bands * 8)
+        ms_pack = _timed(ctx, lambda: _native.check(lib.mhx_bbit_pack_dev_typed(ctx.handle, dsig.ptr, _native.MHX_U32, n3, k3, 1, d_pack.ptr)))
+        ms_dig = _timed(ctx, lambda: _native.check(lib.mhx_band_digests_dev_typed(ctx.handle, dsig.ptr, _native.MHX_U32, n3, k3, bands, r, d_dig.ptr)))
+        rows, tok = sample_rows()
+        a3, b3 = st["perms3"]
+        want = O.c_minhash_bulk_dense(tok, a3, b3)
+        pack = d_pack.download((n3, nb), np.uint64)
+        if not np.array_equal(pack[rows], O.c_bbit_pack(want, 1)):
+            raise SystemExit("PARITY FAILURE (extra.c5): b=1 blocks differ from the oracle's bBitMinHash packing")
+        del pack
+        res["c5"] = {
+            "workload": f"config 5 per-GPU shard: b=1 packing of {n3} x {k3} signatures (uint32, as all-gathered) + LSH band hashing ({bands} x {r})",
+            "bbit_pack_b1": _roof(n3 * (4 * k3 + k3 // 8), ms_pack),
+            "band_digests": _roof(n3 * (4 * k3 + 8 * bands), ms_dig),
+            "pipeline_ms": ms_pack + ms_dig,
+            "parity": f"{len(rows)} packed rows vs the C oracle (b_bit_minhash.py:82-101 bit order)",
+        }
+        d_pack.free()
+        d_dig.free()
+
+    for key in ("d_tok3", "d_sig3"):
+        if key in state:
+            state[key].free()
+    state.clear()
+
+    if "c4" in only:
+        res["c4"] = extra_c4(ctx)
+    return res
+
+
+def _fnv1a64(data: bytes) -> int:
+    h = 0xCBF29CE484222325
+    for byte in data:
+        h = ((h ^ byte) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def extra_c4(ctx, n=100_000, dim=4096, s=128):
+    """Config 4: WeightedMinHashGenerator(4096, 128, seed=1).minhash_many on X = RandomState(42).uniform(0, 100,
+    (100k, 4096)) float32 -- kernel-only on resident input, and from Python (numpy in, numpy out) in parity mode
+    (np.log on the host) and device-log mode; the device-log mode's (k, t) mismatches against parity mode are
+    counted and gated as BASELINE.md section 3 prescribes."""
+    import scipy.sparse as sp
+
+    from datasketch_amd import WeightedMinHashGenerator, _native
+    from oracle import oracle as O
+
+    rs = np.random.RandomState(42)
+    x = np.empty((n, dim), dtype=np.float32)
+    for i in range(0, n, 10_000):  # the same stream as one call; bounds the float64 temporary
+        x[i:i + 10_000] = rs.uniform(0, 100, (min(10_000, n - i), dim))
+    g = WeightedMinHashGenerator(dim, s, seed=1, gpu_mode="always")
+    gl = WeightedMinHashGenerator(dim, s, seed=1, gpu_mode="always", device_log=True)
+    out = {"workload": f"config 4: {n} dense vectors x dim {dim}, sample_size {s}, float32 (the reference's arithmetic type)"}
+    # from Python, parity mode and device-log mode
+    g.minhash_many_arrays(x[:2048])
+    t0 = time.perf_counter()
+    hv, ne = g.minhash_many_arrays(x)
+    dt_par = time.perf_counter() - t0
+    gl.minhash_many_arrays(x[:2048])
+    t0 = time.perf_counter()
+    hv_l, ne_l = gl.minhash_many_arrays(x)
+    dt_log = time.perf_counter() - t0
+    # kernel only: logs resident on the device
+    lib = ctx.lib
+    _c, handle = g._device_handle()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        logs = np.log(x)
+    d_x = ctx.to_device(logs)
+    d_o = ctx.alloc(n * s * 16)
+    d_ne = ctx.alloc(n)
+    ms = _timed(ctx, lambda: _native.check(lib.mhx_weighted_minhash_many_dense_dev(handle, d_x.ptr, 1, n, d_o.ptr, d_ne.ptr)), reps=2)
+    d_x.upload(x)
+    ms_log = _timed(ctx, lambda: _native.check(lib.mhx_weighted_minhash_many_dense_dev(handle, d_x.ptr, 0, n, d_o.ptr, d_ne.ptr)), reps=2)
+    for d in (d_x, d_o, d_ne):
+        d.free()
+    # parity gate: sample rows against the C oracle (bit-exact (k, t) in parity mode)
+    rows = np.unique(np.linspace(0, n - 1, 48).astype(np.int64))
+    csr = sp.csr_matrix(x[rows])
+    csr.sort_indices()
+    wo, wn = O.c_weighted_minhash_many(csr.indptr, csr.indices, csr.data, g.rs, g.ln_cs, g.betas)
+    if not (np.array_equal(hv[rows], wo) and np.array_equal(ne[rows], wn)):
+        raise SystemExit("PARITY FAILURE (extra.c4): weighted (k, t) differ from the oracle in parity mode")
+    # fast-mode acceptance gate (BASELINE.md section 3): every (k, t) mismatch must come from two smallest ln_a
+    # within 1e-6 relative of each other
+    mism = np.argwhere(np.any(hv != hv_l, axis=2))
+    gate = weighted_gap_gate(x, g, hv, hv_l, mism[:5000])
+    if gate["unexplained"]:
+        raise SystemExit(f"PARITY FAILURE (extra.c4): {gate['unexplained']} device-log mismatches outside the 1e-6 ln_a tolerance")
+    alg = n * (4 * dim + 16 * s)
+    out.update({
+        "kernel": dict(_roof(alg, ms), vectors_per_s=n / (ms * 1e-3), element_evaluations_per_s=n * dim * s / (ms * 1e-3),
+                       note="fp32-VALU bound (one quotient, floor and 6 add/mul/compare per element-sample); logs precomputed, resident"),
+        "kernel_device_log": dict(_roof(alg, ms_log), vectors_per_s=n / (ms_log * 1e-3)),
+        "from_python_parity_mode": {"seconds": dt_par, "vectors_per_s": n / dt_par, "note": "numpy in -> numpy out; np.log on the host"},
+        "from_python_device_log": {"seconds": dt_log, "vectors_per_s": n / dt_log},
+        "device_log_mismatch_rate": float(len(mism)) / (n * s),
+        "device_log_mismatches": int(len(mism)),
+        "device_log_gate": gate,
+        "parity": f"{len(rows)} rows bit-exact (k, t) vs the C oracle in parity mode; all-rows nonempty = {bool(ne.all())}",
+    })
+    return out
+
+
+def weighted_gap_gate(x, g, hv_par, hv_log, mism, tol=1e-6):
+    """BASELINE.md section 3's acceptance rule for the device-log mode: a (k, t) pair may differ from parity mode
+    only where the choice was within rounding -- the two competing columns' ln_a (float32, the reference's formula,
+    weighted_minhash.py:212-218) within `tol` relative of each other, or (same effect one step earlier) a column's
+    ln(x)/r + beta within `tol` relative of an integer, where one ulp of the log moves the floor.  Returns the
+    largest relative gap seen among the accepted mismatches and the number of mismatches neither rule explains."""
+    worst_gap, worst_edge, unexplained, edge_cases = None, None, 0, 0
+    one = np.float32(1)
+    for row, smp in mism:
+        k0, k1 = int(hv_par[row, smp, 0]), int(hv_log[row, smp, 0])
+        ln_a, edge = [], []
+        for kk in (k0, k1):
+            lg = np.log(np.float32(x[row, kk]))
+            r, be, lc = g.rs[smp, kk], g.betas[smp, kk], g.ln_cs[smp, kk]
+            y = np.float32(np.float32(lg / r) + be)
+            tt = np.floor(y)
+            ln_a.append(float(np.float32(lc - np.float32(np.float32(np.float32(tt - be) + one) * r))))
+            edge.append(float(min(y - tt, tt + one - y)) / max(abs(float(y)), 1.0))
+        if min(edge) <= tol:  # a floor boundary: t (and with it ln_a) flips with the last bit of the log
+            edge_cases += 1
+            worst_edge = min(edge) if worst_edge is None else max(worst_edge, min(edge))
+            continue
+        gap = abs(ln_a[0] - ln_a[1]) / max(abs(ln_a[0]), abs(ln_a[1]), 1e-30)
+        if k0 != k1 and gap <= tol:
+            worst_gap = gap if worst_gap is None else max(worst_gap, gap)
+        else:
+            unexplained += 1
+    return {"mismatches_examined": int(len(mism)), "worst_relative_ln_a_gap": worst_gap, "floor_boundary_cases": edge_cases,
+            "worst_floor_boundary_distance": worst_edge, "unexplained": unexplained, "tolerance": tol,
+            "rule": "BASELINE.md section 3: (k,t) may differ from parity mode only where the two smallest ln_a "
+                    "(or ln(x)/r+beta and an integer) are within 1e-6 relative"}
 
 
 if __name__ == "__main__":

@@ -40,6 +40,7 @@ _PROTOTYPES = {
     "mhx_dev_free": [_vp, _vp],
     "mhx_memcpy_h2d": [_vp, _vp, _vp, _sz],
     "mhx_memcpy_d2h": [_vp, _vp, _vp, _sz],
+    "mhx_memcpy_d2d": [_vp, _vp, _vp, _sz],
     "mhx_memset_dev": [_vp, _vp, _int, _sz],
     "mhx_event_create": [_vp, ctypes.POINTER(_vp)],
     "mhx_event_record": [_vp],
@@ -50,9 +51,11 @@ _PROTOTYPES = {
     "mhx_perm_destroy": [_vp],
     "mhx_minhash_bulk_dev": [_vp, _vp, _int, _vp, _i64, _i64, _i64, _vp, _i64, _vp, _int],
     "mhx_minhash_bulk": [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp],
+    "mhx_minhash_bulk_typed": [_vp, _vp, _int, _vp, _i64, _i64, _vp, _i64, _vp, _int],
     "mhx_sha1_tokens_dev": [_vp, _vp, _vp, _i64, _int, _vp],
     "mhx_sha1_tokens": [_vp, _vp, _vp, _i64, _int, _vp],
     "mhx_minhash_bulk_bytes": [_vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp],
+    "mhx_minhash_bulk_bytes_typed": [_vp, _vp, _vp, _i64, _int, _vp, _i64, _vp, _i64, _vp],
     "mhx_minhash_update_batch": [_vp, _vp, _i64, _vp],
     "mhx_minhash_merge_dev": [_vp, _vp, _vp, _i64, _vp],
     "mhx_minhash_merge": [_vp, _vp, _vp, _i64, _vp],
@@ -62,6 +65,7 @@ _PROTOTYPES = {
     "mhx_weighted_minhash_many_dense": [_vp, _vp, _int, _i64, _vp, _vp],
     "mhx_weighted_minhash_many_dense_dev": [_vp, _vp, _int, _i64, _vp, _vp],
     "mhx_weighted_minhash_many_dev": [_vp, _vp, _vp, _vp, _int, _i64, _i64, _vp, _vp],
+    "mhx_weighted_logf": [_vp, _vp, _i64, _vp],
     "mhx_bbit_num_blocks": [_i32, _i32, ctypes.POINTER(_i32)],
     "mhx_bbit_pack_dev": [_vp, _vp, _i64, _i32, _i32, _vp],
     "mhx_bbit_pack": [_vp, _vp, _i64, _i32, _i32, _vp],
@@ -74,14 +78,19 @@ _PROTOTYPES = {
     "mhx_lsh_candidate_pairs_dev": [_vp, _vp, _vp, _i64, ctypes.c_int32, _vp, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
     "mhx_lsh_candidate_pairs": [_vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _i64,
                                 ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
+    "mhx_lsh_query_dev": [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _int, _i32, _i64, _vp, _i64, ctypes.POINTER(_i64)],
     "mhx_jaccard_pairs_dev": [_vp, _vp, _vp, ctypes.c_int32, _vp, _i64, _vp],
     "mhx_jaccard_pairs": [_vp, _vp, _i64, ctypes.c_int32, _vp, _i64, _vp],
+    "mhx_bbit_pack_dev_typed": [_vp, _vp, _int, _i64, _i32, _i32, _vp],
+    "mhx_band_digests_dev_typed": [_vp, _vp, _int, _i64, _i32, _i32, _i32, _vp],
+    "mhx_lsh_sort_bands_dev_typed": [_vp, _vp, _int, _i64, _i32, _i32, _i32, _vp, _vp],
+    "mhx_jaccard_pairs_dev_typed": [_vp, _vp, _vp, _int, _i32, _vp, _i64, _vp],
     "mhx_lean_serialize_dev": [_vp, _vp, _i64, _i32, _i64, _vp],
     "mhx_lean_serialize": [_vp, _vp, _i64, _i32, _i64, _vp],
-    "mhx_comm_preload": [],
     "mhx_comm_unique_id": [_vp],
     "mhx_comm_create": [_vp, _vp, _int, _int, ctypes.POINTER(_vp)],
     "mhx_comm_destroy": [_vp],
+    "mhx_comm_info": [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)],
     "mhx_comm_allgather_dev": [_vp, _vp, _vp, _sz],
 }
 _RESTYPE = {"mhx_last_error": ctypes.c_char_p, "mhx_version": ctypes.c_char_p}
@@ -296,6 +305,10 @@ class Context:
     def event(self) -> Event:
         return Event(self)
 
+    def copy_dev(self, d_dst: int, d_src: int, nbytes: int) -> None:
+        """Device-to-device copy on the context's stream (enqueued, not synchronised)."""
+        check(self.lib.mhx_memcpy_d2d(self.handle, _vp(d_dst), _vp(d_src), int(nbytes)))
+
     # -- MinHash permutations (replaces the reference's _ensure_gpu_caches)
     def perm_handle(self, permutations) -> int:
         a = np.ascontiguousarray(permutations[0], dtype=np.uint64)
@@ -332,13 +345,23 @@ class Context:
 
     # -- host-buffer entry points ------------------------------------------------------------
     def minhash_bulk(self, permutations, hv: np.ndarray, offsets: Optional[np.ndarray], fixed_len: int, n_sets: int,
-                     init: Optional[np.ndarray] = None, out: Optional[np.ndarray] = None) -> np.ndarray:
-        """CSR / fixed-length corpus of pre-hashed tokens -> [n_sets, K] uint64 (host in, host out).
-        ``out`` may name a C-contiguous uint64 [n_sets, K] array to fill (reusing one avoids the page
-        faults of a fresh gigabyte)."""
+                     init: Optional[np.ndarray] = None, out: Optional[np.ndarray] = None, out_dtype=np.uint64) -> np.ndarray:
+        """CSR / fixed-length corpus of pre-hashed tokens -> [n_sets, K] signatures (host in, host out).
+        ``hv`` travels as it is when it is a uint32 or uint64 array (uint32 = the range of ``sha1_hash32``: half
+        the bytes over PCIe), anything else is converted to uint64.  ``out`` may name a C-contiguous
+        [n_sets, K] array of ``out_dtype`` (uint64 = the reference's layout, uint32 = compact) to fill --
+        reusing one avoids the page faults of a fresh gigabyte."""
         perm = self.perm_handle(permutations)
         k = len(permutations[0])
-        hv = np.ascontiguousarray(hv, dtype=np.uint64)
+        hv = np.asarray(hv)
+        if hv.dtype != np.uint32:
+            hv = np.ascontiguousarray(hv, dtype=np.uint64)
+        hv = np.ascontiguousarray(hv)
+        hv_code = MHX_U32 if hv.dtype == np.uint32 else MHX_U64
+        out_dtype = np.dtype(out_dtype if out is None else out.dtype)
+        if out_dtype not in (np.dtype(np.uint64), np.dtype(np.uint32)):
+            raise ValueError("signatures are uint64 or uint32")
+        out_code = MHX_U32 if out_dtype == np.uint32 else MHX_U64
         if offsets is not None:
             offsets = np.ascontiguousarray(offsets, dtype=np.int64)
             if offsets.shape != (n_sets + 1,):
@@ -357,10 +380,11 @@ class Context:
             else:
                 raise ValueError("init must have shape (K,) or (n_sets, K)")
         if out is None:
-            out = np.empty((n_sets, k), dtype=np.uint64)
-        elif out.dtype != np.uint64 or out.shape != (n_sets, k) or not out.flags.c_contiguous:
-            raise ValueError("out must be a C-contiguous uint64 array of shape (n_sets, K)")
-        check(self.lib.mhx_minhash_bulk(perm, _ptr(hv), _ptr(offsets), int(fixed_len), int(n_sets), _ptr(init), stride, _ptr(out)))
+            out = np.empty((n_sets, k), dtype=out_dtype)
+        elif out.shape != (n_sets, k) or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous array of shape (n_sets, K)")
+        check(self.lib.mhx_minhash_bulk_typed(perm, _ptr(hv), hv_code, _ptr(offsets), int(fixed_len), int(n_sets), _ptr(init),
+                                              stride, _ptr(out), out_code))
         return out
 
     @staticmethod
@@ -401,8 +425,11 @@ class Context:
         return out
 
     def minhash_bulk_bytes(self, permutations, buf: np.ndarray, byte_offsets: np.ndarray, set_offsets: np.ndarray,
-                           init: Optional[np.ndarray] = None) -> np.ndarray:
-        """Raw byte tokens -> sha1_hash32 -> [n_sets, K] uint64 signatures, all on the device."""
+                           init: Optional[np.ndarray] = None, bits: int = 32) -> np.ndarray:
+        """Raw byte tokens -> sha1_hash32 (``bits=32``) or sha1_hash64 (``bits=64``) -> [n_sets, K] uint64
+        signatures, all on the device."""
+        if bits not in (32, 64):
+            raise ValueError("bits must be 32 or 64")
         perm = self.perm_handle(permutations)
         k = len(permutations[0])
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
@@ -417,8 +444,8 @@ class Context:
             elif init.shape != (k,):
                 raise ValueError("init must have shape (K,) or (n_sets, K)")
         out = np.empty((n_sets, k), dtype=np.uint64)
-        check(self.lib.mhx_minhash_bulk_bytes(perm, _ptr(buf), _ptr(byte_offsets), n_tokens, _ptr(set_offsets), n_sets,
-                                              _ptr(init), stride, _ptr(out)))
+        check(self.lib.mhx_minhash_bulk_bytes_typed(perm, _ptr(buf), _ptr(byte_offsets), n_tokens, MHX_U32 if bits == 32 else MHX_U64,
+                                                    _ptr(set_offsets), n_sets, _ptr(init), stride, _ptr(out)))
         return out
 
     def minhash_update_batch(self, permutations, hv: np.ndarray, hashvalues: np.ndarray) -> np.ndarray:
@@ -455,6 +482,13 @@ class Context:
         nonempty = np.zeros(n, dtype=np.uint8)
         check(self.lib.mhx_weighted_minhash_many_dense(h, _ptr(x), int(bool(values_are_logs)), n, _ptr(out), _ptr(nonempty)))
         return out, nonempty.astype(bool)
+
+    def weighted_logf(self, x: np.ndarray) -> np.ndarray:
+        """The float32 log the device-log mode of the weighted path takes (mhx_weighted_logf)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        out = np.empty_like(x)
+        check(self.lib.mhx_weighted_logf(self.handle, _ptr(x), x.size, _ptr(out)))
+        return out
 
     def bbit_pack(self, sig: np.ndarray, b: int) -> np.ndarray:
         sig = np.ascontiguousarray(sig, dtype=np.uint64)
@@ -554,7 +588,7 @@ class Communicator:
     """RCCL communicator of libmhx (mhx_comm_*): one rank per Context / GPU, all-gather of row shards
     over xGMI on the context's stream.  The 128-byte unique id is created on rank 0
     (``Communicator.unique_id()``) and handed to the other ranks by the caller -- any channel works
-    (``datasketch_amd.dist`` broadcasts it over a gloo process group)."""
+    (``datasketch_amd.dist`` broadcasts it over its own TCP rendezvous, ``datasketch_amd.rendezvous``)."""
 
     ID_BYTES = 128
 
@@ -572,6 +606,12 @@ class Communicator:
         buf = (ctypes.c_uint8 * Communicator.ID_BYTES)()
         check(load().mhx_comm_unique_id(buf))
         return bytes(buf)
+
+    def info(self) -> dict:
+        """What RCCL itself reports: rank, ranks seen (ncclCommCount), HIP device, library version."""
+        r, w, d, v = _int(-1), _int(-1), _int(-1), _int(0)
+        check(self.ctx.lib.mhx_comm_info(self.handle, ctypes.byref(r), ctypes.byref(w), ctypes.byref(d), ctypes.byref(v)))
+        return {"rank": r.value, "ranks_seen": w.value, "device": d.value, "rccl_version": v.value}
 
     def allgather_dev(self, d_send: int, d_recv: int, bytes_per_rank: int) -> None:
         """Enqueue the all-gather on the context's stream (device pointers; d_recv holds world*bytes)."""

@@ -23,6 +23,10 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 };
@@ -48,6 +52,10 @@ Rccl &rccl() {
         MHX_SYM(CommDestroy, "ncclCommDestroy")
         MHX_SYM(AllGather, "ncclAllGather")
         MHX_SYM(GetErrorString, "ncclGetErrorString")
+        MHX_SYM(CommCount, "ncclCommCount")
+        MHX_SYM(CommUserRank, "ncclCommUserRank")
+        MHX_SYM(CommCuDevice, "ncclCommCuDevice")
+        MHX_SYM(GetVersion, "ncclGetVersion")
 #undef MHX_SYM
     });
     return r;
@@ -68,19 +76,9 @@ int rccl_ready() {
 
 }  // namespace
 
-namespace mhx {
-// Called from mhx_ctx_create: bind RCCL while the process holds only the system HIP runtime.  A
-// PyTorch-ROCm wheel imported later brings its own copies of the ROCm libraries; an RCCL loaded
-// after that resolves against those and finds no device.  Failure to load is not an error here
-// (mhx_comm_* reports it when a communicator is actually requested).
-void preload_rccl() { (void)rccl(); }
-}  // namespace mhx
-
 static_assert(sizeof(ncclUniqueId) == MHX_COMM_ID_BYTES, "RCCL unique id size changed");
 
 extern "C" {
-
-int mhx_comm_preload(void) { return rccl_ready(); }
 
 int mhx_comm_unique_id(uint8_t id[MHX_COMM_ID_BYTES]) {
     if (!id) return mhx::fail(MHX_ERR_INVALID, "id is NULL");
@@ -96,6 +94,7 @@ int mhx_comm_create(mhx_ctx *ctx, const uint8_t id[MHX_COMM_ID_BYTES], int rank,
     if (!ctx || !id || !out) return mhx::fail(MHX_ERR_INVALID, "NULL argument");
     MHX_REQUIRE(world_size > 0 && rank >= 0 && rank < world_size, "bad rank %d / world_size %d", rank, world_size);
     if (int rc = rccl_ready()) return rc;
+    MHX_GUARD(ctx);
     if (int rc = ctx->activate()) return rc;
     ncclUniqueId uid;
     memcpy(&uid, id, MHX_COMM_ID_BYTES);
@@ -112,6 +111,30 @@ int mhx_comm_create(mhx_ctx *ctx, const uint8_t id[MHX_COMM_ID_BYTES], int rank,
     return MHX_OK;
 }
 
+int mhx_comm_info(mhx_comm *comm, int *rank, int *world_size, int *device, int *rccl_version) {
+    if (!comm) return mhx::fail(MHX_ERR_INVALID, "comm is NULL");
+    // asked of RCCL itself, not echoed from mhx_comm_create's arguments: "ranks seen" is what the
+    // communicator was really built with
+    int v = 0;
+    if (world_size) {
+        MHX_RCCL_CHECK(rccl().CommCount(comm->comm, &v));
+        *world_size = v;
+    }
+    if (rank) {
+        MHX_RCCL_CHECK(rccl().CommUserRank(comm->comm, &v));
+        *rank = v;
+    }
+    if (device) {
+        MHX_RCCL_CHECK(rccl().CommCuDevice(comm->comm, &v));
+        *device = v;
+    }
+    if (rccl_version) {
+        MHX_RCCL_CHECK(rccl().GetVersion(&v));
+        *rccl_version = v;
+    }
+    return MHX_OK;
+}
+
 int mhx_comm_destroy(mhx_comm *comm) {
     if (!comm) return MHX_OK;
     (void)hipSetDevice(comm->ctx->device);
@@ -125,6 +148,7 @@ int mhx_comm_allgather_dev(mhx_comm *comm, const void *d_send, void *d_recv, siz
     if (!comm) return mhx::fail(MHX_ERR_INVALID, "comm is NULL");
     if (bytes_per_rank == 0) return MHX_OK;
     MHX_REQUIRE(d_send && d_recv, "NULL device pointer");
+    MHX_GUARD(comm->ctx);
     if (int rc = comm->ctx->activate()) return rc;
     MHX_RCCL_CHECK(rccl().AllGather(d_send, d_recv, bytes_per_rank, ncclUint8, comm->comm, comm->ctx->stream));
     return MHX_OK;

@@ -148,6 +148,76 @@ __global__ __launch_bounds__(256) void unpack_pairs_kernel(const uint64_t *__res
     }
 }
 
+
+// ---- bulk query against sorted bands ---------------------------------------------------------------
+// What MinHashLSH.query does per probe (ref: datasketch/lsh.py:423-431: for every band, look the band key up
+// in that band's dictionary and union the buckets), for M probes at once against an index of n rows held as
+// sorted bands: the probe's band digest is located by binary search in the band's ascending digests; the
+// matching run is its bucket.
+
+// per (probe q, band j): first[idx] = position of the first equal digest in the band, count[idx] = run length
+__global__ __launch_bounds__(256) void query_ranges_kernel(const uint64_t *__restrict__ q_digests, int64_t m, int32_t bands,
+                                                           const uint64_t *__restrict__ sorted_digests, int64_t n,
+                                                           uint32_t *__restrict__ first, uint32_t *__restrict__ count) {
+    const int64_t total = m * (int64_t)bands;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int band = (int)(idx % bands);
+        const uint64_t d = q_digests[idx];
+        const uint64_t *col = sorted_digests + (int64_t)band * n;
+        int64_t lo = 0, hi = n;  // lower bound
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (col[mid] < d) lo = mid + 1; else hi = mid;
+        }
+        int64_t end = lo;
+        if (lo < n && col[lo] == d) {  // upper bound by galloping: buckets are short
+            int64_t step = 1;
+            end = lo + 1;
+            while (end < n && col[end] == d) {
+                end = std::min<int64_t>(n, end + step);
+                step <<= 1;
+            }
+            int64_t a = std::max<int64_t>(lo, end - step / 2 - 1), b = end;  // last equal is in [a, b)
+            while (a < b) {
+                const int64_t mid = (a + b) >> 1;
+                if (col[mid] <= d) a = mid + 1; else b = mid;
+            }
+            end = a;
+        }
+        first[idx] = (uint32_t)lo;
+        count[idx] = (uint32_t)(end - lo);
+    }
+}
+
+// raw[where[idx] + i] = (q << 32) | row for the rows of the probe's bucket in band j.  With VERIFY the r words of
+// the band are compared (probe signature against index signature): a 64-bit digest collision between different
+// band keys then yields no candidate -- exactly the reference's dictionary semantics -- and the slot gets ~0.
+template <typename SigT, bool VERIFY>
+__global__ __launch_bounds__(256) void query_emit_kernel(const uint32_t *__restrict__ first, const uint32_t *__restrict__ count,
+                                                         const uint64_t *__restrict__ where, int64_t m, int32_t bands, int64_t n,
+                                                         const uint32_t *__restrict__ sorted_rows,
+                                                         const SigT *__restrict__ q_sig, const SigT *__restrict__ idx_sig,
+                                                         int32_t k, int32_t r, uint64_t *__restrict__ raw) {
+    const int64_t total = m * (int64_t)bands;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t c = count[idx];
+        if (c == 0) continue;
+        const int64_t q = idx / bands;
+        const int band = (int)(idx - q * bands);
+        const uint32_t *rows = sorted_rows + (int64_t)band * n + first[idx];
+        uint64_t *dst = raw + where[idx];
+        for (uint32_t i = 0; i < c; ++i) {
+            const uint32_t row = rows[i];
+            bool same = true;
+            if (VERIFY) {
+                const SigT *x = q_sig + q * k + (int64_t)band * r, *y = idx_sig + (int64_t)row * k + (int64_t)band * r;
+                for (int w = 0; w < r; ++w) same &= x[w] == y[w];
+            }
+            dst[i] = same ? (((uint64_t)q << 32) | row) : ~0ull;
+        }
+    }
+}
+
 unsigned grid_for(const mhx_ctx *ctx, int64_t items) {
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>((items + 255) / 256, (int64_t)ctx->num_cus * 16));
 }
@@ -225,7 +295,7 @@ int launch_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *d_sorted_digests, c
     return MHX_OK;
 }
 
-int launch_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
+int launch_lsh_sort_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t bands, int32_t r,
                           uint64_t *d_sorted_digests, uint32_t *d_sorted_rows) {
     if (n >= ((int64_t)1 << 32)) return fail(MHX_ERR_UNSUPPORTED, "more than 2^32-1 signatures per call");
     // scratch[3]: digests[n, bands] | keys u64[total] | sorted keys u64[total] | rows u32[total] | marks u8[total] |
@@ -256,7 +326,7 @@ int launch_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_
     uint32_t *d_rows = (uint32_t *)((char *)ctx->scratch[3] + 3 * dig_bytes);
     uint8_t *d_mixed = (uint8_t *)((char *)ctx->scratch[3] + 3 * dig_bytes + row_bytes);
     void *d_tmp = (char *)ctx->scratch[3] + 3 * dig_bytes + row_bytes + mark_bytes;
-    if (int rc = launch_band_digests(ctx, d_sig, n, k, bands, r, d_dig)) return rc;
+    if (int rc = launch_band_digests(ctx, d_sig, sig_dtype, n, k, bands, r, d_dig)) return rc;
     const dim3 grid(grid_for(ctx, total));
     hipLaunchKernelGGL(band_keys_for_sort_kernel, grid, dim3(256), 0, ctx->stream, d_dig, n, bands, band_bits, sort_bits, d_keys, d_rows);
     MHX_HIP_CHECK(hipGetLastError());
@@ -269,6 +339,93 @@ int launch_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_
     hipLaunchKernelGGL(mark_mixed_runs_kernel, grid, dim3(256), 0, ctx->stream, d_keys_sorted, d_sorted_digests, n, total, d_mixed);
     hipLaunchKernelGGL(order_mixed_runs_kernel, grid, dim3(256), 0, ctx->stream, d_keys_sorted, d_mixed, n, total,
                        d_sorted_digests, d_sorted_rows);
+    MHX_HIP_CHECK(hipGetLastError());
+    return MHX_OK;
+}
+
+int launch_lsh_query(mhx_ctx *ctx, const uint64_t *d_sorted_digests, const uint32_t *d_sorted_rows, int64_t n, int32_t bands,
+                     int32_t r, const void *d_q_sig, const void *d_idx_sig, int sig_dtype, int32_t k, int64_t m,
+                     int64_t *d_pairs, int64_t capacity, int64_t *n_pairs) {
+    *n_pairs = 0;
+    const int64_t total = m * (int64_t)bands;
+    if (total == 0 || n == 0) return MHX_OK;
+    // scratch[4]: probe digests u64[total] | first u32[total] | count u32[total] | where u64[total] | scan temporary
+    const size_t dig_bytes = ((sizeof(uint64_t) * (size_t)total) + 255) & ~(size_t)255;
+    const size_t u32_bytes = ((sizeof(uint32_t) * (size_t)total) + 255) & ~(size_t)255;
+    size_t scan_tmp = 0;
+    hipError_t e = rocprim::exclusive_scan(nullptr, scan_tmp, (const uint32_t *)nullptr, (uint64_t *)nullptr, (uint64_t)0,
+                                           (size_t)total, rocprim::plus<uint64_t>(), ctx->stream);
+    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::exclusive_scan (size query) failed: %s", hipGetErrorString(e));
+    if (int rc = ctx->ensure_scratch(4, 2 * dig_bytes + 2 * u32_bytes + 256 + scan_tmp)) return rc;
+    char *base = (char *)ctx->scratch[4];
+    uint64_t *d_qdig = (uint64_t *)base;
+    uint32_t *d_first = (uint32_t *)(base + dig_bytes);
+    uint32_t *d_count = (uint32_t *)(base + dig_bytes + u32_bytes);
+    uint64_t *d_where = (uint64_t *)(base + dig_bytes + 2 * u32_bytes);
+    void *d_scan_tmp = base + 2 * dig_bytes + 2 * u32_bytes + 256;
+    if (int rc = launch_band_digests(ctx, d_q_sig, sig_dtype, m, k, bands, r, d_qdig)) return rc;
+    const dim3 grid(grid_for(ctx, total));
+    hipLaunchKernelGGL(query_ranges_kernel, grid, dim3(256), 0, ctx->stream, d_qdig, m, bands, d_sorted_digests, n, d_first, d_count);
+    MHX_HIP_CHECK(hipGetLastError());
+    e = rocprim::exclusive_scan(d_scan_tmp, scan_tmp, (const uint32_t *)d_count, d_where, (uint64_t)0, (size_t)total,
+                                rocprim::plus<uint64_t>(), ctx->stream);
+    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::exclusive_scan failed: %s", hipGetErrorString(e));
+    uint64_t last_where = 0;
+    uint32_t last_count = 0;
+    MHX_HIP_CHECK(hipMemcpyAsync(&last_where, d_where + (total - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipMemcpyAsync(&last_count, d_count + (total - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const int64_t raw = (int64_t)(last_where + last_count);
+    if (raw == 0) return MHX_OK;
+    if ((size_t)raw * 16 > (size_t)ctx->hbm_bytes / 2)
+        return fail(MHX_ERR_OOM, "%lld candidates before deduplication do not fit in device memory", (long long)raw);
+    // scratch[3]: raw u64[raw] | sorted u64[raw] | count u64 | sort / select temporary
+    const size_t raw_bytes = ((sizeof(uint64_t) * (size_t)raw) + 255) & ~(size_t)255;
+    size_t sort_tmp = 0, uniq_tmp = 0;
+    e = rocprim::radix_sort_keys(nullptr, sort_tmp, (const uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)raw, 0, 64, ctx->stream);
+    if (e == hipSuccess)
+        e = rocprim::unique(nullptr, uniq_tmp, (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)raw,
+                            rocprim::equal_to<uint64_t>(), ctx->stream);
+    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim size query failed: %s", hipGetErrorString(e));
+    const size_t tmp_bytes = std::max(sort_tmp, uniq_tmp);
+    if (int rc = ctx->ensure_scratch(3, 2 * raw_bytes + 256 + tmp_bytes)) return rc;
+    uint64_t *d_raw = (uint64_t *)ctx->scratch[3];
+    uint64_t *d_sorted = (uint64_t *)((char *)ctx->scratch[3] + raw_bytes);
+    uint64_t *d_cnt = (uint64_t *)((char *)ctx->scratch[3] + 2 * raw_bytes);
+    void *d_tmp = (char *)ctx->scratch[3] + 2 * raw_bytes + 256;
+    const bool verify = d_idx_sig != nullptr;
+    if (sig_dtype == MHX_U32) {
+        if (verify)
+            hipLaunchKernelGGL((query_emit_kernel<uint32_t, true>), grid, dim3(256), 0, ctx->stream, d_first, d_count, d_where, m, bands, n,
+                               d_sorted_rows, (const uint32_t *)d_q_sig, (const uint32_t *)d_idx_sig, k, r, d_raw);
+        else
+            hipLaunchKernelGGL((query_emit_kernel<uint32_t, false>), grid, dim3(256), 0, ctx->stream, d_first, d_count, d_where, m, bands, n,
+                               d_sorted_rows, (const uint32_t *)d_q_sig, (const uint32_t *)d_idx_sig, k, r, d_raw);
+    } else {
+        if (verify)
+            hipLaunchKernelGGL((query_emit_kernel<uint64_t, true>), grid, dim3(256), 0, ctx->stream, d_first, d_count, d_where, m, bands, n,
+                               d_sorted_rows, (const uint64_t *)d_q_sig, (const uint64_t *)d_idx_sig, k, r, d_raw);
+        else
+            hipLaunchKernelGGL((query_emit_kernel<uint64_t, false>), grid, dim3(256), 0, ctx->stream, d_first, d_count, d_where, m, bands, n,
+                               d_sorted_rows, (const uint64_t *)d_q_sig, (const uint64_t *)d_idx_sig, k, r, d_raw);
+    }
+    MHX_HIP_CHECK(hipGetLastError());
+    e = rocprim::radix_sort_keys(d_tmp, sort_tmp, (const uint64_t *)d_raw, d_sorted, (size_t)raw, 0, 64, ctx->stream);
+    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_keys failed: %s", hipGetErrorString(e));
+    e = rocprim::unique(d_tmp, uniq_tmp, (const uint64_t *)d_sorted, d_raw, d_cnt, (size_t)raw, rocprim::equal_to<uint64_t>(), ctx->stream);
+    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::unique failed: %s", hipGetErrorString(e));
+    uint64_t unique_count = 0, last_key = 0;
+    MHX_HIP_CHECK(hipMemcpyAsync(&unique_count, d_cnt, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (unique_count > 0) {  // a failed verification left ~0, which sorts last
+        MHX_HIP_CHECK(hipMemcpyAsync(&last_key, d_raw + (unique_count - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+        MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (last_key == ~0ull) --unique_count;
+    }
+    *n_pairs = (int64_t)unique_count;
+    if ((int64_t)unique_count > capacity || unique_count == 0) return MHX_OK;  // caller sees n_pairs > capacity and calls again
+    hipLaunchKernelGGL(unpack_pairs_kernel, dim3(grid_for(ctx, (int64_t)unique_count)), dim3(256), 0, ctx->stream, d_raw,
+                       (int64_t)unique_count, d_pairs);
     MHX_HIP_CHECK(hipGetLastError());
     return MHX_OK;
 }

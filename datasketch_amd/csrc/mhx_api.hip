@@ -55,6 +55,7 @@ int mhx_ctx::activate() const {
 
 int mhx_ctx::ensure_scratch(int slot, size_t bytes) {
     if (bytes <= scratch_bytes[slot]) return MHX_OK;
+    const size_t old = scratch_bytes[slot];
     if (scratch[slot]) {
         MHX_HIP_CHECK(hipStreamSynchronize(stream));
         MHX_HIP_CHECK(hipFree(scratch[slot]));
@@ -62,7 +63,7 @@ int mhx_ctx::ensure_scratch(int slot, size_t bytes) {
         scratch_bytes[slot] = 0;
     }
     // grow geometrically so repeated slightly larger calls do not reallocate every time
-    size_t want = std::max(bytes, scratch_bytes[slot] + scratch_bytes[slot] / 2);
+    size_t want = std::max(bytes, old + old / 2);
     want = (want + 255) & ~(size_t)255;
     hipError_t e = hipMalloc(&scratch[slot], want);
     if (e != hipSuccess && want != bytes) {
@@ -143,13 +144,6 @@ int mhx_ctx_create(int device, mhx_ctx **out) {
         delete ctx;
         return fail(MHX_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
     }
-    // RCCL has to be loaded before another HIP runtime enters the process (a PyTorch-ROCm wheel brings its
-    // own); loading it costs ~1 s, so it is done up front only for multi-process jobs (WORLD_SIZE > 1, as
-    // torchrun sets it) or on request (MHX_PRELOAD_RCCL=1), otherwise at the first mhx_comm_* call
-    {
-        const char *force = getenv("MHX_PRELOAD_RCCL"), *world = getenv("WORLD_SIZE");
-        if (force ? atoi(force) != 0 : (world && atoi(world) > 1)) mhx::preload_rccl();
-    }
     *out = ctx;
     return MHX_OK;
 }
@@ -171,12 +165,14 @@ int mhx_ctx_destroy(mhx_ctx *ctx) {
 
 int mhx_ctx_synchronize(mhx_ctx *ctx) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return MHX_OK;
 }
 
 int mhx_ctx_release_scratch(mhx_ctx *ctx) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     if (int rc = ctx->activate()) return rc;
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 5; ++i) {
@@ -194,6 +190,7 @@ int mhx_ctx_release_scratch(mhx_ctx *ctx) {
 
 int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus, int64_t *hbm_bytes) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     if (name && name_len > 0) {
         strncpy(name, ctx->name, (size_t)name_len - 1);
         name[name_len - 1] = 0;
@@ -205,6 +202,7 @@ int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus, int64_
 
 int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     if (!ctx || !key) return fail(MHX_ERR_INVALID, "ctx/key is NULL");
+    MHX_GUARD(ctx);
     if (!strcmp(key, "minhash.path")) ctx->opt_minhash_path = value;
     else if (!strcmp(key, "minhash.split")) ctx->opt_minhash_split = value;
     else if (!strcmp(key, "blocks_per_cu")) ctx->opt_blocks_per_cu = value;
@@ -219,6 +217,7 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
 
 int mhx_ctx_counters(mhx_ctx *ctx, int enable, uint64_t out[MHX_NUM_COUNTERS]) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     if (int rc = ctx->activate()) return rc;
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (out) {
@@ -244,6 +243,7 @@ int mhx_ctx_counters(mhx_ctx *ctx, int enable, uint64_t out[MHX_NUM_COUNTERS]) {
 // ---- device memory -------------------------------------------------------------------------
 int mhx_dev_alloc(mhx_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return fail(MHX_ERR_INVALID, "ctx/dptr is NULL");
+    MHX_GUARD(ctx);
     *dptr = nullptr;
     if (int rc = ctx->activate()) return rc;
     hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
@@ -256,6 +256,7 @@ int mhx_dev_alloc(mhx_ctx *ctx, size_t bytes, void **dptr) {
 
 int mhx_dev_free(mhx_ctx *ctx, void *dptr) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     if (!dptr) return MHX_OK;
     if (int rc = ctx->activate()) return rc;
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -265,6 +266,7 @@ int mhx_dev_free(mhx_ctx *ctx, void *dptr) {
 
 int mhx_memcpy_h2d(mhx_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     if (!bytes) return MHX_OK;
     if (int rc = ctx->activate()) return rc;
     MHX_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -274,6 +276,7 @@ int mhx_memcpy_h2d(mhx_ctx *ctx, void *dst, const void *src, size_t bytes) {
 
 int mhx_memcpy_d2h(mhx_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     if (!bytes) return MHX_OK;
     if (int rc = ctx->activate()) return rc;
     MHX_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -281,8 +284,18 @@ int mhx_memcpy_d2h(mhx_ctx *ctx, void *dst, const void *src, size_t bytes) {
     return MHX_OK;
 }
 
+int mhx_memcpy_d2d(mhx_ctx *ctx, void *dst, const void *src, size_t bytes) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    if (!bytes) return MHX_OK;
+    if (int rc = ctx->activate()) return rc;
+    MHX_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return MHX_OK;
+}
+
 int mhx_memset_dev(mhx_ctx *ctx, void *dst, int byte_value, size_t bytes) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     if (!bytes) return MHX_OK;
     if (int rc = ctx->activate()) return rc;
     MHX_HIP_CHECK(hipMemsetAsync(dst, byte_value, bytes, ctx->stream));
@@ -292,6 +305,7 @@ int mhx_memset_dev(mhx_ctx *ctx, void *dst, int byte_value, size_t bytes) {
 // ---- events --------------------------------------------------------------------------------
 int mhx_event_create(mhx_ctx *ctx, mhx_event **ev) {
     if (!ctx || !ev) return fail(MHX_ERR_INVALID, "ctx/ev is NULL");
+    MHX_GUARD(ctx);
     if (int rc = ctx->activate()) return rc;
     mhx_event *e = new mhx_event();
     e->ctx = ctx;
@@ -306,6 +320,7 @@ int mhx_event_create(mhx_ctx *ctx, mhx_event **ev) {
 
 int mhx_event_record(mhx_event *ev) {
     if (!ev) return fail(MHX_ERR_INVALID, "event is NULL");
+    MHX_GUARD(ev->ctx);
     MHX_HIP_CHECK(hipEventRecord(ev->ev, ev->ctx->stream));
     return MHX_OK;
 }
@@ -333,6 +348,7 @@ int mhx_event_destroy(mhx_event *ev) {
 int mhx_perm_create(mhx_ctx *ctx, const uint64_t *a, const uint64_t *b, int32_t num_perm,
                     mhx_perm **out) {
     if (!ctx || !a || !b || !out) return fail(MHX_ERR_INVALID, "NULL argument");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(num_perm > 0, "num_perm must be positive, got %d", num_perm);
     if (int rc = ctx->activate()) return rc;
     mhx_perm *p = new mhx_perm();
@@ -359,6 +375,7 @@ int mhx_perm_create(mhx_ctx *ctx, const uint64_t *a, const uint64_t *b, int32_t 
 
 int mhx_perm_destroy(mhx_perm *perm) {
     if (!perm) return MHX_OK;
+    MHX_GUARD(perm->ctx);
     (void)hipSetDevice(perm->ctx->device);
     (void)hipStreamSynchronize(perm->ctx->stream);
     (void)hipFree(perm->d_a);
@@ -370,6 +387,7 @@ int mhx_minhash_bulk_dev(mhx_perm *perm, const void *d_hv, int hv_dtype, const i
                          int64_t fixed_len, int64_t n_sets, int64_t total_tokens,
                          const uint64_t *d_init, int64_t init_stride, void *d_out, int out_dtype) {
     if (!perm) return fail(MHX_ERR_INVALID, "perm is NULL");
+    MHX_GUARD(perm->ctx);
     MHX_REQUIRE(n_sets >= 0, "n_sets must be >= 0");
     MHX_REQUIRE(hv_dtype == MHX_U64 || hv_dtype == MHX_U32, "bad hv_dtype %d", hv_dtype);
     MHX_REQUIRE(out_dtype == MHX_U64 || out_dtype == MHX_U32, "bad out_dtype %d", out_dtype);
@@ -396,22 +414,23 @@ struct Piece {
 
 // Cut the corpus into pieces of about `target` bytes (tokens in + signature rows out); a piece is
 // at least one set, so one enormous set still becomes one piece.
-std::vector<Piece> cut_pieces(const int64_t *offsets, int64_t fixed_len, int64_t n_sets, int64_t k, int64_t target) {
+std::vector<Piece> cut_pieces(const int64_t *offsets, int64_t fixed_len, int64_t n_sets, int64_t k, int64_t target,
+                              int64_t tok_size = 8, int64_t out_size = 8) {
     std::vector<Piece> pieces;
     int64_t s0 = 0;
     while (s0 < n_sets) {
         int64_t s1;
         if (offsets) {
-            // largest s1 with 8*(offsets[s1]-offsets[s0]) + 8*k*(s1-s0) <= target: the cost is increasing in s1
+            // largest s1 with tok_size*(offsets[s1]-offsets[s0]) + out_size*k*(s1-s0) <= target: the cost is increasing in s1
             int64_t lo = s0 + 1, hi = n_sets;
             while (lo < hi) {
                 const int64_t mid = lo + (hi - lo + 1) / 2;
-                const int64_t cost = 8 * (offsets[mid] - offsets[s0]) + 8 * k * (mid - s0);
+                const int64_t cost = tok_size * (offsets[mid] - offsets[s0]) + out_size * k * (mid - s0);
                 if (cost <= target) lo = mid; else hi = mid - 1;
             }
             s1 = lo;
         } else {
-            const int64_t per_set = 8 * (fixed_len + k);
+            const int64_t per_set = tok_size * fixed_len + out_size * k;
             s1 = std::min(n_sets, s0 + std::max<int64_t>(1, target / per_set));
         }
         Piece p;
@@ -430,11 +449,12 @@ std::vector<Piece> cut_pieces(const int64_t *offsets, int64_t fixed_len, int64_t
 // rows of piece i-1 (copy_out stream).  PCIe is full duplex, so a large call costs about
 // max(upload, download) instead of their sum.  Device buffers hold the whole corpus (no reuse
 // hazards); offsets stay absolute, so a piece is just a window of sets.
-int bulk_pipelined(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets, int64_t fixed_len, int64_t n_sets,
-                   const uint64_t *init, int64_t init_stride, uint64_t *out, uint64_t *d_hv, int64_t *d_off,
-                   uint64_t *d_init, uint64_t *d_out, const std::vector<Piece> &pieces) {
+int bulk_pipelined(mhx_perm *perm, const char *hv, int hv_dtype, const int64_t *offsets, int64_t fixed_len, int64_t n_sets,
+                   const uint64_t *init, int64_t init_stride, char *out, int out_dtype, char *d_hv, int64_t *d_off,
+                   uint64_t *d_init, char *d_out, const std::vector<Piece> &pieces) {
     mhx_ctx *ctx = perm->ctx;
     const int64_t k = perm->num_perm;
+    const size_t ts = hv_dtype == MHX_U32 ? 4 : 8, os = out_dtype == MHX_U32 ? 4 : 8;  // element sizes
     if (int rc = ctx->ensure_copy_streams()) return rc;
     const size_t n_pieces = pieces.size();
     std::vector<hipEvent_t> uploaded(n_pieces, nullptr), computed(n_pieces, nullptr);
@@ -467,7 +487,7 @@ int bulk_pipelined(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets, i
             const Piece &p = pieces[i];
             e = hipStreamWaitEvent(ctx->copy_out, computed[i], 0);
             if (e == hipSuccess)
-                e = hipMemcpyAsync(out + p.s0 * k, d_out + p.s0 * k, sizeof(uint64_t) * (size_t)((p.s1 - p.s0) * k),
+                e = hipMemcpyAsync(out + os * (size_t)(p.s0 * k), d_out + os * (size_t)(p.s0 * k), os * (size_t)((p.s1 - p.s0) * k),
                                    hipMemcpyDeviceToHost, ctx->copy_out);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_out);
@@ -498,7 +518,7 @@ int bulk_pipelined(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets, i
         const Piece &p = pieces[i];
         hipError_t e = hipSuccess;
         if (p.t1 > p.t0)
-            e = hipMemcpyAsync(d_hv + p.t0, hv + p.t0, sizeof(uint64_t) * (size_t)(p.t1 - p.t0), hipMemcpyHostToDevice,
+            e = hipMemcpyAsync(d_hv + ts * (size_t)p.t0, hv + ts * (size_t)p.t0, ts * (size_t)(p.t1 - p.t0), hipMemcpyHostToDevice,
                                ctx->copy_in);
         if (e == hipSuccess && init && init_stride)
             e = hipMemcpyAsync(d_init + p.s0 * init_stride, init + p.s0 * init_stride,
@@ -506,12 +526,12 @@ int bulk_pipelined(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets, i
         if (e == hipSuccess) e = hipEventRecord(uploaded[i], ctx->copy_in);
         if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, uploaded[i], 0);
         if (e != hipSuccess) return finish(fail(MHX_ERR_HIP, "uploading tokens failed: %s", hipGetErrorString(e)));
-        const uint64_t *piece_hv = offsets ? d_hv : d_hv + p.t0;
+        const char *piece_hv = offsets ? d_hv : d_hv + ts * (size_t)p.t0;
         const int64_t *piece_off = offsets ? d_off + p.s0 : nullptr;
         const uint64_t *piece_init = !init ? nullptr : (init_stride ? d_init + p.s0 * init_stride : d_init);
         const int64_t first = offsets ? p.t0 : 0, last = offsets ? p.t1 : p.t1 - p.t0;
-        if (int rc = mhx::launch_minhash_bulk(perm, piece_hv, MHX_U64, piece_off, fixed_len, p.s1 - p.s0, last,
-                                              piece_init, init_stride, d_out + p.s0 * k, MHX_U64, first))
+        if (int rc = mhx::launch_minhash_bulk(perm, piece_hv, hv_dtype, piece_off, fixed_len, p.s1 - p.s0, last,
+                                              piece_init, init_stride, d_out + os * (size_t)(p.s0 * k), out_dtype, first))
             return finish(rc);
         e = hipEventRecord(computed[i], ctx->stream);
         if (e != hipSuccess) return finish(fail(MHX_ERR_HIP, "hipEventRecord failed: %s", hipGetErrorString(e)));
@@ -527,16 +547,20 @@ int bulk_pipelined(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets, i
 }  // namespace
 }  // extern "C++"
 
-int mhx_minhash_bulk(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets, int64_t fixed_len,
-                     int64_t n_sets, const uint64_t *init, int64_t init_stride, uint64_t *out) {
+int mhx_minhash_bulk_typed(mhx_perm *perm, const void *hv, int hv_dtype, const int64_t *offsets, int64_t fixed_len,
+                           int64_t n_sets, const uint64_t *init, int64_t init_stride, void *out, int out_dtype) {
     if (!perm) return fail(MHX_ERR_INVALID, "perm is NULL");
+    MHX_GUARD(perm->ctx);
     MHX_REQUIRE(n_sets >= 0, "n_sets must be >= 0");
+    MHX_REQUIRE(hv_dtype == MHX_U64 || hv_dtype == MHX_U32, "bad hv_dtype %d", hv_dtype);
+    MHX_REQUIRE(out_dtype == MHX_U64 || out_dtype == MHX_U32, "bad out_dtype %d", out_dtype);
     if (n_sets == 0) return MHX_OK;
     MHX_REQUIRE(out, "out is NULL");
     MHX_REQUIRE(offsets || fixed_len >= 0, "fixed_len must be >= 0 when offsets is NULL");
     mhx_ctx *ctx = perm->ctx;
     if (int rc = ctx->activate()) return rc;
     const int64_t k = perm->num_perm;
+    const size_t ts = hv_dtype == MHX_U32 ? 4 : 8, os = out_dtype == MHX_U32 ? 4 : 8;
     int64_t total = 0;
     if (offsets) {
         MHX_REQUIRE(offsets[0] >= 0, "offsets[0] must be >= 0");
@@ -547,49 +571,55 @@ int mhx_minhash_bulk(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets,
         total = n_sets * fixed_len;
     }
     MHX_REQUIRE(hv || total == 0, "hv is NULL");
-    const size_t hv_bytes = sizeof(uint64_t) * (size_t)total;
+    const size_t hv_bytes = ts * (size_t)total;
     const size_t off_bytes = offsets ? sizeof(int64_t) * (size_t)(n_sets + 1) : 0;
-    const size_t out_bytes = sizeof(uint64_t) * (size_t)(n_sets * k);
+    const size_t out_bytes = os * (size_t)(n_sets * k);
     const size_t init_bytes = init ? sizeof(uint64_t) * (size_t)(init_stride ? n_sets * init_stride : k) : 0;
     if (int rc = ctx->ensure_scratch(0, hv_bytes + 256)) return rc;
     if (int rc = ctx->ensure_scratch(1, off_bytes + init_bytes + 512)) return rc;
     if (int rc = ctx->ensure_scratch(2, out_bytes)) return rc;
-    uint64_t *d_hv = (uint64_t *)ctx->scratch[0];
+    char *d_hv = (char *)ctx->scratch[0];
     int64_t *d_off = offsets ? (int64_t *)ctx->scratch[1] : nullptr;
     uint64_t *d_init = init ? (uint64_t *)((char *)ctx->scratch[1] + ((off_bytes + 255) & ~(size_t)255)) : nullptr;
-    uint64_t *d_out = (uint64_t *)ctx->scratch[2];
+    char *d_out = (char *)ctx->scratch[2];
 
     // large corpora: upload, kernels and download overlap piece by piece
     const int64_t chunk_opt = ctx->opt_host_chunk_bytes;
     const int64_t target = chunk_opt > 0 ? chunk_opt : (int64_t)96 << 20;
     const bool pipelined = chunk_opt > 0 || (chunk_opt == 0 && hv_bytes + out_bytes > ((size_t)256 << 20));
     if (pipelined) {
-        const std::vector<Piece> pieces = cut_pieces(offsets, fixed_len, n_sets, k, target);
+        const std::vector<Piece> pieces = cut_pieces(offsets, fixed_len, n_sets, k, target, (int64_t)ts, (int64_t)os);
         if (pieces.size() > 1) {
             // small operands first, on the compute stream: every piece's kernels are ordered after them
             if (off_bytes) MHX_HIP_CHECK(hipMemcpyAsync(d_off, offsets, off_bytes, hipMemcpyHostToDevice, ctx->stream));
             if (init && !init_stride)
                 MHX_HIP_CHECK(hipMemcpyAsync(d_init, init, init_bytes, hipMemcpyHostToDevice, ctx->stream));
-            const int rc = bulk_pipelined(perm, hv, offsets, fixed_len, n_sets, init, init_stride, out, d_hv, d_off, d_init,
-                                          d_out, pieces);
+            const int rc = bulk_pipelined(perm, (const char *)hv, hv_dtype, offsets, fixed_len, n_sets, init, init_stride,
+                                          (char *)out, out_dtype, d_hv, d_off, d_init, d_out, pieces);
             if (rc != kNoSecondThread) return rc;
         }
     }
     if (hv_bytes) MHX_HIP_CHECK(hipMemcpyAsync(d_hv, hv, hv_bytes, hipMemcpyHostToDevice, ctx->stream));
     if (off_bytes) MHX_HIP_CHECK(hipMemcpyAsync(d_off, offsets, off_bytes, hipMemcpyHostToDevice, ctx->stream));
     if (init_bytes) MHX_HIP_CHECK(hipMemcpyAsync(d_init, init, init_bytes, hipMemcpyHostToDevice, ctx->stream));
-    if (int rc = mhx::launch_minhash_bulk(perm, d_hv, MHX_U64, d_off, fixed_len, n_sets, total, d_init,
-                                          init_stride, d_out, MHX_U64))
+    if (int rc = mhx::launch_minhash_bulk(perm, d_hv, hv_dtype, d_off, fixed_len, n_sets, total, d_init,
+                                          init_stride, d_out, out_dtype))
         return rc;
     MHX_HIP_CHECK(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return MHX_OK;
 }
 
+int mhx_minhash_bulk(mhx_perm *perm, const uint64_t *hv, const int64_t *offsets, int64_t fixed_len,
+                     int64_t n_sets, const uint64_t *init, int64_t init_stride, uint64_t *out) {
+    return mhx_minhash_bulk_typed(perm, hv, MHX_U64, offsets, fixed_len, n_sets, init, init_stride, out, MHX_U64);
+}
+
 // ---- token hashing (sha1_hash32 / sha1_hash64 of byte tokens) ----------------------------------
 int mhx_sha1_tokens_dev(mhx_ctx *ctx, const uint8_t *d_bytes, const int64_t *d_byte_offsets, int64_t n_tokens,
                         int out_dtype, void *d_out) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(n_tokens >= 0, "n_tokens must be >= 0");
     MHX_REQUIRE(out_dtype == MHX_U32 || out_dtype == MHX_U64, "out_dtype must be MHX_U32 or MHX_U64");
     if (n_tokens == 0) return MHX_OK;
@@ -622,6 +652,7 @@ int upload_tokens(mhx_ctx *ctx, const uint8_t *bytes, const int64_t *byte_offset
 int mhx_sha1_tokens(mhx_ctx *ctx, const uint8_t *bytes, const int64_t *byte_offsets, int64_t n_tokens,
                     int out_dtype, void *out) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(n_tokens >= 0, "n_tokens must be >= 0");
     MHX_REQUIRE(out_dtype == MHX_U32 || out_dtype == MHX_U64, "out_dtype must be MHX_U32 or MHX_U64");
     if (n_tokens == 0) return MHX_OK;
@@ -641,7 +672,15 @@ int mhx_sha1_tokens(mhx_ctx *ctx, const uint8_t *bytes, const int64_t *byte_offs
 int mhx_minhash_bulk_bytes(mhx_perm *perm, const uint8_t *bytes, const int64_t *byte_offsets, int64_t n_tokens,
                            const int64_t *set_offsets, int64_t n_sets, const uint64_t *init, int64_t init_stride,
                            uint64_t *out) {
+    return mhx_minhash_bulk_bytes_typed(perm, bytes, byte_offsets, n_tokens, MHX_U32, set_offsets, n_sets, init, init_stride, out);
+}
+
+int mhx_minhash_bulk_bytes_typed(mhx_perm *perm, const uint8_t *bytes, const int64_t *byte_offsets, int64_t n_tokens,
+                                 int hash_dtype, const int64_t *set_offsets, int64_t n_sets, const uint64_t *init,
+                                 int64_t init_stride, uint64_t *out) {
     if (!perm) return fail(MHX_ERR_INVALID, "perm is NULL");
+    MHX_GUARD(perm->ctx);
+    MHX_REQUIRE(hash_dtype == MHX_U32 || hash_dtype == MHX_U64, "hash_dtype must be MHX_U32 (sha1_hash32) or MHX_U64 (sha1_hash64)");
     MHX_REQUIRE(n_sets >= 0 && n_tokens >= 0, "n_sets and n_tokens must be >= 0");
     if (n_sets == 0) return MHX_OK;
     MHX_REQUIRE(out && set_offsets, "out/set_offsets is NULL");
@@ -655,21 +694,22 @@ int mhx_minhash_bulk_bytes(mhx_perm *perm, const uint8_t *bytes, const int64_t *
     int64_t *d_boffs = nullptr;
     if (n_tokens > 0)
         if (int rc = upload_tokens(ctx, bytes, byte_offsets, n_tokens, &d_bytes, &d_boffs)) return rc;
-    // scratch[1]: set offsets | init | uint32 token hashes;  scratch[2]: signatures
+    // scratch[1]: set offsets | init | token hashes (uint32 or uint64);  scratch[2]: signatures
+    const size_t hs = hash_dtype == MHX_U32 ? 4 : 8;
     const size_t off_bytes = sizeof(int64_t) * (size_t)(n_sets + 1);
     const size_t init_bytes = init ? sizeof(uint64_t) * (size_t)(init_stride ? n_sets * init_stride : k) : 0;
     const size_t off_pad = (off_bytes + 255) & ~(size_t)255, init_pad = (init_bytes + 255) & ~(size_t)255;
     const size_t out_bytes = sizeof(uint64_t) * (size_t)(n_sets * k);
-    if (int rc = ctx->ensure_scratch(1, off_pad + init_pad + sizeof(uint32_t) * (size_t)n_tokens + 256)) return rc;
+    if (int rc = ctx->ensure_scratch(1, off_pad + init_pad + hs * (size_t)n_tokens + 256)) return rc;
     if (int rc = ctx->ensure_scratch(2, out_bytes)) return rc;
     int64_t *d_soffs = (int64_t *)ctx->scratch[1];
     uint64_t *d_init = init ? (uint64_t *)((char *)ctx->scratch[1] + off_pad) : nullptr;
-    uint32_t *d_hv = (uint32_t *)((char *)ctx->scratch[1] + off_pad + init_pad);
+    void *d_hv = (char *)ctx->scratch[1] + off_pad + init_pad;
     uint64_t *d_out = (uint64_t *)ctx->scratch[2];
     MHX_HIP_CHECK(hipMemcpyAsync(d_soffs, set_offsets, off_bytes, hipMemcpyHostToDevice, ctx->stream));
     if (init_bytes) MHX_HIP_CHECK(hipMemcpyAsync(d_init, init, init_bytes, hipMemcpyHostToDevice, ctx->stream));
-    if (int rc = mhx::launch_sha1_tokens(ctx, d_bytes, d_boffs, n_tokens, MHX_U32, d_hv)) return rc;
-    if (int rc = mhx::launch_minhash_bulk(perm, d_hv, MHX_U32, d_soffs, 0, n_sets, n_tokens, d_init, init_stride, d_out,
+    if (int rc = mhx::launch_sha1_tokens(ctx, d_bytes, d_boffs, n_tokens, hash_dtype, d_hv)) return rc;
+    if (int rc = mhx::launch_minhash_bulk(perm, d_hv, hash_dtype, d_soffs, 0, n_sets, n_tokens, d_init, init_stride, d_out,
                                           MHX_U64))
         return rc;
     MHX_HIP_CHECK(hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -679,6 +719,7 @@ int mhx_minhash_bulk_bytes(mhx_perm *perm, const uint8_t *bytes, const int64_t *
 
 int mhx_minhash_update_batch(mhx_perm *perm, const uint64_t *hv, int64_t n, uint64_t *hashvalues) {
     if (!perm) return fail(MHX_ERR_INVALID, "perm is NULL");
+    MHX_GUARD(perm->ctx);
     MHX_REQUIRE(n >= 0, "n must be >= 0");
     if (n == 0) return MHX_OK;  // ref: minhash.py:265-266
     MHX_REQUIRE(hv && hashvalues, "hv/hashvalues is NULL");
@@ -688,6 +729,7 @@ int mhx_minhash_update_batch(mhx_perm *perm, const uint64_t *hv, int64_t n, uint
 int mhx_minhash_merge_dev(mhx_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y, int64_t count,
                           uint64_t *d_out) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(count >= 0, "count must be >= 0");
     if (count == 0) return MHX_OK;
     MHX_REQUIRE(d_x && d_y && d_out, "NULL device pointer");
@@ -697,6 +739,7 @@ int mhx_minhash_merge_dev(mhx_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y
 
 int mhx_minhash_merge(mhx_ctx *ctx, const uint64_t *x, const uint64_t *y, int64_t count, uint64_t *out) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(count >= 0, "count must be >= 0");
     if (count == 0) return MHX_OK;
     MHX_REQUIRE(x && y && out, "NULL host pointer");
@@ -726,17 +769,70 @@ int mhx_bbit_num_blocks(int32_t num_perm, int32_t b, int32_t *num_blocks) {
 int mhx_bbit_pack_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t b,
                       uint64_t *d_out) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(b >= 0 && b <= 32, "b must be an integer in [0, 32]");
     MHX_REQUIRE(k > 0 && n >= 0, "bad shape");
     if (n == 0) return MHX_OK;
     MHX_REQUIRE(d_sig && d_out, "NULL device pointer");
     if (int rc = ctx->activate()) return rc;
-    return mhx::launch_bbit_pack(ctx, d_sig, n, k, b, d_out);
+    return mhx::launch_bbit_pack(ctx, d_sig, MHX_U64, n, k, b, d_out);
+}
+
+int mhx_bbit_pack_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t b,
+                            uint64_t *d_out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    MHX_REQUIRE(sig_dtype == MHX_U64 || sig_dtype == MHX_U32, "bad sig_dtype %d", sig_dtype);
+    MHX_REQUIRE(b >= 0 && b <= 32, "b must be an integer in [0, 32]");
+    MHX_REQUIRE(k > 0 && n >= 0, "bad shape");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(d_sig && d_out, "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_bbit_pack(ctx, d_sig, sig_dtype, n, k, b, d_out);
+}
+
+int mhx_band_digests_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t bands,
+                               int32_t r, uint64_t *d_out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    MHX_REQUIRE(sig_dtype == MHX_U64 || sig_dtype == MHX_U32, "bad sig_dtype %d", sig_dtype);
+    MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
+    MHX_REQUIRE(n >= 0, "bad shape");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(d_sig && d_out, "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_band_digests(ctx, d_sig, sig_dtype, n, k, bands, r, d_out);
+}
+
+int mhx_lsh_sort_bands_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t bands,
+                                 int32_t r, uint64_t *d_sorted_digests, uint32_t *d_sorted_rows) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    MHX_REQUIRE(sig_dtype == MHX_U64 || sig_dtype == MHX_U32, "bad sig_dtype %d", sig_dtype);
+    MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
+    MHX_REQUIRE(n >= 0, "bad shape");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(d_sig && d_sorted_digests && d_sorted_rows, "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_lsh_sort_bands(ctx, d_sig, sig_dtype, n, k, bands, r, d_sorted_digests, d_sorted_rows);
+}
+
+int mhx_jaccard_pairs_dev_typed(mhx_ctx *ctx, const void *d_sig_a, const void *d_sig_b, int sig_dtype, int32_t k,
+                                const int64_t *d_pairs, int64_t n_pairs, int32_t *d_counts) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    MHX_REQUIRE(sig_dtype == MHX_U64 || sig_dtype == MHX_U32, "bad sig_dtype %d", sig_dtype);
+    MHX_REQUIRE(k > 0 && n_pairs >= 0, "bad shape");
+    if (n_pairs == 0) return MHX_OK;
+    MHX_REQUIRE(d_sig_a && d_sig_b && d_pairs && d_counts, "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_jaccard_pairs(ctx, d_sig_a, d_sig_b, sig_dtype, k, d_pairs, n_pairs, d_counts);
 }
 
 int mhx_band_keys_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands,
                       int32_t r, uint64_t *d_out) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
     MHX_REQUIRE(n >= 0, "bad shape");
     if (n == 0) return MHX_OK;
@@ -748,6 +844,7 @@ int mhx_band_keys_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k,
 int mhx_lean_serialize_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int64_t seed,
                            uint8_t *d_out) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(k > 0 && n >= 0, "bad shape");
     if (n == 0) return MHX_OK;
     MHX_REQUIRE(d_sig && d_out, "NULL device pointer");
@@ -773,6 +870,7 @@ static int fetch_out(mhx_ctx *ctx, void *out, size_t out_bytes) {
 
 int mhx_bbit_pack(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int32_t b, uint64_t *out) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     int32_t nb = 0;
     if (int rc = mhx_bbit_num_blocks(k, b, &nb)) return rc;
     MHX_REQUIRE(n >= 0, "bad shape");
@@ -780,7 +878,7 @@ int mhx_bbit_pack(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int32
     MHX_REQUIRE(sig && out, "NULL host pointer");
     const size_t out_bytes = sizeof(uint64_t) * (size_t)(n * nb);
     if (int rc = stage_sig(ctx, sig, n, k, out_bytes)) return rc;
-    if (int rc = mhx::launch_bbit_pack(ctx, (const uint64_t *)ctx->scratch[0], n, k, b, (uint64_t *)ctx->scratch[2]))
+    if (int rc = mhx::launch_bbit_pack(ctx, ctx->scratch[0], MHX_U64, n, k, b, (uint64_t *)ctx->scratch[2]))
         return rc;
     return fetch_out(ctx, out, out_bytes);
 }
@@ -788,6 +886,7 @@ int mhx_bbit_pack(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int32
 int mhx_band_keys(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int32_t bands, int32_t r,
                   uint64_t *out) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
     MHX_REQUIRE(n >= 0, "bad shape");
     if (n == 0) return MHX_OK;
@@ -803,24 +902,26 @@ int mhx_band_keys(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int32
 int mhx_band_digests_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
                          uint64_t *d_out) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
     MHX_REQUIRE(n >= 0, "bad shape");
     if (n == 0) return MHX_OK;
     MHX_REQUIRE(d_sig && d_out, "NULL device pointer");
     if (int rc = ctx->activate()) return rc;
-    return mhx::launch_band_digests(ctx, d_sig, n, k, bands, r, d_out);
+    return mhx::launch_band_digests(ctx, d_sig, MHX_U64, n, k, bands, r, d_out);
 }
 
 int mhx_band_digests(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int32_t bands, int32_t r,
                      uint64_t *out) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
     MHX_REQUIRE(n >= 0, "bad shape");
     if (n == 0) return MHX_OK;
     MHX_REQUIRE(sig && out, "NULL host pointer");
     const size_t out_bytes = sizeof(uint64_t) * (size_t)(n * bands);
     if (int rc = stage_sig(ctx, sig, n, k, out_bytes)) return rc;
-    if (int rc = mhx::launch_band_digests(ctx, (const uint64_t *)ctx->scratch[0], n, k, bands, r,
+    if (int rc = mhx::launch_band_digests(ctx, ctx->scratch[0], MHX_U64, n, k, bands, r,
                                           (uint64_t *)ctx->scratch[2]))
         return rc;
     return fetch_out(ctx, out, out_bytes);
@@ -829,17 +930,19 @@ int mhx_band_digests(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, in
 int mhx_lsh_sort_bands_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
                            uint64_t *d_sorted_digests, uint32_t *d_sorted_rows) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
     MHX_REQUIRE(n >= 0, "bad shape");
     if (n == 0) return MHX_OK;
     MHX_REQUIRE(d_sig && d_sorted_digests && d_sorted_rows, "NULL device pointer");
     if (int rc = ctx->activate()) return rc;
-    return mhx::launch_lsh_sort_bands(ctx, d_sig, n, k, bands, r, d_sorted_digests, d_sorted_rows);
+    return mhx::launch_lsh_sort_bands(ctx, d_sig, MHX_U64, n, k, bands, r, d_sorted_digests, d_sorted_rows);
 }
 
 int mhx_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int32_t bands, int32_t r,
                        uint64_t *sorted_digests, uint32_t *sorted_rows) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
     MHX_REQUIRE(n >= 0, "bad shape");
     if (n == 0) return MHX_OK;
@@ -849,7 +952,7 @@ int mhx_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, 
     if (int rc = stage_sig(ctx, sig, n, k, dig_pad + row_bytes)) return rc;
     uint64_t *d_dig = (uint64_t *)ctx->scratch[2];
     uint32_t *d_rows = (uint32_t *)((char *)ctx->scratch[2] + dig_pad);
-    if (int rc = mhx::launch_lsh_sort_bands(ctx, (const uint64_t *)ctx->scratch[0], n, k, bands, r, d_dig, d_rows)) return rc;
+    if (int rc = mhx::launch_lsh_sort_bands(ctx, ctx->scratch[0], MHX_U64, n, k, bands, r, d_dig, d_rows)) return rc;
     MHX_HIP_CHECK(hipMemcpyAsync(sorted_digests, d_dig, dig_bytes, hipMemcpyDeviceToHost, ctx->stream));
     MHX_HIP_CHECK(hipMemcpyAsync(sorted_rows, d_rows, row_bytes, hipMemcpyDeviceToHost, ctx->stream));
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -859,6 +962,7 @@ int mhx_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, 
 int mhx_lsh_candidate_pairs_dev(mhx_ctx *ctx, const uint64_t *d_sorted_digests, const uint32_t *d_sorted_rows, int64_t n,
                                 int32_t bands, int64_t *d_pairs, int64_t capacity, int64_t *n_pairs, int64_t *n_raw) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(n_pairs, "n_pairs is NULL");
     MHX_REQUIRE(bands > 0 && n >= 0 && capacity >= 0, "bad shape");
     MHX_REQUIRE(n < ((int64_t)1 << 32), "more than 2^32-1 signatures per call");
@@ -873,6 +977,7 @@ int mhx_lsh_candidate_pairs_dev(mhx_ctx *ctx, const uint64_t *d_sorted_digests, 
 int mhx_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int32_t bands, int32_t r,
                             int64_t *pairs, int64_t capacity, int64_t *n_pairs, int64_t *n_raw) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(n_pairs, "n_pairs is NULL");
     MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
     MHX_REQUIRE(n >= 0 && capacity >= 0, "bad shape");
@@ -888,7 +993,7 @@ int mhx_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_
     uint64_t *d_dig = (uint64_t *)ctx->scratch[2];
     uint32_t *d_rows = (uint32_t *)((char *)ctx->scratch[2] + dig_bytes);
     int64_t *d_pairs = (int64_t *)((char *)ctx->scratch[2] + dig_bytes + row_bytes);
-    if (int rc = mhx::launch_lsh_sort_bands(ctx, (const uint64_t *)ctx->scratch[0], n, k, bands, r, d_dig, d_rows)) return rc;
+    if (int rc = mhx::launch_lsh_sort_bands(ctx, ctx->scratch[0], MHX_U64, n, k, bands, r, d_dig, d_rows)) return rc;
     if (int rc = mhx::launch_lsh_candidate_pairs(ctx, d_dig, d_rows, n, bands, d_pairs, capacity, n_pairs, n_raw)) return rc;
     if (*n_pairs > 0 && *n_pairs <= capacity)
         MHX_HIP_CHECK(hipMemcpyAsync(pairs, d_pairs, sizeof(int64_t) * 2 * (size_t)*n_pairs, hipMemcpyDeviceToHost, ctx->stream));
@@ -896,19 +1001,39 @@ int mhx_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_
     return MHX_OK;
 }
 
+int mhx_lsh_query_dev(mhx_ctx *ctx, const uint64_t *d_sorted_digests, const uint32_t *d_sorted_rows, int64_t n,
+                      int32_t bands, int32_t r, const void *d_query_sig, const void *d_index_sig, int sig_dtype,
+                      int32_t k, int64_t m, int64_t *d_pairs, int64_t capacity, int64_t *n_pairs) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    MHX_REQUIRE(n_pairs, "n_pairs is NULL");
+    MHX_REQUIRE(sig_dtype == MHX_U64 || sig_dtype == MHX_U32, "bad sig_dtype %d", sig_dtype);
+    MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
+    MHX_REQUIRE(n >= 0 && m >= 0 && capacity >= 0, "bad shape");
+    MHX_REQUIRE(n < ((int64_t)1 << 32) && m < ((int64_t)1 << 32), "more than 2^32-1 rows per call");
+    *n_pairs = 0;
+    if (n == 0 || m == 0) return MHX_OK;
+    MHX_REQUIRE(d_sorted_digests && d_sorted_rows && d_query_sig && (d_pairs || capacity == 0), "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_lsh_query(ctx, d_sorted_digests, d_sorted_rows, n, bands, r, d_query_sig, d_index_sig, sig_dtype, k, m,
+                                 d_pairs, capacity, n_pairs);
+}
+
 int mhx_jaccard_pairs_dev(mhx_ctx *ctx, const uint64_t *d_sig_a, const uint64_t *d_sig_b, int32_t k,
                           const int64_t *d_pairs, int64_t n_pairs, int32_t *d_counts) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(k > 0 && n_pairs >= 0, "bad shape");
     if (n_pairs == 0) return MHX_OK;
     MHX_REQUIRE(d_sig_a && d_sig_b && d_pairs && d_counts, "NULL device pointer");
     if (int rc = ctx->activate()) return rc;
-    return mhx::launch_jaccard_pairs(ctx, d_sig_a, d_sig_b, k, d_pairs, n_pairs, d_counts);
+    return mhx::launch_jaccard_pairs(ctx, d_sig_a, d_sig_b, MHX_U64, k, d_pairs, n_pairs, d_counts);
 }
 
 int mhx_jaccard_pairs(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, const int64_t *pairs,
                       int64_t n_pairs, int32_t *counts) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(k > 0 && n >= 0 && n_pairs >= 0, "bad shape");
     if (n_pairs == 0) return MHX_OK;
     MHX_REQUIRE(sig && pairs && counts, "NULL host pointer");
@@ -920,7 +1045,7 @@ int mhx_jaccard_pairs(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, c
     MHX_HIP_CHECK(hipMemcpyAsync(ctx->scratch[1], pairs, sizeof(int64_t) * 2 * (size_t)n_pairs, hipMemcpyHostToDevice,
                                  ctx->stream));
     const uint64_t *d_sig = (const uint64_t *)ctx->scratch[0];
-    if (int rc = mhx::launch_jaccard_pairs(ctx, d_sig, d_sig, k, (const int64_t *)ctx->scratch[1], n_pairs,
+    if (int rc = mhx::launch_jaccard_pairs(ctx, d_sig, d_sig, MHX_U64, k, (const int64_t *)ctx->scratch[1], n_pairs,
                                            (int32_t *)ctx->scratch[2]))
         return rc;
     return fetch_out(ctx, counts, out_bytes);
@@ -928,6 +1053,7 @@ int mhx_jaccard_pairs(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, c
 
 int mhx_lean_serialize(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int64_t seed, uint8_t *out) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(k > 0 && n >= 0, "bad shape");
     if (n == 0) return MHX_OK;
     MHX_REQUIRE(sig && out, "NULL host pointer");
@@ -943,6 +1069,7 @@ int mhx_lean_serialize(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, 
 int mhx_wgen_create(mhx_ctx *ctx, const float *rs, const float *ln_cs, const float *betas,
                     int32_t sample_size, int32_t dim, mhx_wgen **out) {
     if (!ctx || !rs || !ln_cs || !betas || !out) return fail(MHX_ERR_INVALID, "NULL argument");
+    MHX_GUARD(ctx);
     MHX_REQUIRE(sample_size > 0 && dim > 0, "sample_size and dim must be positive");
     if (int rc = ctx->activate()) return rc;
     mhx_wgen *g = new mhx_wgen();
@@ -984,6 +1111,7 @@ int mhx_wgen_create(mhx_ctx *ctx, const float *rs, const float *ln_cs, const flo
 
 int mhx_wgen_destroy(mhx_wgen *gen) {
     if (!gen) return MHX_OK;
+    MHX_GUARD(gen->ctx);
     (void)hipSetDevice(gen->ctx->device);
     (void)hipStreamSynchronize(gen->ctx->stream);
     (void)hipFree(gen->d_params);
@@ -995,6 +1123,7 @@ int mhx_weighted_minhash_many_dev(mhx_wgen *gen, const int64_t *d_indptr, const 
                                   const float *d_values, int values_are_logs, int64_t n_rows,
                                   int64_t nnz, int64_t *d_out, uint8_t *d_nonempty) {
     if (!gen) return fail(MHX_ERR_INVALID, "gen is NULL");
+    MHX_GUARD(gen->ctx);
     MHX_REQUIRE(n_rows >= 0 && nnz >= 0, "bad shape");
     if (n_rows == 0) return MHX_OK;
     MHX_REQUIRE(d_indptr && d_out && d_nonempty, "NULL device pointer");
@@ -1008,6 +1137,7 @@ int mhx_weighted_minhash_many(mhx_wgen *gen, const int64_t *indptr, const int32_
                               const float *values, int values_are_logs, int64_t n_rows, int64_t *out,
                               uint8_t *nonempty) {
     if (!gen) return fail(MHX_ERR_INVALID, "gen is NULL");
+    MHX_GUARD(gen->ctx);
     MHX_REQUIRE(n_rows >= 0, "bad shape");
     if (n_rows == 0) return MHX_OK;
     MHX_REQUIRE(indptr && out && nonempty, "NULL host pointer");
@@ -1046,9 +1176,27 @@ int mhx_weighted_minhash_many(mhx_wgen *gen, const int64_t *indptr, const int32_
     return MHX_OK;
 }
 
+int mhx_weighted_logf(mhx_ctx *ctx, const float *x, int64_t n, float *out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    MHX_REQUIRE(n >= 0, "bad shape");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(x && out, "NULL host pointer");
+    if (int rc = ctx->activate()) return rc;
+    const size_t bytes = sizeof(float) * (size_t)n;
+    if (int rc = ctx->ensure_scratch(0, bytes)) return rc;
+    if (int rc = ctx->ensure_scratch(2, bytes)) return rc;
+    MHX_HIP_CHECK(hipMemcpyAsync(ctx->scratch[0], x, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = mhx::launch_weighted_log(ctx, (const float *)ctx->scratch[0], n, (float *)ctx->scratch[2])) return rc;
+    MHX_HIP_CHECK(hipMemcpyAsync(out, ctx->scratch[2], bytes, hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MHX_OK;
+}
+
 int mhx_weighted_minhash_many_dense_dev(mhx_wgen *gen, const float *d_x, int values_are_logs, int64_t n_rows,
                                         int64_t *d_out, uint8_t *d_nonempty) {
     if (!gen) return fail(MHX_ERR_INVALID, "gen is NULL");
+    MHX_GUARD(gen->ctx);
     MHX_REQUIRE(n_rows >= 0, "bad shape");
     if (n_rows == 0) return MHX_OK;
     MHX_REQUIRE(d_x && d_out && d_nonempty, "NULL device pointer");
@@ -1059,6 +1207,7 @@ int mhx_weighted_minhash_many_dense_dev(mhx_wgen *gen, const float *d_x, int val
 int mhx_weighted_minhash_many_dense(mhx_wgen *gen, const float *x, int values_are_logs, int64_t n_rows, int64_t *out,
                                     uint8_t *nonempty) {
     if (!gen) return fail(MHX_ERR_INVALID, "gen is NULL");
+    MHX_GUARD(gen->ctx);
     MHX_REQUIRE(n_rows >= 0, "bad shape");
     if (n_rows == 0) return MHX_OK;
     MHX_REQUIRE(x && out && nonempty, "NULL host pointer");

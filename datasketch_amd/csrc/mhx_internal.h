@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 
@@ -28,6 +29,9 @@ int fail(int code, const char *fmt, ...);
         }                                                                                        \
     } while (0)
 
+// serialise the calls on one context (see mhx_ctx::mu)
+#define MHX_GUARD(ctxp) std::lock_guard<std::recursive_mutex> _mhx_guard((ctxp)->mu)
+
 #define MHX_REQUIRE(cond, ...)                                       \
     do {                                                             \
         if (!(cond)) return ::mhx::fail(MHX_ERR_INVALID, __VA_ARGS__); \
@@ -37,6 +41,9 @@ int fail(int code, const char *fmt, ...);
 
 // Opaque handle layouts (C linkage names are declared in mhx.h).
 struct mhx_ctx {
+    // One stream, one set of staging buffers: calls on a context are serialised (ctypes releases the GIL, so
+    // two Python threads can be inside libmhx at once).  Recursive: host entry points call each other.
+    std::recursive_mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 0;
@@ -110,25 +117,28 @@ int launch_minhash_merge(mhx_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y,
 int launch_weighted(mhx_wgen *gen, const int64_t *d_indptr, const int32_t *d_indices,
                     const float *d_values, int values_are_logs, int64_t n_rows, int64_t nnz,
                     int64_t *d_out, uint8_t *d_nonempty);
+int launch_weighted_log(mhx_ctx *ctx, const float *d_x, int64_t n, float *d_out);
 int launch_wgen_transpose(mhx_wgen *gen, const float *d_rs, const float *d_lncs, const float *d_betas);
-int launch_bbit_pack(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t b,
+int launch_bbit_pack(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t b,
                      uint64_t *d_out);
 int launch_band_keys(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands,
                      int32_t r, uint64_t *d_out);
-int launch_band_digests(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
+int launch_band_digests(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t bands, int32_t r,
                         uint64_t *d_out);
-int launch_jaccard_pairs(mhx_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, int32_t k, const int64_t *d_pairs,
+int launch_jaccard_pairs(mhx_ctx *ctx, const void *d_a, const void *d_b, int sig_dtype, int32_t k, const int64_t *d_pairs,
                          int64_t m, int32_t *d_counts);
 int launch_weighted_dense(mhx_wgen *gen, const float *d_x, int values_are_logs, int64_t n_rows, int64_t *d_out,
                           uint8_t *d_nonempty);
 int launch_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *d_sorted_digests, const uint32_t *d_sorted_rows, int64_t n,
                                int32_t bands, int64_t *d_pairs, int64_t capacity, int64_t *n_pairs, int64_t *n_raw);
-int launch_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
+int launch_lsh_sort_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t bands, int32_t r,
                           uint64_t *d_sorted_digests, uint32_t *d_sorted_rows);
+int launch_lsh_query(mhx_ctx *ctx, const uint64_t *d_sorted_digests, const uint32_t *d_sorted_rows, int64_t n, int32_t bands,
+                     int32_t r, const void *d_q_sig, const void *d_idx_sig, int sig_dtype, int32_t k, int64_t m,
+                     int64_t *d_pairs, int64_t capacity, int64_t *n_pairs);
 int launch_lean_serialize(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int64_t seed,
                           uint8_t *d_out);
 
 int bbit_slot_size(int b);
-void preload_rccl();
 
 }  // namespace mhx

@@ -13,7 +13,8 @@ constexpr int kWave = 64;
 // n = 64/slot values sits at bit (n-1-j)*slot).  Lane l of a wave handles value kk0+l of a row;
 // the `per` lanes of one block OR their shifted contributions together with a butterfly of
 // DPP/shuffle steps and the first lane of the group stores the block.
-__global__ __launch_bounds__(256) void bbit_pack_kernel(const uint64_t *__restrict__ sig, int64_t n,
+template <typename SigT>
+__global__ __launch_bounds__(256) void bbit_pack_kernel(const SigT *__restrict__ sig, int64_t n,
                                                         int32_t k, int32_t b, int32_t slot,
                                                         int32_t nb, uint64_t *__restrict__ out) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -27,19 +28,19 @@ __global__ __launch_bounds__(256) void bbit_pack_kernel(const uint64_t *__restri
     const int blocks_per_iter = kWave / per;      // blocks a wave finishes per 64 values
     for (int64_t row = (int64_t)blockIdx.x * waves_per_block + wave; row < n;
          row += (int64_t)gridDim.x * waves_per_block) {
-        const uint64_t *src = sig + row * k;
+        const SigT *src = sig + row * k;
         uint64_t *dst = out + row * nb;
         for (int kk0 = 0; kk0 < padded; kk0 += kWave) {
             const int kk = kk0 + lane;
             if (slot == 1) {
                 // one bit per value: the wave's ballot IS the block, lane 0 holding the top bit
                 // (3.0 -> 4.9 TB/s; the shuffle butterfly below is what bounds the other widths)
-                const uint64_t bits = __brevll(__ballot(kk < k && (src[kk] & 1ull) != 0));
+                const uint64_t bits = __brevll(__ballot(kk < k && (src[kk] & 1u) != 0));
                 if (lane == 0) dst[kk0 >> 6] = bits;
                 continue;
             }
             uint64_t v = 0;
-            if (kk < k) v = ((uint64_t)(uint32_t)(src[kk] & mask)) << shift;
+            if (kk < k) v = ((uint64_t)(uint32_t)((uint64_t)src[kk] & mask)) << shift;
             // OR-reduce across the `per` lanes of the block
             for (int d = 1; d < per; d <<= 1) {
                 const uint32_t lo = __shfl_xor((uint32_t)v, d);
@@ -108,7 +109,8 @@ __global__ __launch_bounds__(256) void lean_serialize_kernel(const uint64_t *__r
 // uses as that band's dictionary key (ref: datasketch/lsh.py:199,344,537-538: the r hashvalues of the
 // band, each as 8 big-endian bytes).  It is what MinHashLSH(hashfunc=fnv1a_64) would store
 // (ref: lsh.py:540-543), in a form a device-side sort can group by.  One lane per (row, band).
-__global__ __launch_bounds__(256) void band_digest_kernel(const uint64_t *__restrict__ sig, int64_t n, int32_t k,
+template <typename SigT>
+__global__ __launch_bounds__(256) void band_digest_kernel(const SigT *__restrict__ sig, int64_t n, int32_t k,
                                                           int32_t bands, int32_t r, uint64_t *__restrict__ out) {
     constexpr uint64_t kPrime = 0x100000001b3ull;
     constexpr uint64_t kPrime4 = kPrime * kPrime * kPrime * kPrime;  // four zero bytes: h ^= 0 leaves h, so h *= prime^4
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void band_digest_kernel(const uint64_t *__rest
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = idx / bands;
         const int band = (int)(idx - row * bands);
-        const uint64_t *src = sig + row * k + (int64_t)band * r;
+        const SigT *src = sig + row * k + (int64_t)band * r;
         uint64_t h = 0xcbf29ce484222325ull;
         const auto absorb = [&](uint64_t v) {
             const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
@@ -136,7 +138,21 @@ __global__ __launch_bounds__(256) void band_digest_kernel(const uint64_t *__rest
                 h *= kPrime;
             }
         };
-        if (((r | k) & 1) == 0 && (reinterpret_cast<uintptr_t>(sig) & 15) == 0) {
+        if constexpr (sizeof(SigT) == 4) {
+            // uint32 signatures (the all-gather's wire format): the key bytes are those of the widened value
+            if (((r | k) & 3) == 0 && (reinterpret_cast<uintptr_t>(sig) & 15) == 0) {
+                const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
+                for (int c = 0; c < r / 4; ++c) {
+                    const uint4 v = src4[c];
+                    absorb(v.x);
+                    absorb(v.y);
+                    absorb(v.z);
+                    absorb(v.w);
+                }
+            } else {
+                for (int c = 0; c < r; ++c) absorb(src[c]);
+            }
+        } else if (((r | k) & 1) == 0 && (reinterpret_cast<uintptr_t>(sig) & 15) == 0) {
             // 16-byte loads: a lane's band is r*8 contiguous bytes, but neighbouring lanes are r*8 bytes
             // apart, so every load instruction touches many lines -- fewer, wider loads it is
             const ulonglong2 *src2 = reinterpret_cast<const ulonglong2 *>(src);
@@ -146,7 +162,7 @@ __global__ __launch_bounds__(256) void band_digest_kernel(const uint64_t *__rest
                 absorb(v.y);
             }
         } else {
-            for (int c = 0; c < r; ++c) absorb(src[c]);
+            for (int c = 0; c < r; ++c) absorb((uint64_t)src[c]);
         }
         out[idx] = h;
     }
@@ -156,15 +172,16 @@ __global__ __launch_bounds__(256) void band_digest_kernel(const uint64_t *__rest
 // counts[p] = number of positions where signature rows pairs[p][0] (of A) and pairs[p][1] (of B) agree;
 // MinHash.jaccard is counts / K (ref: datasketch/minhash.py:299-324).  One wave per pair, lanes
 // over the K positions (coalesced row reads), ballot + popcount.
-__global__ __launch_bounds__(256) void jaccard_pairs_kernel(const uint64_t *__restrict__ a, const uint64_t *__restrict__ b,
+template <typename SigT>
+__global__ __launch_bounds__(256) void jaccard_pairs_kernel(const SigT *__restrict__ a, const SigT *__restrict__ b,
                                                             int32_t k, const int64_t *__restrict__ pairs, int64_t m,
                                                             int32_t *__restrict__ counts) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     const int waves_per_block = blockDim.x >> 6;
     for (int64_t p = (int64_t)blockIdx.x * waves_per_block + wave; p < m; p += (int64_t)gridDim.x * waves_per_block) {
-        const uint64_t *x = a + pairs[2 * p] * k;
-        const uint64_t *y = b + pairs[2 * p + 1] * k;
+        const SigT *x = a + pairs[2 * p] * k;
+        const SigT *y = b + pairs[2 * p + 1] * k;
         int32_t cnt = 0;
         for (int c = lane; c < k + lane; c += kWave) {  // uniform trip count: every lane reaches the ballot
             const bool eq = c < k && x[c] == y[c];
@@ -181,13 +198,17 @@ inline dim3 row_grid(mhx_ctx *ctx, int64_t n) {
 
 }  // namespace
 
-int launch_bbit_pack(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t b,
+int launch_bbit_pack(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t b,
                      uint64_t *d_out) {
     const int slot = bbit_slot_size(b);
     const int per = 64 / slot;
     const int nb = (k + per - 1) / per;
-    hipLaunchKernelGGL(bbit_pack_kernel, row_grid(ctx, n), dim3(256), 0, ctx->stream, d_sig, n, k, b, slot,
-                       nb, d_out);
+    if (sig_dtype == MHX_U32)
+        hipLaunchKernelGGL(bbit_pack_kernel<uint32_t>, row_grid(ctx, n), dim3(256), 0, ctx->stream, (const uint32_t *)d_sig, n,
+                           k, b, slot, nb, d_out);
+    else
+        hipLaunchKernelGGL(bbit_pack_kernel<uint64_t>, row_grid(ctx, n), dim3(256), 0, ctx->stream, (const uint64_t *)d_sig, n,
+                           k, b, slot, nb, d_out);
     MHX_HIP_CHECK(hipGetLastError());
     return MHX_OK;
 }
@@ -210,19 +231,26 @@ int launch_band_keys(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, 
     return MHX_OK;
 }
 
-int launch_band_digests(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
+int launch_band_digests(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t bands, int32_t r,
                         uint64_t *d_out) {
     const int64_t want = (n * bands + 255) / 256;
     dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * 16)));
-    hipLaunchKernelGGL(band_digest_kernel, grid, dim3(256), 0, ctx->stream, d_sig, n, k, bands, r, d_out);
+    if (sig_dtype == MHX_U32)
+        hipLaunchKernelGGL(band_digest_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, (const uint32_t *)d_sig, n, k, bands, r, d_out);
+    else
+        hipLaunchKernelGGL(band_digest_kernel<uint64_t>, grid, dim3(256), 0, ctx->stream, (const uint64_t *)d_sig, n, k, bands, r, d_out);
     MHX_HIP_CHECK(hipGetLastError());
     return MHX_OK;
 }
 
-int launch_jaccard_pairs(mhx_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, int32_t k, const int64_t *d_pairs,
+int launch_jaccard_pairs(mhx_ctx *ctx, const void *d_a, const void *d_b, int sig_dtype, int32_t k, const int64_t *d_pairs,
                          int64_t m, int32_t *d_counts) {
-    hipLaunchKernelGGL(jaccard_pairs_kernel, row_grid(ctx, m), dim3(256), 0, ctx->stream, d_a, d_b, k, d_pairs, m,
-                       d_counts);
+    if (sig_dtype == MHX_U32)
+        hipLaunchKernelGGL(jaccard_pairs_kernel<uint32_t>, row_grid(ctx, m), dim3(256), 0, ctx->stream, (const uint32_t *)d_a,
+                           (const uint32_t *)d_b, k, d_pairs, m, d_counts);
+    else
+        hipLaunchKernelGGL(jaccard_pairs_kernel<uint64_t>, row_grid(ctx, m), dim3(256), 0, ctx->stream, (const uint64_t *)d_a,
+                           (const uint64_t *)d_b, k, d_pairs, m, d_counts);
     MHX_HIP_CHECK(hipGetLastError());
     return MHX_OK;
 }

@@ -433,6 +433,20 @@ int launch_weighted_dense(mhx_wgen *gen, const float *d_x, int values_are_logs, 
     return launch_weighted(gen, d_indptr, d_indices, d_values, values_are_logs, n_rows, n_rows * (int64_t)dim, d_out, d_nonempty);
 }
 
+// the log of the device-log mode on its own (tests and the bench's tolerance gate look at it)
+__global__ __launch_bounds__(256) void weighted_log_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = logf(x[i]);
+}
+
+int launch_weighted_log(mhx_ctx *ctx, const float *d_x, int64_t n, float *d_out) {
+    const int64_t want = (n + 255) / 256;
+    hipLaunchKernelGGL(weighted_log_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * 16))),
+                       dim3(256), 0, ctx->stream, d_x, n, d_out);
+    MHX_HIP_CHECK(hipGetLastError());
+    return MHX_OK;
+}
+
 int launch_weighted(mhx_wgen *gen, const int64_t *d_indptr, const int32_t *d_indices, const float *d_values,
                     int values_are_logs, int64_t n_rows, int64_t nnz, int64_t *d_out, uint8_t *d_nonempty) {
     mhx_ctx *ctx = gen->ctx;

@@ -3,25 +3,25 @@
 The path is embarrassingly parallel over sets (every rank needs only the 2*K permutation
 parameters, regenerated from the seed), so the compute phase has NO collective.  The only
 exchange step is the optional assembly of the full ``[N, K]`` signature matrix on every rank
-(an all-gather of row shards) when one consumer -- e.g. ``MinHashLSH.insert`` -- needs it whole.
+(an all-gather of row shards) when one consumer -- ``MinHashLSH`` insertion, b-bit packing and
+band hashing of the whole corpus -- needs it whole.
 
 On the GPU the collective is RCCL over xGMI through libmhx's own binding (``mhx_comm_*`` in
 include/mhx.h, :class:`datasketch_amd._native.Communicator`): device buffers in, device buffer
-out, enqueued on the kernel's stream.  ``torch.distributed`` is plumbing only -- a ``gloo`` group
-carries the 128-byte RCCL id and the shard sizes, and is the CPU stand-in for the collective in
-the tests (PyTorch never touches the GPU in this package).
+out, enqueued on the kernel's stream, uint32 on the wire (signature values are < 2**32: half the
+bytes).  Host-side plumbing -- the 128-byte RCCL id, shard sizes, barriers -- goes over
+:mod:`datasketch_amd.rendezvous` (plain TCP, no PyTorch); on a host without GPUs the same group
+carries the shards themselves, which is what the CPU tests exercise.  Any object with ``rank``,
+``world`` and ``allgather(bytes) -> list[bytes]`` can stand in for the group (the tests wrap a
+``torch.distributed`` gloo group that way).
 """
 from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
-import os
-
 import numpy as np
 
-# A program that imports this module means to use the RCCL path: libmhx then loads RCCL when the context
-# is created (before a PyTorch-ROCm wheel brings its own ROCm runtime into the process) instead of lazily.
-os.environ.setdefault("MHX_PRELOAD_RCCL", "1")
+from datasketch_amd import rendezvous
 
 
 def shard_rows(n_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
@@ -48,101 +48,135 @@ def shard_by_tokens(offsets: Sequence[int], world_size: int) -> List[Tuple[int, 
     return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
 
 
+def _group(group):
+    return group if group is not None else rendezvous.Group(0, 1)
+
+
+def gather_counts(n_local: int, group=None) -> List[int]:
+    """Rows held by every rank, in rank order."""
+    g = _group(group)
+    return [int(np.frombuffer(p, dtype=np.int64)[0]) for p in g.allgather(np.int64(n_local).tobytes())]
+
+
 def allgather_signatures(local: np.ndarray, group=None, counts: Optional[Sequence[int]] = None) -> np.ndarray:
-    """Assemble the full signature matrix from per-rank row shards (host arrays in, host array out).
-
-    ``local`` is this rank's ``[n_r, K]`` uint64 shard.  Values are < 2**32, so shards travel as
-    uint32 (half the bytes on the wire) and are widened on arrival.  Unequal shard sizes are
-    padded to the largest (``counts`` = rows per rank; gathered first when not given).
-    """
-    import torch
-    import torch.distributed as dist
-
-    if not dist.is_initialized():
-        return np.asarray(local, dtype=np.uint64)
-    world = dist.get_world_size(group)
+    """Assemble the full signature matrix from per-rank row shards (host arrays in, host array out):
+    the CPU stand-in for the RCCL all-gather.  ``local`` is this rank's ``[n_r, K]`` uint64 shard;
+    values are < 2**32, so shards travel as uint32 and are widened on arrival.  Shards may be unequal."""
+    g = _group(group)
     local = np.ascontiguousarray(local, dtype=np.uint64)
-    k = local.shape[1]
-    dev = torch.device("cpu")  # host arrays travel over gloo; device shards use allgather_signatures_dev
-    if counts is None:
-        c = torch.tensor([local.shape[0]], dtype=torch.int64, device=dev)
-        all_c = torch.zeros(world, dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(all_c, c, group=group)
-        counts = [int(x) for x in all_c.cpu().tolist()]
+    if g.world == 1:
+        return local
+    if local.ndim != 2:
+        raise ValueError("a signature shard is a 2-D array")
     if np.any(local > np.uint64(0xFFFFFFFF)):
         raise ValueError("signature values >= 2**32 cannot use the uint32 wire format")
-    width = max(counts) if counts else 0
-    send = np.zeros((width, k), dtype=np.int32)
-    send[: local.shape[0]] = local.astype(np.uint32).view(np.int32)
-    t_send = torch.from_numpy(send).to(dev)
-    t_recv = torch.empty((world * width, k), dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(t_recv, t_send, group=group)
-    recv = t_recv.cpu().numpy().view(np.uint32).reshape(world, width, k)
-    parts = [recv[r, : counts[r]] for r in range(world)]
-    return np.concatenate(parts, axis=0).astype(np.uint64)
+    k = local.shape[1]
+    parts = g.allgather(local.astype(np.uint32).tobytes())
+    mats = [np.frombuffer(p, dtype=np.uint32).reshape(-1, k) for p in parts]
+    if counts is not None and [m.shape[0] for m in mats] != [int(c) for c in counts]:
+        raise ValueError("shard sizes differ from the counts given")
+    return np.concatenate(mats, axis=0).astype(np.uint64)
 
 
 _COMM_CACHE = {}
 
 
-def communicator(ctx, group=None):
+def communicator(ctx, group):
     """The RCCL communicator of this rank's context for ``group`` (created once: rank 0 makes the
-    id, a gloo broadcast hands it out)."""
+    128-byte id, the group's broadcast hands it out)."""
     from datasketch_amd import _native
 
-    _native.check(_native.load().mhx_comm_preload())  # RCCL before torch's own ROCm runtime enters the process
-    import torch.distributed as dist
-
     key = (id(ctx), id(group))
-    if key not in _COMM_CACHE:
-        from datasketch_amd import _native
+    comm = _COMM_CACHE.get(key)
+    if comm is None:
+        uid = _native.Communicator.unique_id() if group.rank == 0 else b""
+        uid = group.allgather(uid)[0]
+        comm = _native.Communicator(ctx, uid, group.rank, group.world)
+        _COMM_CACHE[key] = comm
+    return comm
 
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
-        box = [_native.Communicator.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        _COMM_CACHE[key] = _native.Communicator(ctx, box[0], rank, world)
-    return _COMM_CACHE[key]
+
+class GatheredSignatures:
+    """The all-gathered signature matrix, resident on this rank's GPU: ``buffer`` holds ``[rows, k]`` uint32
+    (row-major, rank order).  Feed ``buffer.ptr`` to the ``*_dev`` entry points that take ``sig_dtype =
+    MHX_U32`` (b-bit packing, band digests, LSH sort), or :meth:`to_host` for a numpy matrix."""
+
+    def __init__(self, ctx, buffer, rows: int, k: int):
+        self.ctx, self.buffer, self.rows, self.k = ctx, buffer, int(rows), int(k)
+
+    def to_host(self, dtype=np.uint64) -> np.ndarray:
+        self.ctx.synchronize()
+        m = self.buffer.download((self.rows, self.k), np.uint32)
+        return m if np.dtype(dtype) == np.uint32 else m.astype(dtype)
 
 
-def allgather_signatures_dev(ctx, d_local, rows: int, k: int, counts: Sequence[int], group=None) -> np.ndarray:
+def allgather_signatures_dev(ctx, d_local, rows: int, k: int, counts: Sequence[int], group) -> GatheredSignatures:
     """Device path of :func:`allgather_signatures`: ``d_local`` is a DeviceBuffer holding this rank's
-    ``[rows, k]`` **uint32** shard (the compact output type of ``mhx_minhash_bulk_dev``), padded
-    capacity ``max(counts)`` rows.  RCCL gathers the padded shards; the host trims and widens."""
+    ``[rows, k]`` **uint32** shard (the compact output type of ``mhx_minhash_bulk_dev``) with capacity
+    for ``max(counts)`` rows.  One RCCL all-gather of the padded shards; when the shards are unequal the
+    padding is squeezed out with ``world`` device-to-device copies.  Nothing comes back to the host."""
     world = len(counts)
     width = max(counts)
+    total = int(sum(counts))
+    if rows != counts[group.rank]:
+        raise ValueError("rows differs from this rank's entry of counts")
     comm = communicator(ctx, group)
-    d_all = ctx.alloc(max(1, world * width * k * 4))
-    comm.allgather_dev(d_local.ptr, d_all.ptr, width * k * 4)
-    ctx.synchronize()
-    recv = d_all.download((world, width, k), np.uint32)
-    return np.concatenate([recv[r, : counts[r]] for r in range(world)], axis=0).astype(np.uint64)
+    row_bytes = k * 4
+    d_all = ctx.alloc(max(1, world * width * row_bytes))
+    comm.allgather_dev(d_local.ptr, d_all.ptr, width * row_bytes)
+    if all(c == width for c in counts):
+        return GatheredSignatures(ctx, d_all, total, k)
+    d_packed = ctx.alloc(max(1, total * row_bytes))
+    pos = 0
+    for r in range(world):
+        ctx.copy_dev(d_packed.ptr + pos * row_bytes, d_all.ptr + r * width * row_bytes, counts[r] * row_bytes)
+        pos += counts[r]
+    ctx.synchronize()  # d_all is released on return: the copies must have read it
+    return GatheredSignatures(ctx, d_packed, total, k)
 
 
-def bulk_signatures_sharded(tokens, *, num_perm: int, seed: int = 1, gpu_mode: str = "always", group=None) -> np.ndarray:
-    """Config-3 shape: every rank hashes its row block of ``tokens`` (a dense ``[N, T]`` array of
-    pre-hashed tokens, identical on every rank) and the shards are all-gathered; every rank
-    returns the full ``[N, K]`` matrix.  With a GPU the shard stays on the device from the kernel
-    to the RCCL all-gather (uint32 on the wire); ``gpu_mode='disable'`` is the numpy + gloo path."""
-    import torch.distributed as dist
+def bulk_signatures_sharded(local_tokens, *, num_perm: int, seed: int = 1, gpu_mode: str = "always", group=None,
+                            counts: Optional[Sequence[int]] = None, keep_on_device: bool = False):
+    """Config-3 shape: every rank hashes ITS OWN rows -- ``local_tokens`` is this rank's dense ``[n_r, T]``
+    array of pre-hashed tokens (uint32 or uint64), or a callable returning it (so that a rank only ever
+    materialises its own shard) -- and the shards are all-gathered; every rank gets the full ``[N, K]``
+    matrix in rank order.  ``counts`` = rows per rank (gathered over the group when not given).
 
+    With a GPU the shard stays on the device from the kernel to the RCCL all-gather (uint32 on the wire).
+    ``keep_on_device=True`` returns a :class:`GatheredSignatures` (for the pack / digest / sort chain) instead
+    of a host uint64 matrix.  ``gpu_mode='disable'`` is the numpy path with the host stand-in collective."""
     from datasketch_amd import _native
     from datasketch_amd.hashfunc import prehashed
     from datasketch_amd.minhash import MinHash
 
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    begin, end = shard_rows(tokens.shape[0], world, rank)
-    counts = [e - b for b, e in (shard_rows(tokens.shape[0], world, r) for r in range(world))]
+    g = _group(group)
+    shard = local_tokens() if callable(local_tokens) else local_tokens
+    shard = np.asarray(shard)
+    if shard.ndim != 2:
+        raise ValueError("local_tokens must be a dense [rows, tokens] array")
+    if counts is None:
+        counts = gather_counts(shard.shape[0], g)
+    counts = [int(c) for c in counts]
+    if counts[g.rank] != shard.shape[0]:
+        raise ValueError("counts[rank] differs from the number of local rows")
     use_gpu = gpu_mode == "always" or (gpu_mode == "detect" and _native.gpu_available())
-    if not use_gpu or world == 1:
-        local = MinHash.bulk_signatures(tokens[begin:end], num_perm=num_perm, seed=seed, hashfunc=prehashed, gpu_mode=gpu_mode)
-        return allgather_signatures(local, group=group, counts=counts)
+    if not use_gpu:
+        if keep_on_device:
+            raise ValueError("keep_on_device needs the GPU path")
+        local = MinHash.bulk_signatures(shard, num_perm=num_perm, seed=seed, hashfunc=prehashed, gpu_mode=gpu_mode)
+        return allgather_signatures(local, group=g, counts=counts)
     ctx = _native.context()
     proto = MinHash(num_perm=num_perm, seed=seed, hashfunc=prehashed, gpu_mode=gpu_mode)
-    shard = np.ascontiguousarray(tokens[begin:end], dtype=np.uint64)
-    t = shard.shape[1]
+    if shard.dtype != np.uint32:
+        shard = np.ascontiguousarray(shard, dtype=np.uint64)
+    shard = np.ascontiguousarray(shard)
+    tok_code = _native.MHX_U32 if shard.dtype == np.uint32 else _native.MHX_U64
+    n_local, t = shard.shape
     d_tok = ctx.to_device(shard)
     d_out = ctx.alloc(max(1, max(counts) * num_perm * 4))
-    ctx.minhash_bulk_dev(proto.permutations, d_tok.ptr, _native.MHX_U64, None, t, shard.shape[0], shard.size, None, 0,
-                         d_out.ptr, _native.MHX_U32)
-    return allgather_signatures_dev(ctx, d_out, shard.shape[0], num_perm, counts, group=group)
+    ctx.minhash_bulk_dev(proto.permutations, d_tok.ptr, tok_code, None, t, n_local, shard.size, None, 0, d_out.ptr, _native.MHX_U32)
+    if g.world == 1:
+        gathered = GatheredSignatures(ctx, d_out, n_local, num_perm)
+    else:
+        gathered = allgather_signatures_dev(ctx, d_out, n_local, num_perm, counts, g)
+    return gathered if keep_on_device else gathered.to_host(np.uint64)

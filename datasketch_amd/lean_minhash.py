@@ -121,9 +121,12 @@ def serialize_matrix(signatures: np.ndarray, seed: int, gpu_mode: str = "always"
 
     Returns a uint8 array ``[N, 12 + 4*K]``; row ``i`` equals what ``LeanMinHash(seed=seed,
     hashvalues=signatures[i]).serialize(buf, '<')`` writes.  Runs on the device unless
-    ``gpu_mode='disable'``.
+    ``gpu_mode='disable'``.  A hash value above 2**32-1 does not fit the format's ``I`` field:
+    ``struct.error``, as ``LeanMinHash.serialize`` raises for it (lean_minhash.py:174-175).
     """
     signatures = np.ascontiguousarray(signatures, dtype=np.uint64)
+    if signatures.size and int(signatures.max()) > 0xFFFFFFFF:
+        raise struct.error("'I' format requires 0 <= number <= 4294967295")
     if gpu_mode != "disable" and (gpu_mode == "always" or _native.gpu_available()):
         return _native.context().lean_serialize(signatures, seed)
     n, k = signatures.shape

@@ -272,17 +272,21 @@ class MinHash:
         hv = np.concatenate(parts) if parts else np.empty(0, dtype=np.uint64)
         return hv.astype(np.uint64, copy=False), offsets
 
-    def _bulk_chunks(self, b: Iterable) -> Generator[np.ndarray, None, None]:
+    def _bulk_chunks(self, b: Iterable, out_dtype=np.uint64) -> Generator[np.ndarray, None, None]:
         """Yield ``[n_i, K]`` signature blocks for consecutive chunks of the corpus ``b``."""
         init = None if self.is_empty() else self.hashvalues
         if self.hashfunc is prehashed and isinstance(b, np.ndarray) and b.ndim == 2:
-            # dense corpus of fixed-length sets: no per-set Python work at all
-            tok = _as_hash_array(b) if b.dtype != np.uint64 else np.ascontiguousarray(b)
+            # dense corpus of fixed-length sets: no per-set Python work at all; a uint32 array (the range of
+            # sha1_hash32) travels to the device as it is -- half the bytes over PCIe
+            if b.dtype == np.uint32 and self._use_gpu():
+                tok = np.ascontiguousarray(b)
+            else:
+                tok = _as_hash_array(b) if b.dtype != np.uint64 else np.ascontiguousarray(b)
             n, t = tok.shape
             step = max(1, min(n, _BULK_CHUNK_TOKENS // max(t, 1)))
             for s in range(0, n, step):
                 blk = tok[s : s + step]
-                yield self._signatures_csr(blk.reshape(-1), None, t, blk.shape[0], init)
+                yield self._signatures_csr(blk.reshape(-1), None, t, blk.shape[0], init, out_dtype)
             return
         if self.hashfunc is prehashed and isinstance(b, tuple) and len(b) == 2:
             values, offsets = b
@@ -293,10 +297,13 @@ class MinHash:
             while s < n:
                 e = min(n, s + _BULK_CHUNK_SETS)
                 local = offsets[s : e + 1] - offsets[s]
-                yield self._signatures_csr(values[offsets[s] : offsets[e]], local, 0, e - s, init)
+                yield self._signatures_csr(values[offsets[s] : offsets[e]], local, 0, e - s, init, out_dtype)
                 s = e
             return
-        device_sha1 = self.hashfunc is sha1_hash32 and self._use_gpu()
+        # the reference's two default token hashes run on the device (32: hashfunc.py:5-15, 64: :17-28)
+        device_sha1 = 32 if self.hashfunc is sha1_hash32 else 64 if self.hashfunc is sha1_hash64 else 0
+        if device_sha1 and not self._use_gpu():
+            device_sha1 = 0
         chunk: List = []
         tokens = 0
         for s in b:
@@ -304,12 +311,12 @@ class MinHash:
             chunk.append(s)
             tokens += len(s)
             if len(chunk) >= _BULK_CHUNK_SETS or tokens >= _BULK_CHUNK_TOKENS:
-                yield self._signatures_of_sets(chunk, init, device_sha1)
+                yield self._signatures_of_sets(chunk, init, device_sha1).astype(out_dtype, copy=False)
                 chunk, tokens = [], 0
         if chunk:
-            yield self._signatures_of_sets(chunk, init, device_sha1)
+            yield self._signatures_of_sets(chunk, init, device_sha1).astype(out_dtype, copy=False)
 
-    def _signatures_of_sets(self, sets: List, init, device_sha1: bool) -> np.ndarray:
+    def _signatures_of_sets(self, sets: List, init, device_sha1: int) -> np.ndarray:
         if not device_sha1:
             hv, offsets = self._hash_sets(sets)
             return self._signatures_csr(hv, offsets, 0, len(sets), init)
@@ -317,11 +324,11 @@ class MinHash:
         # (repeated tokens are left in: dropping them here costs more host time per set -- a dict per set --
         # than the kernel's slow path for such sets costs on the device)
         buf, byte_offsets, set_offsets = _native.Context.pack_sets(sets)
-        return _native.context().minhash_bulk_bytes(self.permutations, buf, byte_offsets, set_offsets, init)
+        return _native.context().minhash_bulk_bytes(self.permutations, buf, byte_offsets, set_offsets, init, bits=device_sha1)
 
-    def _signatures_csr(self, hv, offsets, fixed_len, n_sets, init) -> np.ndarray:
+    def _signatures_csr(self, hv, offsets, fixed_len, n_sets, init, out_dtype=np.uint64) -> np.ndarray:
         if self._use_gpu():
-            return _native.context().minhash_bulk(self.permutations, hv, offsets, fixed_len, n_sets, init)
+            return _native.context().minhash_bulk(self.permutations, hv, offsets, fixed_len, n_sets, init, out_dtype=out_dtype)
         # gpu_mode='disable': the reference's per-set numpy arithmetic (minhash.py:293-297)
         a, c = self.permutations
         k = len(a)
@@ -335,7 +342,7 @@ class MinHash:
             col = hv[beg:end].reshape(-1, 1)
             phv = np.bitwise_and((col * a + c) % _mersenne_prime, _max_hash)
             out[i] = np.minimum(proto, phv.min(axis=0))
-        return out
+        return out.astype(out_dtype, copy=False)
 
     @classmethod
     def bulk(cls, b: Iterable, **minhash_kwargs) -> List["MinHash"]:
@@ -355,15 +362,20 @@ class MinHash:
                 yield m._spawn(row.copy())
 
     @classmethod
-    def bulk_signatures(cls, b, **minhash_kwargs) -> np.ndarray:
-        """Not in the reference: the ``[N, K]`` uint64 signature matrix of a corpus, without
-        creating N Python objects.  ``b`` is any iterable of token iterables, or -- with
-        ``hashfunc=prehashed`` -- a 2-D integer array (fixed-length sets) or a ``(values, offsets)``
-        CSR pair of already hashed tokens."""
+    def bulk_signatures(cls, b, out_dtype=np.uint64, **minhash_kwargs) -> np.ndarray:
+        """Not in the reference: the ``[N, K]`` signature matrix of a corpus, without creating N
+        Python objects.  ``b`` is any iterable of token iterables, or -- with ``hashfunc=prehashed``
+        -- a 2-D integer array (fixed-length sets; a uint32 array is uploaded as it is) or a
+        ``(values, offsets)`` CSR pair of already hashed tokens.  ``out_dtype``: uint64 (the
+        reference's ``hashvalues`` type) or uint32 (values are < 2**32: half the bytes back)."""
+        if np.dtype(out_dtype) not in (np.dtype(np.uint64), np.dtype(np.uint32)):
+            raise ValueError("out_dtype must be uint64 or uint32")
         m = cls(**minhash_kwargs)
-        blocks = list(m._bulk_chunks(b))
+        if np.dtype(out_dtype) == np.uint32 and not m.is_empty() and int(m.hashvalues.max()) > 0xFFFFFFFF:
+            raise ValueError("initial hashvalues >= 2**32 do not fit uint32 signatures")
+        blocks = list(m._bulk_chunks(b, np.dtype(out_dtype)))
         if not blocks:
-            return np.empty((0, len(m)), dtype=np.uint64)
+            return np.empty((0, len(m)), dtype=out_dtype)
         return blocks[0] if len(blocks) == 1 else np.concatenate(blocks, axis=0)
 
     # ------------------------------------------------------------------ pickling

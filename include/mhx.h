@@ -13,8 +13,10 @@
  *     memory, and never retain the pointers.  "_dev" entry points take device pointers
  *     (from mhx_dev_alloc or any other HIP allocation on the same device), enqueue on the
  *     context's stream and return without synchronising.
- *   - a context owns one device + one HIP stream and is not thread-safe; distinct contexts
- *     are independent (one context per GPU / per process is the multi-GPU model).
+ *   - a context owns one device + one HIP stream; calls on one context (and on the perm / wgen /
+ *     comm handles created from it) are serialised by a mutex inside the context, so concurrent
+ *     callers are safe but do not overlap; distinct contexts are independent (one context per
+ *     GPU / per process is the multi-GPU model).
  *   - citations "ref:" are paths in the reference repository (ekzhu/datasketch v1.10.0).
  */
 #ifndef MHX_H_
@@ -84,6 +86,8 @@ MHX_API int mhx_dev_alloc(mhx_ctx *ctx, size_t bytes, void **dptr);
 MHX_API int mhx_dev_free(mhx_ctx *ctx, void *dptr);
 MHX_API int mhx_memcpy_h2d(mhx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 MHX_API int mhx_memcpy_d2h(mhx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* device-to-device copy, enqueued on the context's stream (no synchronisation) */
+MHX_API int mhx_memcpy_d2d(mhx_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);
 MHX_API int mhx_memset_dev(mhx_ctx *ctx, void *dst_dev, int byte_value, size_t bytes);
 
 MHX_API int mhx_event_create(mhx_ctx *ctx, mhx_event **ev);
@@ -135,6 +139,13 @@ MHX_API int mhx_minhash_bulk(mhx_perm *perm, const uint64_t *hv, const int64_t *
                              int64_t fixed_len, int64_t n_sets, const uint64_t *init,
                              int64_t init_stride, uint64_t *out);
 
+/* The same with the element types of mhx_minhash_bulk_dev: hv of hv_dtype (MHX_U32: tokens in the range of
+ * sha1_hash32, ref: datasketch/hashfunc.py:5-15 -- half the bytes over PCIe), out of out_dtype (MHX_U32: values
+ * are < 2^32 by construction, ref: minhash.py:31,297).  mhx_minhash_bulk is the (MHX_U64, MHX_U64) case. */
+MHX_API int mhx_minhash_bulk_typed(mhx_perm *perm, const void *hv, int hv_dtype, const int64_t *offsets,
+                                   int64_t fixed_len, int64_t n_sets, const uint64_t *init,
+                                   int64_t init_stride, void *out, int out_dtype);
+
 /*
  * The reference's default token hash on the device: out[i] = sha1_hash32(token i) (MHX_U32,
  * ref: datasketch/hashfunc.py:5-15: first 4 bytes of the SHA-1 digest, little-endian) or
@@ -156,6 +167,12 @@ MHX_API int mhx_sha1_tokens(mhx_ctx *ctx, const uint8_t *bytes, const int64_t *b
 MHX_API int mhx_minhash_bulk_bytes(mhx_perm *perm, const uint8_t *bytes, const int64_t *byte_offsets,
                                    int64_t n_tokens, const int64_t *set_offsets, int64_t n_sets,
                                    const uint64_t *init, int64_t init_stride, uint64_t *out);
+
+/* hash_dtype = MHX_U32: sha1_hash32 (mhx_minhash_bulk_bytes), MHX_U64: sha1_hash64 (ref: hashfunc.py:17-28). */
+MHX_API int mhx_minhash_bulk_bytes_typed(mhx_perm *perm, const uint8_t *bytes, const int64_t *byte_offsets,
+                                         int64_t n_tokens, int hash_dtype, const int64_t *set_offsets,
+                                         int64_t n_sets, const uint64_t *init, int64_t init_stride,
+                                         uint64_t *out);
 
 /*
  * One update_batch on one MinHash state (the reference's GPU seam itself,
@@ -207,6 +224,11 @@ MHX_API int mhx_weighted_minhash_many_dense(mhx_wgen *gen, const float *x, int v
 MHX_API int mhx_weighted_minhash_many_dense_dev(mhx_wgen *gen, const float *d_x, int values_are_logs,
                                                 int64_t n_rows, int64_t *d_out, uint8_t *d_nonempty);
 
+/* out[i] = the float32 logarithm the device-log mode (values_are_logs == 0) takes of x[i]: the one place where the
+ * fast mode can differ from numpy's float32 log (ref: weighted_minhash.py:212), exposed so that callers can check
+ * the difference against their tolerance (BASELINE: 1e-6 relative). */
+MHX_API int mhx_weighted_logf(mhx_ctx *ctx, const float *x, int64_t n, float *out);
+
 /* ---- Packing for downstream consumers ----------------------------------------------------- */
 /* Number of uint64 blocks bBitMinHash uses for num_perm values of b bits
  * (ref: datasketch/b_bit_minhash.py:147-172). */
@@ -254,6 +276,17 @@ MHX_API int mhx_lsh_candidate_pairs_dev(mhx_ctx *ctx, const uint64_t *d_sorted_d
 MHX_API int mhx_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs, int32_t num_perm,
                                     int32_t bands, int32_t r, int64_t *pairs, int64_t capacity,
                                     int64_t *n_pairs, int64_t *n_raw);
+/* Bulk query: the keys MinHashLSH.query (ref: datasketch/lsh.py:370-431) would return for each of m probe
+ * signatures against an index of n signatures held as sorted bands (mhx_lsh_sort_bands*): for every band the
+ * probe's digest is located by binary search and the matching run is its bucket.  pairs: int64[capacity, 2] =
+ * (probe, index row), ascending, unique; *n_pairs as in mhx_lsh_candidate_pairs_dev (larger than capacity: nothing
+ * written, call again).  d_index_sig (may be NULL): the index's own [n, num_perm] matrix of the same sig_dtype;
+ * when given, a candidate is kept only if the r words of the band really are equal, so a 64-bit digest
+ * collision between different band keys cannot produce a row the reference's dictionaries would not.  Blocking. */
+MHX_API int mhx_lsh_query_dev(mhx_ctx *ctx, const uint64_t *d_sorted_digests, const uint32_t *d_sorted_rows,
+                              int64_t n_sigs, int32_t bands, int32_t r, const void *d_query_sig,
+                              const void *d_index_sig, int sig_dtype, int32_t num_perm, int64_t n_queries,
+                              int64_t *d_pairs, int64_t capacity, int64_t *n_pairs);
 /* Batched MinHash.jaccard numerators (ref: datasketch/minhash.py:299-324): counts[p] = number of equal
  * positions of rows pairs[p][0] of sig_a and pairs[p][1] of sig_b (both [*, num_perm] uint64; may be the
  * same matrix); the estimate is counts / num_perm.  pairs int64[n_pairs, 2]. */
@@ -262,6 +295,19 @@ MHX_API int mhx_jaccard_pairs_dev(mhx_ctx *ctx, const uint64_t *d_sig_a, const u
                                   int32_t *d_counts);
 MHX_API int mhx_jaccard_pairs(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs, int32_t num_perm,
                               const int64_t *pairs, int64_t n_pairs, int32_t *counts);
+/* The device entry points above for signature matrices of sig_dtype MHX_U64 or MHX_U32 -- uint32 is the compact
+ * output of mhx_minhash_bulk_dev and the wire format of the all-gather (values are < 2^32, ref: minhash.py:31,297);
+ * results are those of the widened matrix. */
+MHX_API int mhx_bbit_pack_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n_sigs,
+                                    int32_t num_perm, int32_t b, uint64_t *d_out);
+MHX_API int mhx_band_digests_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n_sigs,
+                                       int32_t num_perm, int32_t bands, int32_t r, uint64_t *d_out);
+MHX_API int mhx_lsh_sort_bands_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n_sigs,
+                                         int32_t num_perm, int32_t bands, int32_t r,
+                                         uint64_t *d_sorted_digests, uint32_t *d_sorted_rows);
+MHX_API int mhx_jaccard_pairs_dev_typed(mhx_ctx *ctx, const void *d_sig_a, const void *d_sig_b, int sig_dtype,
+                                        int32_t num_perm, const int64_t *d_pairs, int64_t n_pairs,
+                                        int32_t *d_counts);
 /* LeanMinHash.serialize of every row, little-endian: n records of 12+4*K bytes
  * (ref: datasketch/lean_minhash.py:126-175). */
 MHX_API int mhx_lean_serialize_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n_sigs,
@@ -272,15 +318,14 @@ MHX_API int mhx_lean_serialize(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs
 /* ---- Multi-GPU: assemble the signature matrix (RCCL over xGMI) ----------------------------- */
 /* 128-byte RCCL unique id, created on rank 0 and distributed by the caller (env, file, socket). */
 #define MHX_COMM_ID_BYTES 128
-/* Load RCCL now.  It must enter the process before any other ROCm runtime does (a PyTorch-ROCm wheel ships
- * its own and RCCL loaded after it finds no device); loading takes about a second, so mhx_ctx_create does
- * it up front only when WORLD_SIZE > 1 or MHX_PRELOAD_RCCL=1 is set; otherwise the first mhx_comm_* call
- * (or this one) does. */
-MHX_API int mhx_comm_preload(void);
+/* RCCL (librccl.so) is bound with dlopen at the first mhx_comm_* call, so libmhx loads on hosts without it. */
 MHX_API int mhx_comm_unique_id(uint8_t id[MHX_COMM_ID_BYTES]);
 MHX_API int mhx_comm_create(mhx_ctx *ctx, const uint8_t id[MHX_COMM_ID_BYTES], int rank,
                             int world_size, mhx_comm **comm);
 MHX_API int mhx_comm_destroy(mhx_comm *comm);
+/* What RCCL itself reports for the communicator: ncclCommUserRank, ncclCommCount ("ranks seen"),
+ * ncclCommCuDevice and ncclGetVersion.  Any out pointer may be NULL. */
+MHX_API int mhx_comm_info(mhx_comm *comm, int *rank, int *world_size, int *device, int *rccl_version);
 /* All-gather equal-sized row shards: every rank contributes bytes_per_rank bytes from d_send,
  * d_recv receives world_size*bytes_per_rank bytes in rank order.  Enqueued on the ctx stream. */
 MHX_API int mhx_comm_allgather_dev(mhx_comm *comm, const void *d_send, void *d_recv,

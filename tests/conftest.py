@@ -6,10 +6,6 @@ import sys
 import numpy as np
 import pytest
 
-# the suite exercises the RCCL path in the same process as torch.distributed (gloo): RCCL is loaded with the
-# context, before torch's ROCm libraries can get in (see mhx_comm_preload in include/mhx.h)
-os.environ.setdefault("MHX_PRELOAD_RCCL", "1")
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

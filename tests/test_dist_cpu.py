@@ -1,6 +1,9 @@
-"""N>1 path on CPU: world_size-2 gloo processes shard the corpus, hash their rows, all-gather."""
+"""N>1 path on CPU: two processes shard the corpus, hash their own rows, all-gather -- once over the
+package's own TCP rendezvous (what bench.py and dist.py use), once with a torch.distributed gloo group
+wrapped as the same three-member protocol (rank, world, allgather)."""
 import os
 import socket
+import subprocess
 import sys
 
 import numpy as np
@@ -34,44 +37,134 @@ def test_shard_by_tokens_balances_ragged():
     assert max(tok) - min(tok) < 2 * 500
 
 
-def _worker(rank, world, port, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    sys.path.insert(0, ROOT)
-    import torch.distributed as dist
-
-    from datasketch_amd.dist import allgather_signatures, bulk_signatures_sharded
-
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    try:
-        tokens = np.random.RandomState(5).randint(0, 2**32, (101, 33), dtype=np.uint64)
-        full = bulk_signatures_sharded(tokens, num_perm=24, seed=3, gpu_mode="disable")
-        # unequal shards without precomputed counts
-        mine = full[: 10 + 5 * rank]
-        glued = allgather_signatures(mine)
-        q.put((rank, full, glued.shape[0]))
-    finally:
-        dist.destroy_process_group()
+def _corpus():
+    return np.random.RandomState(5).randint(0, 2**32, (101, 33), dtype=np.uint64)
 
 
-def test_two_rank_gloo_sharded_bulk_equals_single_process():
-    import torch.multiprocessing as mp
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+_RANK_BODY = r"""
+import os, sys, pickle
+import numpy as np
+sys.path.insert(0, {root!r})
+from datasketch_amd import dist, rendezvous
+from datasketch_amd.dist import allgather_signatures, bulk_signatures_sharded, shard_rows
+{make_group}
+tokens = np.random.RandomState(5).randint(0, 2**32, (101, 33), dtype=np.uint64)
+b, e = shard_rows(tokens.shape[0], group.world, group.rank)
+calls = []
+def mine():                      # a rank only ever materialises its own rows
+    calls.append(1)
+    return tokens[b:e]
+full = bulk_signatures_sharded(mine, num_perm=24, seed=3, gpu_mode="disable", group=group)
+glued = allgather_signatures(full[: 10 + 5 * group.rank], group=group)   # unequal shards, counts not given
+group.barrier() if hasattr(group, "barrier") else None
+with open({out!r} + str(group.rank), "wb") as f:
+    pickle.dump((full, glued.shape[0], len(calls)), f)
+{close}
+"""
+
+
+def _run_two_ranks(tmp_path, make_group, close, extra_env):
+    out = str(tmp_path / "rank")
+    body = _RANK_BODY.format(root=ROOT, make_group=make_group, close=close, out=out)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", **extra_env)
+        procs.append(subprocess.Popen([sys.executable, "-c", body], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        text, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, text.decode()
+    import pickle
 
     from datasketch_amd import MinHash, prehashed
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=180) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    tokens = np.random.RandomState(5).randint(0, 2**32, (101, 33), dtype=np.uint64)
-    want = MinHash.bulk_signatures(tokens, num_perm=24, seed=3, hashfunc=prehashed)
-    for _rank, full, glued_rows in results:
+    want = MinHash.bulk_signatures(_corpus(), num_perm=24, seed=3, hashfunc=prehashed, gpu_mode="disable")
+    for rank in range(2):
+        with open(out + str(rank), "rb") as f:
+            full, glued_rows, calls = pickle.load(f)
         assert np.array_equal(full, want)
         assert glued_rows == 10 + 15
+        assert calls == 1
+
+
+def test_two_ranks_over_own_rendezvous_sharded_bulk_equals_single_process(tmp_path):
+    _run_two_ranks(tmp_path, "group = rendezvous.from_env()", "group.close()",
+                   {"MHX_RDZV_ADDR": f"127.0.0.1:{_free_port()}"})
+
+
+def test_two_ranks_found_through_the_launcher_environment(tmp_path):
+    # torch.distributed.run exports MASTER_ADDR / MASTER_PORT (the port belongs to the launcher's own store):
+    # rank 0 publishes a free port in a file named after the launcher's pid
+    env = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port()), "LOCAL_WORLD_SIZE": "2"}
+    assert "MHX_RDZV_ADDR" not in os.environ
+    _run_two_ranks(tmp_path, "group = rendezvous.from_env()", "group.close()", env)
+
+
+_GLOO_GROUP = r"""
+import torch.distributed as tdist
+tdist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+class GlooGroup:                 # the three members dist.py needs, on top of a gloo process group
+    rank, world = tdist.get_rank(), tdist.get_world_size()
+    def allgather(self, payload):
+        box = [None] * self.world
+        tdist.all_gather_object(box, bytes(payload))
+        return box
+group = GlooGroup()
+"""
+
+
+def test_two_rank_gloo_sharded_bulk_equals_single_process(tmp_path):
+    pytest.importorskip("torch")
+    env = {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())}
+    _run_two_ranks(tmp_path, _GLOO_GROUP, "tdist.destroy_process_group()", env)
+
+
+def test_group_collectives_in_threads():
+    import threading
+
+    from datasketch_amd import rendezvous
+
+    port = _free_port()
+    world, res = 3, {}
+
+    def run(rank):
+        with rendezvous.Group(rank, world, "127.0.0.1", port, timeout=30) as g:
+            got = g.allgather(bytes([rank]) * (rank + 1))
+            mx = g.allreduce_max(10.0 * rank)
+            bc = g.broadcast(b"id-from-0" if rank == 0 else None)
+            ints = g.allgather_ints([rank, 100 + rank])
+            g.barrier()
+            res[rank] = (got, mx, bc, ints)
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    for r in range(world):
+        got, mx, bc, ints = res[r]
+        assert got == [b"\x00", b"\x01\x01", b"\x02\x02\x02"]
+        assert mx == 20.0 and bc == b"id-from-0"
+        assert ints == [[0, 100], [1, 101], [2, 102]]
+
+
+def test_bench_self_launch_spawns_ranks_and_propagates_failure_without_a_gpu():
+    """`python bench.py --gpus 2` with no launcher environment spawns two ranks itself; on this device-less box
+    both meet at the rendezvous, find no HIP device and exit non-zero -- and so does the parent."""
+    from datasketch_amd import _native
+
+    try:
+        if _native.device_count() > 0:
+            pytest.skip("a GPU is visible: the launch path is exercised by the gpu tests")
+    except _native.MhxError:
+        pytest.skip("libmhx.so not built")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MHX_RDZV_ADDR")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--sets", "1000"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert p.returncode != 0
+    assert (p.stdout + p.stderr).count("no HIP device visible") == 2

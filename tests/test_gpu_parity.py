@@ -717,27 +717,24 @@ def test_rccl_allgather_single_rank(ctx):
 
 def test_device_allgather_through_dist_single_rank(ctx):
     """datasketch_amd.dist device path at world size 1: kernel -> uint32 shard on the device ->
-    RCCL all-gather (libmhx communicator, id broadcast over a gloo group) -> host matrix."""
-    import socket
-
-    import torch.distributed as dist
-
+    RCCL all-gather (libmhx communicator, id handed out over the package's own rendezvous group) ->
+    device-resident matrix -> host."""
+    from datasketch_amd import rendezvous
     from datasketch_amd.dist import allgather_signatures_dev
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
-    try:
-        n, t, k = 3000, 100, 128
-        tok = np.random.RandomState(3).randint(0, 2**32, (n, t), dtype=np.uint64)
-        a, b = O.np_init_permutations(k, 1)
-        d_tok, d_out = ctx.to_device(tok), ctx.alloc(n * k * 4)
-        ctx.minhash_bulk_dev((a, b), d_tok.ptr, _native.MHX_U64, None, t, n, n * t, None, 0, d_out.ptr, _native.MHX_U32)
-        full = allgather_signatures_dev(ctx, d_out, n, k, [n])
-        assert np.array_equal(full, O.c_minhash_bulk_dense(tok, a, b))
-    finally:
-        dist.destroy_process_group()
+    group = rendezvous.Group(0, 1)
+    n, t, k = 3000, 100, 128
+    tok = np.random.RandomState(3).randint(0, 2**32, (n, t), dtype=np.uint64)
+    a, b = O.np_init_permutations(k, 1)
+    d_tok, d_out = ctx.to_device(tok), ctx.alloc(n * k * 4)
+    ctx.minhash_bulk_dev((a, b), d_tok.ptr, _native.MHX_U64, None, t, n, n * t, None, 0, d_out.ptr, _native.MHX_U32)
+    full = allgather_signatures_dev(ctx, d_out, n, k, [n], group)
+    assert full.rows == n and full.k == k
+    assert np.array_equal(full.to_host(), O.c_minhash_bulk_dense(tok, a, b))
+    from datasketch_amd.dist import communicator
+
+    info = communicator(ctx, group).info()
+    assert info["ranks_seen"] == 1 and info["rank"] == 0 and info["device"] == ctx.device and info["rccl_version"] > 0
 
 
 # ------------------------------------------------------------------ device SHA-1 (row f2)

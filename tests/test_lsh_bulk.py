@@ -145,3 +145,94 @@ def test_insert_bulk_of_weighted_signatures_matches_the_reference_index():
     assert sorted(one.query(probe)) == sorted(bulk.query(probe)) and 7 in bulk.query(probe)
     with pytest.raises(ValueError):
         LB.insert_bulk(bulk, ["x"], sig[:1, :8], gpu_mode="disable")  # wrong sample count
+
+
+def _reference():
+    sys.path.insert(0, REFERENCE)
+    try:
+        import datasketch as ref
+    finally:
+        sys.path.remove(REFERENCE)
+    return ref
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE), reason="reference repository not mounted")
+@pytest.mark.parametrize("prepickle", [True, False])
+def test_insert_bulk_in_batches_and_query_bulk_equal_the_per_key_calls(prepickle):
+    """Two bulk batches (the second onto a non-empty index, with band keys shared inside the batch and with the
+    first batch) leave every dictionary as the per-key loop does; query_bulk == [lsh.query(m) for m in probes]
+    for 1000 probes (ref: datasketch/lsh.py:326-347, 370-431; storage.py:210-259)."""
+    ref = _reference()
+    rng = np.random.RandomState(3)
+    n, k = 1500, 64
+    sig = rng.randint(0, 2**32, (n, k)).astype(np.uint64)
+    sig[700:760] = sig[0:60]            # whole rows again, across the batch boundary
+    sig[900:940, :32] = sig[5, :32]     # a big bucket in the first bands
+    sig[1200, 16:] = sig[1100, 16:]     # a near duplicate inside the second batch
+    keys = [("doc", i) for i in range(n)] if prepickle else [b"doc-%d" % i for i in range(n)]
+    kw = dict(threshold=0.6, num_perm=k, prepickle=prepickle)
+    one, bulk = ref.MinHashLSH(**kw), ref.MinHashLSH(**kw)
+    for key, row in zip(keys, sig):
+        one.insert(key, ref.MinHash(num_perm=k, seed=1, hashvalues=row))
+    LB.insert_bulk(bulk, keys[:800], sig[:800], gpu_mode="disable")
+    LB.insert_bulk(bulk, keys[800:], sig[800:], gpu_mode="disable")
+    assert dict(one.keys._dict) == dict(bulk.keys._dict)
+    for t1, t2 in zip(one.hashtables, bulk.hashtables):
+        assert dict(t1._dict) == dict(t2._dict)
+    probes = sig[rng.randint(0, n, 1000)].copy()
+    probes[::3, rng.randint(0, k, 20)] = 7          # perturbed probes: some bands still match
+    probes[1::50] = rng.randint(0, 2**32, (20, k))  # probes that match nothing
+    got = LB.query_bulk(bulk, probes, gpu_mode="disable")
+    assert len(got) == 1000
+    for row, res in zip(probes, got):
+        want = one.query(ref.MinHash(num_perm=k, seed=1, hashvalues=row))
+        assert sorted(map(repr, res)) == sorted(map(repr, want))
+    assert any(len(r) > 30 for r in got) and any(len(r) == 0 for r in got)
+    with pytest.raises(ValueError):
+        LB.query_bulk(bulk, probes[:, :32], gpu_mode="disable")
+    with pytest.raises(ValueError):
+        LB.insert_bulk(bulk, keys[10:12], sig[10:12], gpu_mode="disable")   # present already
+    with pytest.raises(ValueError):
+        LB.insert_bulk(bulk, [keys[0] + (1,) if prepickle else b"x", keys[0] + (1,) if prepickle else b"x"], sig[:2], gpu_mode="disable")  # twice in one batch
+
+
+class _ListStore:
+    """A storage that is NOT the in-memory dict one (no _dict): insert_bulk / query_bulk must go through
+    its API key by key (what a Redis / Cassandra back end gets, ref: storage.py)."""
+
+    def __init__(self, factory):
+        self.data, self.factory, self.calls = {}, factory, 0
+
+    def insert(self, key, *vals, **kwargs):
+        self.calls += 1
+        box = self.data.setdefault(key, self.factory())
+        (box.extend if isinstance(box, list) else box.update)(vals)
+
+    def get(self, key):
+        return self.data.get(key, self.factory())
+
+    def __contains__(self, key):
+        return key in self.data
+
+
+def test_other_storages_take_the_per_key_path():
+    sig = _signatures(n=120, k=64)
+
+    class Index:
+        h, b, r, prepickle, hashfunc = 64, 8, 8, False, None
+
+        def __init__(self):
+            self.keys = _ListStore(list)
+            self.hashtables = [_ListStore(set) for _ in range(8)]
+
+    idx = Index()
+    keys = [b"k%d" % i for i in range(120)]
+    LB.insert_bulk(idx, keys, sig, gpu_mode="disable")
+    assert idx.keys.calls == 120 and all(t.calls == 120 for t in idx.hashtables)
+    bk = LB.band_keys(sig, 8, 8, gpu_mode="disable")
+    assert idx.keys.data[keys[3]] == [bytes(bk[3, j]) for j in range(8)]
+    assert keys[7] in idx.hashtables[2].data[bytes(bk[7, 2])]
+    got = LB.query_bulk(idx, sig[:10], gpu_mode="disable")
+    assert all(keys[i] in got[i] for i in range(10)) and set(got[0]) >= {keys[0], keys[7], keys[14]}  # rows 0, 7, 14 ... are identical sets
+    with pytest.raises(ValueError):
+        LB.insert_bulk(idx, keys[:1], sig[:1], gpu_mode="disable")
