@@ -55,6 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--allgather", action="store_true", help="RCCL all-gather of the uint32 shards inside every step")
     ap.add_argument("--no-allgather-probe", action="store_true", help="N > 1: skip the separate all-gather measurement")
+    ap.add_argument("--probe-timeout", type=float, default=120.0, help="seconds the all-gather probe may take before it is given up")
     ap.add_argument("--check-rows", type=int, default=4096, help="rows verified against the numpy path")
     ap.add_argument("--cpu-sample", type=int, default=160_000, help="sets timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive host->host measurement")
@@ -109,9 +110,8 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     # one GPU per rank: LOCAL_RANK indexes the visible devices; a launcher that already narrowed the
     # visibility to one device per process (HIP_VISIBLE_DEVICES) leaves device 0
-    shared = local_world > visible and visible != 1
-    if local_world > visible and visible == 1 and "HIP_VISIBLE_DEVICES" not in os.environ and "ROCR_VISIBLE_DEVICES" not in os.environ:
-        shared = True
+    # (MHX_ONE_DEVICE_PER_PROCESS=1 says so)
+    shared = local_world > visible and os.environ.get("MHX_ONE_DEVICE_PER_PROCESS", "0") != "1"
     if shared and not args.share_devices:
         raise SystemExit(f"{local_world} ranks on this node but only {visible} visible GPU(s): one GPU per rank "
                          "(--share-devices lets ranks share a GPU for plumbing tests; the numbers then mean nothing)")
@@ -254,7 +254,28 @@ def main():
 
     # ---- N > 1: the exchange step of config 3 on its own (uint32 shards, RCCL over xGMI)
     if world > 1 and not args.no_allgather_probe:
-        out["allgather"] = allgather_probe(ctx, group, gather, perms, d_tok, tok_dtype, n, t, k)
+        # RCCL blocks inside the library when a peer is missing or a topology is refused on one rank only; the compute
+        # numbers above are complete, so a probe that does not come back in time is reported as such instead of
+        # hanging the job: the watchdog prints the line (rank 0) and leaves
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["allgather"] = {"error": f"RCCL all-gather probe did not finish within {args.probe_timeout:.0f} s"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.probe_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        try:
+            out["allgather"] = allgather_probe(ctx, group, gather, perms, d_tok, tok_dtype, n, t, k)
+        except (ConnectionError, TimeoutError, OSError) as e:  # a peer left (its own watchdog, or a crash inside RCCL)
+            out["allgather"] = {"error": repr(e)}
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog.cancel()
 
     if rank == 0 and world == 1:
         if not args.no_e2e:
@@ -288,6 +309,12 @@ def main():
     group.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if world > 1:
+        # leave without the interpreter's teardown: a process that holds a (possibly half-built) RCCL communicator
+        # can block in the library's exit handlers, and the launcher would wait for it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
 
 
 def measured_traffic(n, t, k, args):
@@ -339,9 +366,9 @@ def allgather_probe(ctx, group, gather, perms, d_tok, tok_dtype, n, t, k, reps=5
         ctx.synchronize()
     except Exception as e:  # noqa: BLE001
         err = repr(e)
-    flags = group.allgather((err or "").encode())
-    if any(flags):
-        res["error"] = [f.decode() for f in flags]
+    flags = group.allgather(b"probe-init:" + (err or "").encode())
+    if any(f != b"probe-init:" for f in flags):
+        res["error"] = [f.decode("utf-8", "replace") for f in flags]
         return res
     group.barrier()
     evs = [ctx.event() for _ in range(reps + 1)]
@@ -652,17 +679,18 @@ def extra_c4(ctx, n=100_000, dim=4096, s=128):
     t0 = time.perf_counter()
     hv_l, ne_l = gl.minhash_many_arrays(x)
     dt_log = time.perf_counter() - t0
-    # kernel only: logs resident on the device
-    lib = ctx.lib
-    _c, handle = g._device_handle()
+    # kernel only: logs resident on the device (the generator lives on the process-wide context: its stream is the
+    # one the events must be recorded on)
+    wctx, handle = g._device_handle()
+    lib = wctx.lib
     with np.errstate(invalid="ignore", divide="ignore"):
         logs = np.log(x)
-    d_x = ctx.to_device(logs)
-    d_o = ctx.alloc(n * s * 16)
-    d_ne = ctx.alloc(n)
-    ms = _timed(ctx, lambda: _native.check(lib.mhx_weighted_minhash_many_dense_dev(handle, d_x.ptr, 1, n, d_o.ptr, d_ne.ptr)), reps=2)
+    d_x = wctx.to_device(logs)
+    d_o = wctx.alloc(n * s * 16)
+    d_ne = wctx.alloc(n)
+    ms = _timed(wctx, lambda: _native.check(lib.mhx_weighted_minhash_many_dense_dev(handle, d_x.ptr, 1, n, d_o.ptr, d_ne.ptr)), reps=2)
     d_x.upload(x)
-    ms_log = _timed(ctx, lambda: _native.check(lib.mhx_weighted_minhash_many_dense_dev(handle, d_x.ptr, 0, n, d_o.ptr, d_ne.ptr)), reps=2)
+    ms_log = _timed(wctx, lambda: _native.check(lib.mhx_weighted_minhash_many_dense_dev(handle, d_x.ptr, 0, n, d_o.ptr, d_ne.ptr)), reps=2)
     for d in (d_x, d_o, d_ne):
         d.free()
     # parity gate: sample rows against the C oracle (bit-exact (k, t) in parity mode)
@@ -727,4 +755,18 @@ def weighted_gap_gate(x, g, hv_par, hv_log, mism, tol=1e-6):
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException as exc:  # noqa: BLE001
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1 and "RANK" in os.environ:  # a rank: report, then leave hard (see main)
+            import traceback
+
+            if not isinstance(exc, SystemExit) or exc.code not in (0, None):
+                if isinstance(exc, SystemExit):
+                    print(exc.code, file=sys.stderr)
+                else:
+                    traceback.print_exc()
+                sys.stderr.flush()
+                os._exit(1)
+            os._exit(0)
+        raise
