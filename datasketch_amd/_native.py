@@ -474,14 +474,22 @@ class Context:
         check(self.lib.mhx_weighted_minhash_many(h, _ptr(indptr), _ptr(indices), _ptr(values), int(bool(values_are_logs)), n, _ptr(out), _ptr(nonempty)))
         return out, nonempty.astype(bool)
 
-    def weighted_minhash_many_dense(self, h: int, sample_size: int, x: np.ndarray, values_are_logs: bool):
-        """Dense [N, dim] float32 rows (values, or logs with -inf for absent entries) -> (out, nonempty)."""
+    def weighted_minhash_many_dense(self, h: int, sample_size: int, x: np.ndarray, values_are_logs: bool, out=None, nonempty=None):
+        """Dense [N, dim] float32 rows (values, or logs with -inf for absent entries) -> (out, nonempty).
+        ``out`` / ``nonempty``: optional C-contiguous int64 [N, S, 2] / uint8 [N] arrays (or leading-axis slices
+        of such) to fill in place."""
         x = np.ascontiguousarray(x, dtype=np.float32)
         n = x.shape[0]
-        out = np.zeros((n, int(sample_size), 2), dtype=np.int64)
-        nonempty = np.zeros(n, dtype=np.uint8)
+        if out is None:
+            out = np.zeros((n, int(sample_size), 2), dtype=np.int64)
+        if nonempty is None:
+            nonempty = np.zeros(n, dtype=np.uint8)
+        if out.shape != (n, int(sample_size), 2) or out.dtype != np.int64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous int64 array of shape (N, sample_size, 2)")
+        if nonempty.shape != (n,) or nonempty.dtype != np.uint8 or not nonempty.flags.c_contiguous:
+            raise ValueError("nonempty must be a C-contiguous uint8 array of shape (N,)")
         check(self.lib.mhx_weighted_minhash_many_dense(h, _ptr(x), int(bool(values_are_logs)), n, _ptr(out), _ptr(nonempty)))
-        return out, nonempty.astype(bool)
+        return out, nonempty.view(bool)
 
     def weighted_logf(self, x: np.ndarray) -> np.ndarray:
         """The float32 log the device-log mode of the weighted path takes (mhx_weighted_logf)."""

@@ -103,6 +103,16 @@ int mhx_ctx::ensure_redo(int64_t n_sets) {
     return MHX_OK;
 }
 
+int mhx_ctx::ensure_work() {
+    if (d_work) return MHX_OK;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_work), 64);
+    if (e != hipSuccess) {
+        d_work = nullptr;
+        return fail(MHX_ERR_OOM, "work counter allocation failed: %s", hipGetErrorString(e));
+    }
+    return MHX_OK;
+}
+
 extern "C" {
 
 const char *mhx_last_error(void) { return mhx::g_last_error.c_str(); }
@@ -156,6 +166,7 @@ int mhx_ctx_destroy(mhx_ctx *ctx) {
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->d_stats) (void)hipFree(ctx->d_stats);
     if (ctx->d_redo) (void)hipFree(ctx->d_redo);
+    if (ctx->d_work) (void)hipFree(ctx->d_work);
     if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
     if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
     (void)hipStreamDestroy(ctx->stream);

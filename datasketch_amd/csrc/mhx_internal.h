@@ -73,6 +73,9 @@ struct mhx_ctx {
     uint8_t *d_redo = nullptr;
     int64_t redo_capacity = 0;
     int ensure_redo(int64_t n_sets);
+    // work counters of the flagged launches + the sieve launch's running failure counts (4 words, zeroed per call)
+    unsigned int *d_work = nullptr;
+    int ensure_work();
 
     int ensure_scratch(int slot, size_t bytes);
     int activate() const;

@@ -44,7 +44,10 @@ struct BulkArgs {
     int32_t path;            // 0 sieve (+ fallbacks), 1 exact fold everywhere, 2 fast fold (+ exact redo)
     unsigned long long *stats;  // optional device counters: [0] sets the sieve launch left to the full one,
                                 // [1] sets redone with the exact fold, [2] sieve blocks, [3] sets hashed pair by pair
-    uint8_t *redo;              // wave-per-set kernels: redo[set] != 0 <=> the sieve launch left the set to the full one
+    uint8_t *redo;              // wave-per-set kernels: redo[set] == 1 <=> the sieve launch left the set to the dedup launch,
+                                // == 2 <=> the dedup launch left it to the pairwise (full) launch
+    int32_t redo_match;         // the flag value this launch works on (MODE_DEDUP: 1, MODE_FULL after it: 2)
+    unsigned int *sieve_hint;   // sieve launch: [0] sets tried, [1] proofs failed so far in this launch (zeroed before it)
     int32_t prefetch;        // warm the next set's tokens with a vector load (option minhash.prefetch)
     int64_t alias_mask;      // profiling only (option minhash.alias): sets read tokens of set (i & mask); -1 = off
     const uint64_t *init;
@@ -354,18 +357,23 @@ __device__ __forceinline__ void sieve_chunk(const Chunk<TokT> &c, const SievePer
 
 // End of a block: rescan the best row of every permutation in the LDS tile (row stride STRIDE dwords,
 // WPT dwords per token), prove uniqueness, hash the one candidate exactly.  Returns the lanes whose
-// proof failed.
-template <int P, int STRIDE, int WPT>
+// proof failed.  PARTIAL: row `last_row` holds only `last_cols` tokens (the dedup launch's compacted tile);
+// the cells behind them are stale and their keys are replaced by 2^32-1.
+template <int P, int STRIDE, int WPT, bool PARTIAL = false>
 __device__ __forceinline__ bool finish_block(const Two (&rows)[P], const uint32_t *tile, const Perms<P> &pm,
-                                             const SievePerms<P> &sp, uint32_t (&res)[P]) {
+                                             const SievePerms<P> &sp, uint32_t (&res)[P], uint32_t last_row = 16,
+                                             uint32_t last_cols = 16) {
     Two cols[P];
     uint64_t best[P];
 #pragma unroll
     for (int q = 0; q < P; ++q) {
-        const uint32_t *rowp = tile + (rows[q].k1 & 15u) * STRIDE;  // per-lane LDS address
+        const uint32_t myrow = rows[q].k1 & 15u;
+        const uint32_t *rowp = tile + myrow * STRIDE;  // per-lane LDS address
+        const uint32_t limit = PARTIAL ? (myrow == last_row ? last_cols : 16u) : 16u;
 #pragma unroll
         for (int c = 0; c < kRowTokens; ++c) {
-            const uint32_t m = (uint32_t)((uint64_t)rowp[c * WPT] * sp.a_lo[q] + sp.b8[q]);
+            uint32_t m = (uint32_t)((uint64_t)rowp[c * WPT] * sp.a_lo[q] + sp.b8[q]);
+            if (PARTIAL) m = (uint32_t)c < limit ? m : kMaxHash;
             cols[q].add(tag16(m, (uint32_t)c));
         }
         const uint32_t j1 = cols[q].k1 & 15u;
@@ -467,17 +475,20 @@ __device__ __forceinline__ bool sieve_range(const TokT MHX_CONST_AS *hv, const T
     return fail;
 }
 
-// ---- the full launch's first attempt at a flagged set: drop repeated tokens, then sieve ---------
-// A set usually fails the sieve because a token occurs twice (two cells tie at the minimum).  Here
-// each block of up to 256 tokens is copied into the wave's LDS tile, repeated tokens are found with two
-// 1024-slot hash tables in LDS (ds_min of the token index; a token whose slot holds a smaller index
-// with the same value is a repeat), the survivors are compacted in place (ballot + mbcnt prefix), and
-// the sieve runs over the compacted tile -- tokens now come from LDS as broadcast reads instead of
-// scalar loads.  The < 16 tokens left over after the full rows are hashed exactly.  Repeats that the
-// tables miss (both slots taken by an earlier, different token: ~1 %) or keys that are genuinely
-// within 32 still fail the proof; the caller then hashes the set pair by pair.
+// ---- the dedup launch: a flagged set with its repeated tokens dropped, then the sieve -----------------
+// A set usually fails the sieve because a token occurs twice (two cells tie at the minimum).  Here each
+// block of up to 256 tokens is copied into the wave's LDS tile and repeated tokens are found with a
+// 1024-slot hash table in LDS (ds_min of the token index; a token whose slot holds a smaller index with the
+// same value is a repeat).  A repeat is missed when an earlier DIFFERENT token sits in its slot (~10 % per
+// pass), so the table is cleared and used again with another hash multiplier, three passes in all, which
+// leaves ~0.1 % of the repeats (one table of 4 KB instead of two of 4 KB each: 6 instead of 3 waves per SIMD
+// fit the LDS).  The survivors are compacted in place (ballot + mbcnt prefix) and the sieve runs over the
+// compacted tile -- tokens now come from LDS as broadcast reads instead of scalar loads; the last, partial
+// row takes part with the cells behind its tokens masked out.  What still fails the proof (a missed repeat,
+// keys that are genuinely within 32) is left to the pairwise launch.
 constexpr int kDedupSlots = 1024;
-constexpr int kDedupWordsPerWave = kStageWordsPerWave + 2 * kDedupSlots;
+constexpr int kDedupPasses = 3;
+constexpr int kDedupWordsPerWave = kStageWordsPerWave + kDedupSlots;
 
 // lane l's four tokens of the block that starts at blk (zero where the block has ended)
 template <typename TokT>
@@ -493,56 +504,60 @@ __device__ __forceinline__ bool dedup_sieve_range(const TokT *hv_vec, int64_t be
                                                   const uint64_t (&first)[4], uint32_t (&res)[P]) {
     constexpr int STRIDE = 36;  // the tile always holds 64-bit tokens here
     uint32_t *tile = lds;
-    uint32_t *table = lds + kStageWordsPerWave;  // [2][kDedupSlots] token indices
+    uint32_t *table = lds + kStageWordsPerWave;  // [kDedupSlots] token indices
     bool fail = false;
     for (int64_t blk = beg; blk < end; blk += kBlockRows * kRowTokens) {
         const int nb = (int)min((int64_t)(kBlockRows * kRowTokens), end - blk);
         // lane l owns tokens 4l .. 4l+3 of the block
         uint64_t t[4];
-        bool valid[4];
+        bool keep[4];
         if (blk == beg) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) t[i] = first[i];
         } else {
             load_quad<TokT>(hv_vec, blk, end, lane, t);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) valid[i] = 4 * lane + i < nb;
-#pragma unroll
-        for (int i = 0; i < 2 * kDedupSlots / kWave; i += 4)
-            *reinterpret_cast<uint4 *>(table + (2 * kDedupSlots / kWave) * lane + i) = uint4{~0u, ~0u, ~0u, ~0u};
-        uint32_t h1[4], h2[4];
+        uint32_t mix[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t idx = 4 * lane + i;
-            const uint32_t m = (uint32_t)t[i] ^ (uint32_t)(t[i] >> 32);
-            h1[i] = (m * 0x9E3779B1u) >> 22;
-            h2[i] = kDedupSlots + ((m * 0x85EBCA77u) >> 22);
+            keep[i] = (int)idx < nb;
+            mix[i] = (uint32_t)t[i] ^ ((uint32_t)(t[i] >> 32) * 0x9E3779B1u);
             uint32_t *cell = tile + (idx >> 4) * STRIDE + (idx & 15u) * 2;  // raw tile: token idx at (row idx/16, column idx%16)
             cell[0] = (uint32_t)t[i];
             cell[1] = (uint32_t)(t[i] >> 32);
-            if (valid[i]) {
-                atomicMin(table + h1[i], idx);
-                atomicMin(table + h2[i], idx);
+        }
+        for (int pass = 0; pass < kDedupPasses; ++pass) {
+            const uint32_t mult = pass == 0 ? 0x9E3779B1u : pass == 1 ? 0x85EBCA77u : 0xC2B2AE3Du;
+#pragma unroll
+            for (int i = 0; i < kDedupSlots / kWave; i += 4)
+                *reinterpret_cast<uint4 *>(table + (kDedupSlots / kWave) * lane + i) = uint4{~0u, ~0u, ~0u, ~0u};
+            // Straight-line code, three LDS round trips per pass for all four tokens of the lane together (with a
+            // branch per token the dependent reads queued up one behind the other: ~10 round trips per pass).  A
+            // token that is already out takes part with the index 2^32-1, which never wins a slot.
+            uint32_t slot[4], owner[4], c0[4], c1[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                slot[i] = (mix[i] * mult) >> 22;
+                atomicMin(table + slot[i], keep[i] ? (uint32_t)(4 * lane + i) : ~0u);
+            }
+            // LDS operations of one wave complete in order: every lane's ds_min is done before the reads below
+#pragma unroll
+            for (int i = 0; i < 4; ++i) owner[i] = table[slot[i]];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint32_t o = owner[i] & 255u;  // a slot nobody took holds 2^32-1: any cell will do, the test below fails
+                const uint32_t *cell = tile + (o >> 4) * STRIDE + (o & 15u) * 2;
+                c0[i] = cell[0];
+                c1[i] = cell[1];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool repeat = owner[i] < (uint32_t)(4 * lane + i) && c0[i] == (uint32_t)t[i] && c1[i] == (uint32_t)(t[i] >> 32);
+                keep[i] = keep[i] && !repeat;
             }
         }
-        bool keep[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint32_t idx = 4 * lane + i;
-            bool repeat = false;
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb) {
-                const uint32_t first = table[tb == 0 ? h1[i] : h2[i]];
-                if (valid[i] && first < idx) {
-                    const uint32_t *cell = tile + (first >> 4) * STRIDE + (first & 15u) * 2;
-                    repeat |= cell[0] == (uint32_t)t[i] && cell[1] == (uint32_t)(t[i] >> 32);
-                }
-            }
-            keep[i] = valid[i] && !repeat;
-        }
-        // compact in place (every read of the raw tile is done: the tile is private to the wave and LDS
-        // operations of one wave complete in order)
+        // compact in place (every read of the raw tile is done: the tile is private to the wave)
         uint32_t below = 0;  // kept tokens of lower lanes
         int kept = 0;        // kept tokens of the block (wave-uniform)
 #pragma unroll
@@ -561,37 +576,44 @@ __device__ __forceinline__ bool dedup_sieve_range(const TokT *hv_vec, int64_t be
                 ++pos;
             }
         }
-        // sieve over the full rows of the compacted tile: wave-uniform LDS addresses = broadcast reads
+        // sieve over the rows of the compacted tile: wave-uniform LDS addresses = broadcast reads
         const int nrows = kept >> 4, rest = kept & 15;
-        if (nrows > 0) {
-            Two rows[P];
-            for (int r = 0; r < nrows; ++r) {
-                const uint4 *rowq = reinterpret_cast<const uint4 *>(tile + r * STRIDE);
-                uint32_t row[P];
+        Two rows[P];
+        for (int r = 0; r < nrows; ++r) {
+            const uint4 *rowq = reinterpret_cast<const uint4 *>(tile + r * STRIDE);
+            uint32_t row[P];
 #pragma unroll
-                for (int c2 = 0; c2 < kRowTokens / 2; ++c2) {
-                    const uint4 two = rowq[c2];  // tokens 2*c2 and 2*c2+1: low words .x and .z
+            for (int half = 0; half < 2; ++half) {
+                uint4 two[4];
+#pragma unroll
+                for (int c2 = 0; c2 < 4; ++c2) two[c2] = rowq[4 * half + c2];  // tokens 2*c2 and 2*c2+1: low words .x and .z
+#pragma unroll
+                for (int c2 = 0; c2 < 4; ++c2) {
 #pragma unroll
                     for (int q = 0; q < P; ++q) {
-                        const uint32_t k0 = (uint32_t)((uint64_t)two.x * sp.a_lo[q] + sp.b8[q]);
-                        const uint32_t k1 = (uint32_t)((uint64_t)two.z * sp.a_lo[q] + sp.b8[q]);
-                        row[q] = c2 == 0 ? min(k0, k1) : umin3(row[q], k0, k1);
+                        const uint32_t k0 = sieve_key(two[c2].x, sp.a_lo[q], sp.b8[q]);
+                        const uint32_t k1 = sieve_key(two[c2].z, sp.a_lo[q], sp.b8[q]);
+                        row[q] = (half == 0 && c2 == 0) ? min(k0, k1) : umin3(row[q], k0, k1);
                     }
                 }
-#pragma unroll
-                for (int q = 0; q < P; ++q) rows[q].add(tag16(row[q], (uint32_t)r));
+                __builtin_amdgcn_sched_barrier(0);  // eight tokens in registers at a time
             }
-            fail |= finish_block<P, STRIDE, 2>(rows, tile, pm, sp, res);
-        }
-        for (int i = 0; i < rest; ++i) {  // the tokens after the last full row: exact
-            const uint32_t *cell = tile + nrows * STRIDE + i * 2;
 #pragma unroll
-            for (int q = 0; q < P; ++q) {
-                uint32_t l0, h0;
-                mad_wide(cell[0], cell[1], pm.a_lo[q], pm.a_hi[q], pm.b[q], l0, h0);
-                res[q] = min(res[q], fold_exact(l0, h0));
-            }
+            for (int q = 0; q < P; ++q) rows[q].add(tag16(row[q], (uint32_t)r));
         }
+        if (rest > 0) {  // the partial last row (nrows <= 15 here: a full tile has no rest)
+            uint32_t row[P];
+#pragma unroll
+            for (int q = 0; q < P; ++q) row[q] = kMaxHash;
+            for (int c = 0; c < rest; ++c) {
+                const uint32_t lo = tile[nrows * STRIDE + 2 * c];
+#pragma unroll
+                for (int q = 0; q < P; ++q) row[q] = min(row[q], sieve_key(lo, sp.a_lo[q], sp.b8[q]));
+            }
+#pragma unroll
+            for (int q = 0; q < P; ++q) rows[q].add(tag16(row[q], (uint32_t)nrows));
+        }
+        if (kept > 0) fail |= finish_block<P, STRIDE, 2, true>(rows, tile, pm, sp, res, (uint32_t)nrows, (uint32_t)rest);
     }
     return fail;
 }
@@ -764,7 +786,11 @@ __device__ __forceinline__ void load_perms(const BulkArgs &args, int kbase, int 
 //               hoisted address arithmetic for paths that run four times in ten thousand sets).
 //   MODE_FULL   the full evaluation (fast fold + exact redo, or the exact fold with path 1) for the
 //               listed sets -- or for every set when the sieve is switched off.
-enum { MODE_SIEVE = 0, MODE_FULL = 1 };
+//   MODE_DEDUP  between the two: the sets the sieve flagged get the dedup sieve (repeated tokens dropped in LDS, sieve
+//               over what is left) and NOTHING else -- a set it cannot settle either is re-flagged for MODE_FULL.  Without
+//               the pair-by-pair code this launch needs far fewer registers than MODE_FULL, and a corpus full of
+//               repeated tokens is settled here at close to the sieve's own rate.
+enum { MODE_SIEVE = 0, MODE_FULL = 1, MODE_DEDUP = 2 };
 enum { SHAPE_GENERAL = 0, SHAPE_PLAIN = 1, SHAPE_PLAIN_FIXED = 2, SHAPE_PLAIN_FIXED_ROWS = 3 };
 
 template <int P, typename TokT, typename OutT, int MODE, int SHAPE>
@@ -786,7 +812,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
     const int waves_per_block = blockDim.x >> 6;
     const int kchunks = (args.num_perm + kWave * P - 1) / (kWave * P);
     // LDS per wave: the token tile of the rescan; the full launch adds the hash tables of its dedup sieve
-    constexpr int kLdsPerWave = MODE == MODE_SIEVE ? kStageWordsPerWave : kDedupWordsPerWave;
+    constexpr int kLdsPerWave = MODE == MODE_DEDUP ? kDedupWordsPerWave : kStageWordsPerWave;
     __shared__ __attribute__((aligned(16))) uint32_t stage[4 * kLdsPerWave];
     uint32_t *lds = stage + wave * kLdsPerWave;
     Perms<P> pm, pm_biased;
@@ -802,18 +828,33 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
     // MODE_FULL after a sieve launch walks the flags 64 sets at a time: one byte load per lane, a
     // ballot, then the flagged sets one by one (a flag array, not an appended list: hundreds of
     // thousands of atomics on one counter serialise -- measured 8 ms for 500k failed sets)
-    const bool flagged_only = MODE == MODE_FULL && args.redo != nullptr;
+    const bool flagged_only = MODE != MODE_SIEVE && args.redo != nullptr;
     // (the four waves of a workgroup share one group of 64 flags and take every fourth flagged set of it:
     // one wave per 64 sets left 2.5 rounds of 64-set waves when everything was flagged)
     const int64_t n_items = flagged_only ? (args.n_sets + kWave - 1) / kWave * waves_per_block : args.n_sets;
     SieveBackoff backoff;
+    int tried = 0, failed = 0;  // MODE_SIEVE: this wave's contribution to args.sieve_hint
+    if (MODE == MODE_SIEVE && args.sieve_hint) {
+        // a launch over a corpus whose sets defeat the sieve (repeated tokens) should not find that out wave by wave
+        // (a wave sees only a handful of sets): waves publish their counts when they leave, and a wave that starts
+        // after most proofs have failed begins in the skipping state
+        const unsigned int t = __builtin_nontemporal_load(args.sieve_hint), f = __builtin_nontemporal_load(args.sieve_hint + 1);
+        if (t >= 64u && 2u * f > t) {
+            backoff.skip = 63;
+            backoff.gap = 64;
+            backoff.streak = 2;
+        }
+    }
+    // flagged launches: the (flag group, wave) items go round the waves of a grid that is exactly as large as what
+    // is resident at once (one atomic counter handing them out one by one serialises: 62 500 items at ~90 dequeues per
+    // microsecond cost 0.7 ms per launch; a larger static grid leaves its last round of workgroups running alone)
     for (int64_t item0 = (int64_t)blockIdx.x * waves_per_block + wave; item0 < n_items; item0 += stride) {
       const int64_t item = flagged_only ? item0 / waves_per_block : item0;  // 64-flag group
       unsigned long long todo = 1;  // sets of this item still to do (bit i = set 64*item + i when flagged_only)
       if (flagged_only) {
           const int64_t cand = item * kWave + lane;
-          const bool mine = (lane % waves_per_block) == wave;
-          todo = __ballot(mine && cand < args.n_sets && args.redo[cand] != 0);
+          const bool mine = (lane % waves_per_block) == (int)(item0 % waves_per_block);  // every fourth flagged set of the group
+          todo = __ballot(mine && cand < args.n_sets && args.redo[cand] == (uint8_t)args.redo_match);
       }
       uint64_t quad[4] = {0, 0, 0, 0};  // MODE_FULL after a sieve launch: first tokens of the current set, fetched one set ahead
       int64_t quad_set = -1;  // the set `quad` belongs to
@@ -855,7 +896,9 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
                 if (kchunks > 1) load_perms<P>(args, kc * (kWave * P), lane, pm, pm_biased, sp, kidx);
                 if (end > beg) {
                     defer = sieve_minima<P, TokT, SHAPE != SHAPE_PLAIN_FIXED_ROWS>(hv, hv_vec, beg, end, pm, pm_biased, sp, args.stats, lane, lds, res);
+                    if (kc == 0) ++tried;
                     if (defer) {
+                        ++failed;
                         backoff.failed();
                         break;
                     }
@@ -868,10 +911,9 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
                     kidx[p] = k < args.num_perm ? k : -1;
                 }
                 if (end > beg) {
-                    // a flagged set first gets the dedup sieve (repeated tokens are what usually broke the
-                    // proof); only what that cannot prove either is hashed pair by pair
-                    bool pairwise = true;
-                    if (flagged_only) {
+                    if (MODE == MODE_DEDUP) {
+                        // a flagged set gets the dedup sieve (repeated tokens are what usually broke the proof); what
+                        // that cannot prove either is left to the pairwise launch
                         load_perms<P>(args, kc * (kWave * P), lane, pm, pm_biased, sp, kidx);
 #pragma unroll
                         for (int p = 0; p < P; ++p) res[p] = kMaxHash;
@@ -889,10 +931,12 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
                             load_quad<TokT>(hv_vec, nbeg, nend, lane, quad);
                             quad_set = nset;
                         }
-                        pairwise = __any(dedup_sieve_range<P, TokT>(hv_vec, beg, end, pm, sp, lds, lane, cur, res));
-                        if (pairwise && args.stats && lane == 0) atomicAdd(args.stats + 3, 1ull);
-                    }
-                    if (pairwise) {
+                        defer = __any(dedup_sieve_range<P, TokT>(hv_vec, beg, end, pm, sp, lds, lane, cur, res));
+                        if (defer) {
+                            if (args.stats && lane == 0) atomicAdd(args.stats + 3, 1ull);
+                            break;
+                        }
+                    } else {
                         const Minima<P> m = full_minima<P, TokT>(hv_vec, beg, end, args.a, args.b, args.num_perm,
                                                                  kc * (kWave * P), args.path == 1, args.stats);
 #pragma unroll
@@ -923,8 +967,14 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
             args.redo[set] = defer ? 1 : 0;
             if (defer && args.stats) atomicAdd(args.stats, 1ull);
         }
+        if (MODE == MODE_DEDUP && defer && lane == 0) args.redo[set] = 2;
         asm volatile("" ::"v"(warm));  // the warm-up load retires here, a whole set later
       }
+    }
+    // (a sample of the waves publishes: atomics of all 65 536 waves on one word would serialise for over a millisecond)
+    if (MODE == MODE_SIEVE && args.sieve_hint && lane == 0 && wave == 0 && (blockIdx.x & 15u) == 0 && tried > 0) {
+        atomicAdd(args.sieve_hint, (unsigned int)tried);
+        if (failed) atomicAdd(args.sieve_hint + 1, (unsigned int)failed);
     }
 }
 
@@ -1034,6 +1084,17 @@ __global__ void minhash_merge_kernel(const uint64_t *__restrict__ x, const uint6
         out[count - 1] = x[count - 1] < y[count - 1] ? x[count - 1] : y[count - 1];
 }
 
+// grid of 256-thread workgroups that is resident all at once (what the occupancy query says per CU, times the CUs),
+// capped by the number of work items
+unsigned resident_grid(mhx_ctx *ctx, const void *kernel, int64_t items) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 2;
+    }
+    return (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, (int64_t)ctx->num_cus * per_cu));
+}
+
 // P permutations per lane in the sieve (and split) launch, PF in the full launch
 template <int P, typename TokT, typename OutT, int PF = P>
 int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_t total_tokens, bool split) {
@@ -1044,20 +1105,36 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_
         const int64_t want = (args.n_sets + 3) / 4;
         dim3 grid((unsigned)std::max<int64_t>(1, std::min(want, max_blocks)), 1u);  // wave loops over kchunks
         if (args.path == 0) {
-            // sieve launch (writes a flag per set), then the full evaluation of the flagged sets (usually a
-            // handful: that launch reads n_sets bytes and returns)
+            // sieve launch (writes a flag per set), then the flagged sets (usually a handful: those launches read
+            // n_sets bytes of flags and return)
+            if (int rc = ctx->ensure_work()) return rc;
+            MHX_HIP_CHECK(hipMemsetAsync(ctx->d_work, 0, 4 * sizeof(unsigned int), ctx->stream));
+            BulkArgs sieve_args = args;
+            sieve_args.sieve_hint = ctx->d_work;
+            const BulkArgs &args_s = sieve_args;
             const bool plain = !args.init && !args.stats && args.alias_mask < 0;
             if (plain && !args.offsets && args.fixed_len % kRowTokens == 0)  // whole 16-token rows: no tail code in the kernel
-                hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN_FIXED_ROWS>), grid, dim3(256), 0, ctx->stream, args);
+                hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN_FIXED_ROWS>), grid, dim3(256), 0, ctx->stream, args_s);
             else if (plain && !args.offsets)
-                hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN_FIXED>), grid, dim3(256), 0, ctx->stream, args);
+                hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN_FIXED>), grid, dim3(256), 0, ctx->stream, args_s);
             else if (plain)
-                hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN>), grid, dim3(256), 0, ctx->stream, args);
+                hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN>), grid, dim3(256), 0, ctx->stream, args_s);
             else
-                hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_GENERAL>), grid, dim3(256), 0, ctx->stream, args);
-            const int64_t flag_groups = (args.n_sets + kWave - 1) / kWave;  // a workgroup scans 64 flags at a time
-            dim3 full_grid((unsigned)std::max<int64_t>(1, std::min(flag_groups, max_blocks)), 1u);
-            hipLaunchKernelGGL((minhash_bulk_kernel<PF, TokT, OutT, MODE_FULL, SHAPE_GENERAL>), full_grid, dim3(256), 0, ctx->stream, args);
+                hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_GENERAL>), grid, dim3(256), 0, ctx->stream, args_s);
+            // the flagged sets: dedup sieve, then pair by pair what is still open (usually nothing: these launches read
+            // n_sets bytes of flags and return).  A workgroup scans 64 flags at a time and strides over the flag
+            // groups: a grid of one short-lived workgroup per group cost 60 us per step in workgroup launches alone
+            const int64_t flag_groups = (args.n_sets + kWave - 1) / kWave;
+            BulkArgs dedup = args;
+            dedup.redo_match = 1;
+            hipLaunchKernelGGL((minhash_bulk_kernel<PF, TokT, OutT, MODE_DEDUP, SHAPE_GENERAL>),
+                               dim3(resident_grid(ctx, (const void *)minhash_bulk_kernel<PF, TokT, OutT, MODE_DEDUP, SHAPE_GENERAL>, flag_groups)),
+                               dim3(256), 0, ctx->stream, dedup);
+            BulkArgs rest = args;
+            rest.redo_match = 2;
+            hipLaunchKernelGGL((minhash_bulk_kernel<PF, TokT, OutT, MODE_FULL, SHAPE_GENERAL>),
+                               dim3(resident_grid(ctx, (const void *)minhash_bulk_kernel<PF, TokT, OutT, MODE_FULL, SHAPE_GENERAL>, flag_groups)),
+                               dim3(256), 0, ctx->stream, rest);
         } else {
             BulkArgs all = args;
             all.redo = nullptr;  // every set
@@ -1117,6 +1194,8 @@ int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const in
     args.path = (int32_t)ctx->opt_minhash_path;
     args.stats = ctx->d_stats;
     args.redo = nullptr;
+    args.redo_match = 1;
+    args.sieve_hint = nullptr;
     args.alias_mask = ctx->opt_minhash_alias;
     args.prefetch = ctx->opt_minhash_prefetch != 0;
     args.init = d_init;

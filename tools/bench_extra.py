@@ -138,13 +138,14 @@ def minhash_shapes(ctx):
             print(json.dumps({"name": f"update_batch host->host n={t} K={k}", "ms": round(1e3 * (time.perf_counter() - t0), 4)}), flush=True)
 
 
-def minhash_ragged(ctx):
+def minhash_ragged(ctx, only_repeats=False):
     """Realistic corpora: ragged sets (CSR), and sets with repeated tokens (failed sieve proofs)."""
     rng = np.random.RandomState(7)
     k = 128
     a, b = MinHash(num_perm=k, seed=1).permutations
-    for name, n, lo, hi, dup in (("ragged 32..480", 500_000, 32, 480, 0.0), ("ragged 1..100", 1_000_000, 1, 100, 0.0),
-                                 ("dense 256 with 10% repeated tokens", 500_000, 256, 256, 0.1)):
+    cases = (("ragged 32..480", 500_000, 32, 480, 0.0), ("ragged 1..100", 1_000_000, 1, 100, 0.0),
+             ("dense 256 with 10% repeated tokens", 500_000, 256, 256, 0.1), ("dense 256 with 1% repeated tokens", 500_000, 256, 256, 0.01))
+    for name, n, lo, hi, dup in (cases[2:] if only_repeats else cases):
         lens = rng.randint(lo, hi + 1, size=n).astype(np.int64)
         off = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(lens, out=off[1:])
@@ -289,6 +290,8 @@ def main():
     print(json.dumps(ctx.info()), flush=True)
     if args.only in ("", "minhash"):
         minhash_shapes(ctx)
+    if args.only == "repeats":
+        minhash_ragged(ctx, only_repeats=True)
     if args.only in ("", "minhash", "ragged"):
         minhash_ragged(ctx)
     if args.only in ("", "sha1"):
