@@ -85,6 +85,8 @@ _PROTOTYPES = {
     "mhx_band_digests_dev_typed": [_vp, _vp, _int, _i64, _i32, _i32, _i32, _vp],
     "mhx_lsh_sort_bands_dev_typed": [_vp, _vp, _int, _i64, _i32, _i32, _i32, _vp, _vp],
     "mhx_jaccard_pairs_dev_typed": [_vp, _vp, _vp, _int, _i32, _vp, _i64, _vp],
+    "mhx_bbit_jaccard_pairs_dev": [_vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp],
+    "mhx_bbit_jaccard_pairs": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp],
     "mhx_lean_serialize_dev": [_vp, _vp, _i64, _i32, _i64, _vp],
     "mhx_lean_serialize": [_vp, _vp, _i64, _i32, _i64, _vp],
     "mhx_comm_unique_id": [_vp],
@@ -555,6 +557,20 @@ class Context:
         n, k = sig.shape
         out = np.empty(pairs.shape[0], dtype=np.int32)
         check(self.lib.mhx_jaccard_pairs(self.handle, _ptr(sig), n, k, _ptr(pairs), pairs.shape[0], _ptr(out)))
+        return out
+
+    def bbit_jaccard_pairs(self, blocks: np.ndarray, num_perm: int, b: int, pairs: np.ndarray) -> np.ndarray:
+        """int32 counts of agreeing b-bit positions for rows (pairs[:,0], pairs[:,1]) of a packed matrix
+        (``bbit_pack`` output, [n, num_blocks] uint64)."""
+        blocks = np.ascontiguousarray(blocks, dtype=np.uint64)
+        pairs = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+        nb = _i32(0)
+        check(self.lib.mhx_bbit_num_blocks(int(num_perm), int(b), ctypes.byref(nb)))
+        if blocks.ndim != 2 or blocks.shape[1] != nb.value:
+            raise ValueError("blocks must be [n, %d] for num_perm=%d, b=%d" % (nb.value, num_perm, b))
+        out = np.empty(pairs.shape[0], dtype=np.int32)
+        check(self.lib.mhx_bbit_jaccard_pairs(self.handle, _ptr(blocks), blocks.shape[0], int(num_perm), int(b), _ptr(pairs),
+                                              pairs.shape[0], _ptr(out)))
         return out
 
     def lean_serialize(self, sig: np.ndarray, seed: int) -> np.ndarray:

@@ -142,3 +142,32 @@ def pack_matrix(signatures: np.ndarray, b: int, gpu_mode: str = "always") -> np.
         return _native.context().bbit_pack(signatures, b)
     masked = np.bitwise_and(signatures, np.uint64((1 << b) - 1))
     return _pack_rows(masked, _slot_size(b))
+
+
+def jaccard_pairs(blocks: np.ndarray, pairs, num_perm: int, b: int, r: float = 0.0, gpu_mode: str = "always") -> np.ndarray:
+    """``bBitMinHash.jaccard`` (ref: datasketch/b_bit_minhash.py:53-72) for rows ``pairs[:, 0]`` and ``pairs[:, 1]`` of a
+    packed matrix (:func:`pack_matrix` output): float64 estimates ``(agreeing / num_perm - C1) / (1 - C2)`` with the
+    reference's ``A(r, b)``, ``C1``, ``C2`` for a common ``r``.  On the device the agreeing positions are counted on the
+    packed blocks (XOR, fold every slot to one bit, popcount); the numpy path unpacks."""
+    b = int(b)
+    if b > 32 or b < 0:
+        raise ValueError("b must be an integer in [0, 32]")
+    if r > 1.0:
+        raise ValueError("r must be a float in [0.0, 1.0]")
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint64)
+    pairs = np.ascontiguousarray(pairs, dtype=np.int64).reshape(-1, 2)
+    if pairs.size and (pairs.min() < 0 or pairs.max() >= blocks.shape[0]):
+        raise ValueError("pair index out of range")
+    slot = _slot_size(b)
+    nb = -(-int(num_perm) // (64 // slot))
+    if blocks.ndim != 2 or blocks.shape[1] != nb:
+        raise ValueError("blocks must be [n, %d] for num_perm=%d, b=%d" % (nb, num_perm, b))
+    if gpu_mode != "disable" and (gpu_mode == "always" or _native.gpu_available()):
+        same = _native.context().bbit_jaccard_pairs(blocks, num_perm, b, pairs)
+    else:
+        vals = _unpack_rows(blocks, slot, num_perm)
+        same = np.count_nonzero(vals[pairs[:, 0]] == vals[pairs[:, 1]], axis=1)
+    proto = object.__new__(bBitMinHash)
+    a = proto._calc_a(float(r), b)
+    c1, c2 = proto._calc_c(a, a, float(r), float(r))
+    return (same.astype(np.float64) / float(num_perm) - c1) / (1 - c2)

@@ -1062,6 +1062,44 @@ int mhx_jaccard_pairs(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, c
     return fetch_out(ctx, counts, out_bytes);
 }
 
+int mhx_bbit_jaccard_pairs_dev(mhx_ctx *ctx, const uint64_t *d_blocks_a, const uint64_t *d_blocks_b, int32_t k, int32_t b,
+                               const int64_t *d_pairs, int64_t n_pairs, int32_t *d_counts) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    MHX_REQUIRE(b >= 0 && b <= 32, "b must be an integer in [0, 32]");
+    MHX_REQUIRE(k > 0 && n_pairs >= 0, "bad shape");
+    if (n_pairs == 0) return MHX_OK;
+    MHX_REQUIRE(d_blocks_a && d_blocks_b && d_pairs && d_counts, "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_bbit_jaccard(ctx, d_blocks_a, d_blocks_b, k, b, d_pairs, n_pairs, d_counts);
+}
+
+int mhx_bbit_jaccard_pairs(mhx_ctx *ctx, const uint64_t *blocks, int64_t n, int32_t k, int32_t b, const int64_t *pairs,
+                           int64_t n_pairs, int32_t *counts) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    int32_t nb = 0;
+    if (int rc = mhx_bbit_num_blocks(k, b, &nb)) return rc;
+    MHX_REQUIRE(n >= 0 && n_pairs >= 0, "bad shape");
+    if (n_pairs == 0) return MHX_OK;
+    MHX_REQUIRE(blocks && pairs && counts, "NULL host pointer");
+    for (int64_t p = 0; p < 2 * n_pairs; ++p)
+        MHX_REQUIRE(pairs[p] >= 0 && pairs[p] < n, "pair index %lld out of range [0,%lld)", (long long)pairs[p], (long long)n);
+    if (int rc = ctx->activate()) return rc;
+    const size_t in_bytes = sizeof(uint64_t) * (size_t)n * (size_t)nb, pair_bytes = sizeof(int64_t) * 2 * (size_t)n_pairs;
+    const size_t out_bytes = sizeof(int32_t) * (size_t)n_pairs;
+    if (int rc = ctx->ensure_scratch(0, in_bytes)) return rc;
+    if (int rc = ctx->ensure_scratch(1, pair_bytes)) return rc;
+    if (int rc = ctx->ensure_scratch(2, out_bytes)) return rc;
+    MHX_HIP_CHECK(hipMemcpyAsync(ctx->scratch[0], blocks, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    MHX_HIP_CHECK(hipMemcpyAsync(ctx->scratch[1], pairs, pair_bytes, hipMemcpyHostToDevice, ctx->stream));
+    const uint64_t *d_blocks = (const uint64_t *)ctx->scratch[0];
+    if (int rc = mhx::launch_bbit_jaccard(ctx, d_blocks, d_blocks, k, b, (const int64_t *)ctx->scratch[1], n_pairs,
+                                          (int32_t *)ctx->scratch[2]))
+        return rc;
+    return fetch_out(ctx, counts, out_bytes);
+}
+
 int mhx_lean_serialize(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, int64_t seed, uint8_t *out) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
     MHX_GUARD(ctx);

@@ -139,6 +139,8 @@ int launch_lsh_sort_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_
 int launch_lsh_query(mhx_ctx *ctx, const uint64_t *d_sorted_digests, const uint32_t *d_sorted_rows, int64_t n, int32_t bands,
                      int32_t r, const void *d_q_sig, const void *d_idx_sig, int sig_dtype, int32_t k, int64_t m,
                      int64_t *d_pairs, int64_t capacity, int64_t *n_pairs);
+int launch_bbit_jaccard(mhx_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, int32_t k, int32_t b, const int64_t *d_pairs,
+                        int64_t m, int32_t *d_counts);
 int launch_lean_serialize(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int64_t seed,
                           uint8_t *d_out);
 

@@ -191,6 +191,40 @@ __global__ __launch_bounds__(256) void jaccard_pairs_kernel(const SigT *__restri
     }
 }
 
+// ---- batched b-bit Jaccard numerators -----------------------------------------------------------
+// counts[p] = number of positions whose b-bit values agree in packed rows pairs[p][0] (of A) and pairs[p][1] (of B):
+// the `intersection` of bBitMinHash.jaccard (ref: datasketch/b_bit_minhash.py:53-72), taken on the packed blocks
+// (ref :82-101) without unpacking: z = x ^ y, OR every slot's bits down into its lowest bit, popcount the slots
+// that differ.  Slots behind num_perm are zero in both rows, so agreeing positions = num_perm - differing slots.
+// LPP lanes share a pair (LPP = power of two >= blocks per row, at most 64): coalesced row reads, shuffle reduction.
+__global__ __launch_bounds__(256) void bbit_jaccard_kernel(const uint64_t *__restrict__ a, const uint64_t *__restrict__ b,
+                                                           int32_t nb, int32_t slot, int32_t k, int32_t lpp,
+                                                           const int64_t *__restrict__ pairs, int64_t m,
+                                                           int32_t *__restrict__ counts) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int sub = lane & (lpp - 1);          // my position among the lanes of one pair
+    const int pairs_per_wave = kWave / lpp;
+    const int64_t wave_id = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int64_t wave_stride = (int64_t)gridDim.x * (blockDim.x >> 6);
+    // lowest bit of every slot
+    const uint64_t low = slot == 1 ? ~0ull : slot == 2 ? 0x5555555555555555ull : slot == 4 ? 0x1111111111111111ull
+                       : slot == 8 ? 0x0101010101010101ull : slot == 16 ? 0x0001000100010001ull : 0x0000000100000001ull;
+    for (int64_t p0 = wave_id * pairs_per_wave; p0 < m; p0 += wave_stride * pairs_per_wave) {
+        const int64_t p = p0 + lane / lpp;
+        int32_t differ = 0;
+        if (p < m) {
+            const uint64_t *x = a + pairs[2 * p] * nb, *y = b + pairs[2 * p + 1] * nb;
+            for (int c = sub; c < nb; c += lpp) {
+                uint64_t z = x[c] ^ y[c];
+                for (int sh = 1; sh < slot; sh <<= 1) z |= z >> sh;
+                differ += __popcll(z & low);
+            }
+        }
+        for (int d = 1; d < lpp; d <<= 1) differ += __shfl_xor(differ, d);
+        if (p < m && sub == 0) counts[p] = k - differ;
+    }
+}
+
 inline dim3 row_grid(mhx_ctx *ctx, int64_t n) {
     const int64_t want = (n + 3) / 4;
     return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * 8)));
@@ -251,6 +285,21 @@ int launch_jaccard_pairs(mhx_ctx *ctx, const void *d_a, const void *d_b, int sig
     else
         hipLaunchKernelGGL(jaccard_pairs_kernel<uint64_t>, row_grid(ctx, m), dim3(256), 0, ctx->stream, (const uint64_t *)d_a,
                            (const uint64_t *)d_b, k, d_pairs, m, d_counts);
+    MHX_HIP_CHECK(hipGetLastError());
+    return MHX_OK;
+}
+
+int launch_bbit_jaccard(mhx_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, int32_t k, int32_t b, const int64_t *d_pairs,
+                        int64_t m, int32_t *d_counts) {
+    const int slot = bbit_slot_size(b);
+    const int per = 64 / slot;
+    const int nb = (k + per - 1) / per;
+    int lpp = 1;
+    while (lpp < nb && lpp < kWave) lpp <<= 1;
+    const int64_t waves = (m * lpp + kWave - 1) / kWave;
+    const int64_t want = (waves + 3) / 4;
+    dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * 8)));
+    hipLaunchKernelGGL(bbit_jaccard_kernel, grid, dim3(256), 0, ctx->stream, d_a, d_b, nb, slot, k, lpp, d_pairs, m, d_counts);
     MHX_HIP_CHECK(hipGetLastError());
     return MHX_OK;
 }

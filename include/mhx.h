@@ -295,6 +295,15 @@ MHX_API int mhx_jaccard_pairs_dev(mhx_ctx *ctx, const uint64_t *d_sig_a, const u
                                   int32_t *d_counts);
 MHX_API int mhx_jaccard_pairs(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs, int32_t num_perm,
                               const int64_t *pairs, int64_t n_pairs, int32_t *counts);
+/* Batched bBitMinHash.jaccard numerators (ref: datasketch/b_bit_minhash.py:53-72) on packed rows (mhx_bbit_pack*):
+ * counts[p] = number of the num_perm positions whose b-bit values agree in rows pairs[p][0] of blocks_a and
+ * pairs[p][1] of blocks_b (both [*, num_blocks] uint64; may be the same matrix) -- XOR + popcount on the packed
+ * blocks, nothing is unpacked.  The estimate is (counts / num_perm - C1) / (1 - C2) with the reference's C1, C2. */
+MHX_API int mhx_bbit_jaccard_pairs_dev(mhx_ctx *ctx, const uint64_t *d_blocks_a, const uint64_t *d_blocks_b,
+                                       int32_t num_perm, int32_t b, const int64_t *d_pairs, int64_t n_pairs,
+                                       int32_t *d_counts);
+MHX_API int mhx_bbit_jaccard_pairs(mhx_ctx *ctx, const uint64_t *blocks, int64_t n_rows, int32_t num_perm, int32_t b,
+                                   const int64_t *pairs, int64_t n_pairs, int32_t *counts);
 /* The device entry points above for signature matrices of sig_dtype MHX_U64 or MHX_U32 -- uint32 is the compact
  * output of mhx_minhash_bulk_dev and the wire format of the all-gather (values are < 2^32, ref: minhash.py:31,297);
  * results are those of the widened matrix. */

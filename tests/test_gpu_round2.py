@@ -407,3 +407,34 @@ os._exit(0)
     with open(os.path.join(ROOT, "gpurun_out", "rccl_two_ranks_one_device.txt"), "w") as f:
         f.write("\n---\n".join(outs))
     assert all(("OK" in o) or ("REFUSED" in o) or ("TIMEOUT" in o) for o in outs), outs
+
+
+# ------------------------------------------------------------------ b-bit Jaccard on packed rows
+@pytest.mark.parametrize("k", [64, 100, 256, 1000])
+def test_bbit_jaccard_pairs_on_the_device(ctx, k):
+    """Agreeing b-bit positions counted on the packed blocks (XOR + popcount) == counted on the unpacked values, for
+    every slot size; the estimate equals bBitMinHash.jaccard (ref: b_bit_minhash.py:53-72)."""
+    from datasketch_amd import bBitMinHash
+    from datasketch_amd.b_bit_minhash import jaccard_pairs, pack_matrix
+
+    rng = np.random.RandomState(k)
+    n = 3000
+    sig = rng.randint(0, 2**32, (n, k)).astype(np.uint64)
+    sig[1::2, : k // 2] = sig[0::2, : k // 2]          # pairs (2i, 2i+1) agree on at least half
+    pairs = np.stack([rng.randint(0, n, 5000), rng.randint(0, n, 5000)], axis=1).astype(np.int64)
+    pairs[:1000, 0] = np.arange(0, 2000, 2)
+    pairs[:1000, 1] = np.arange(1, 2000, 2)
+    pairs[1000] = (7, 7)
+    for b in (1, 2, 3, 4, 7, 8, 12, 16, 20, 32):
+        blocks = pack_matrix(sig, b, gpu_mode="always")
+        got = ctx.bbit_jaccard_pairs(blocks, k, b, pairs)
+        mask = np.uint64((1 << b) - 1)
+        want = np.count_nonzero((sig[pairs[:, 0]] & mask) == (sig[pairs[:, 1]] & mask), axis=1)
+        assert np.array_equal(got, want), b
+        assert got[1000] == k and got[:1000].min() >= k // 2
+    est = jaccard_pairs(pack_matrix(sig, 2, gpu_mode="always"), pairs[:50], k, 2, 0.25, gpu_mode="always")
+    for (i, j), e in zip(pairs[:50], est):
+        x = bBitMinHash(MinHash(num_perm=k, hashvalues=sig[i]), 2, 0.25)
+        y = bBitMinHash(MinHash(num_perm=k, hashvalues=sig[j]), 2, 0.25)
+        assert e == x.jaccard(y)
+    assert ctx.bbit_jaccard_pairs(pack_matrix(sig, 1, gpu_mode="always"), k, 1, np.empty((0, 2), np.int64)).size == 0

@@ -446,3 +446,26 @@ def test_near_duplicates_example_runs_on_the_numpy_paths():
     spec.loader.exec_module(mod)
     out = mod.main(["--docs", "1200", "--gpu-mode", "disable"])
     assert out["signatures"].shape == (1200, 128) and out["recall"] > 0.9 and len(out["kept"]) >= 100
+
+
+def test_bbit_jaccard_pairs_matches_the_object_method():
+    """b_bit_minhash.jaccard_pairs on packed rows == bBitMinHash.jaccard of the two objects
+    (ref: datasketch/b_bit_minhash.py:53-72), for every slot size and for r = 0 and r > 0."""
+    from datasketch_amd.b_bit_minhash import jaccard_pairs, pack_matrix
+
+    rng = np.random.RandomState(0)
+    sig = rng.randint(0, 2**32, (40, 100)).astype(np.uint64)
+    sig[1, :60] = sig[0, :60]
+    pairs = np.array([[0, 1], [2, 3], [4, 4], [0, 39]])
+    for b in (1, 2, 3, 5, 8, 13, 32):
+        for r in (0.0, 0.3):
+            blocks = pack_matrix(sig, b, gpu_mode="disable")
+            est = jaccard_pairs(blocks, pairs, 100, b, r, gpu_mode="disable")
+            for (i, j), e in zip(pairs, est):
+                x = bBitMinHash(MinHash(num_perm=100, hashvalues=sig[i]), b, r)
+                y = bBitMinHash(MinHash(num_perm=100, hashvalues=sig[j]), b, r)
+                assert e == x.jaccard(y)
+    with pytest.raises(ValueError):
+        jaccard_pairs(pack_matrix(sig, 1, gpu_mode="disable"), pairs, 100, 2, gpu_mode="disable")  # blocks of another b
+    with pytest.raises(ValueError):
+        jaccard_pairs(pack_matrix(sig, 1, gpu_mode="disable"), [[0, 40]], 100, 1, gpu_mode="disable")
