@@ -261,6 +261,91 @@ def lsh(ctx, n):
     print(json.dumps({"name": f"candidate_pairs device path host->host N={m}", "seconds": round(time.perf_counter() - t0, 4)}), flush=True)
 
 
+class _DictLSH:
+    """The state of the reference's MinHashLSH with its in-memory storage (ref: datasketch/lsh.py:178-199,
+    storage.py:210-259) -- enough of it for insert_bulk / query_bulk and for the per-key loop below, so that the
+    timing does not need the reference repository on the GPU box (tests/test_lsh_bulk.py checks both against the
+    real class where it is mounted)."""
+
+    def __init__(self, h, b, r):
+        import collections
+
+        class Store:
+            def __init__(self, factory):
+                self._dict = collections.defaultdict(factory)
+
+        self.h, self.b, self.r, self.prepickle, self.hashfunc = h, b, r, False, None
+        self.keys = Store(list)
+        self.hashtables = [Store(set) for _ in range(b)]
+        self.hashranges = [(i * r, (i + 1) * r) for i in range(b)]
+
+    def insert(self, key, hashvalues):  # lsh.py:326-347 on dict storage
+        hs = [bytes(hashvalues[s:e].byteswap().data) for s, e in self.hashranges]
+        self.keys._dict[key].extend(hs)
+        for h, table in zip(hs, self.hashtables):
+            table._dict[h].add(key)
+
+    def query(self, hashvalues):  # lsh.py:423-431
+        cand = set()
+        for (s, e), table in zip(self.hashranges, self.hashtables):
+            cand.update(table._dict.get(bytes(hashvalues[s:e].byteswap().data), ()))
+        return list(cand)
+
+
+def lsh_index(ctx, n):
+    """MinHashLSH insertion and query in bulk (row f1): K=256, (b, r) = (32, 8) as config 3/5."""
+    rng = np.random.RandomState(33)
+    k, b, r = 256, 32, 8
+    sig = rng.randint(0, 2**32, (n, k), dtype=np.uint64)
+    dup = rng.randint(0, n, n // 20)
+    sig[dup, : k // 2] = sig[rng.randint(0, n, n // 20), : k // 2]   # 5 % of the rows share half their bands with another row
+    keys = [b"%d" % i for i in range(n)]
+    one, bulk = _DictLSH(k, b, r), _DictLSH(k, b, r)
+    m = min(n, 20_000)
+    t0 = time.perf_counter()
+    for i in range(m):
+        one.insert(keys[i], sig[i])
+    loop_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    LB.insert_bulk(bulk, keys, sig, gpu_mode="always")
+    bulk_s = time.perf_counter() - t0
+    for j in (0, b - 1):
+        sample = list(one.hashtables[j]._dict.items())[:2000]
+        assert all(bulk.hashtables[j]._dict[h] >= v for h, v in sample)
+    probes = sig[rng.randint(0, n, 20_000)]
+    t0 = time.perf_counter()
+    got = LB.query_bulk(bulk, probes, gpu_mode="always")
+    qbulk_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    want = [bulk.query(row) for row in probes[:2000]]
+    qloop_s = time.perf_counter() - t0
+    assert all(set(a) == set(c) for a, c in zip(got[:2000], want))
+    print(json.dumps({"name": f"MinHashLSH dict index, K={k} ({b} x {r}): insert_bulk of {n} keys", "seconds": round(bulk_s, 3),
+                      "keys_per_s": n / bulk_s, "per_key_loop_keys_per_s": m / loop_s, "per_key_loop_sample": m,
+                      "query_bulk_probes_per_s": len(probes) / qbulk_s, "per_probe_loop_probes_per_s": 2000 / qloop_s}), flush=True)
+    del one, bulk, got, want
+    # the same index resident on the GPU as sorted bands: build + query 1M probes
+    t0 = time.perf_counter()
+    idx = LB.SortedBandsIndex(sig, b, r)
+    ctx.synchronize()
+    build_s = time.perf_counter() - t0
+    probes = sig[rng.randint(0, n, min(n, 1_000_000))].copy()
+    probes[::2, rng.randint(0, k, 40)] = 3
+    idx.query(probes[:1000])
+    t0 = time.perf_counter()
+    offsets, rows = idx.query(probes)
+    q_s = time.perf_counter() - t0
+    print(json.dumps({"name": f"SortedBandsIndex (device), K={k} ({b} x {r}), {n} rows: build from host matrix", "seconds": round(build_s, 4),
+                      "query_probes": int(len(probes)), "query_seconds_host_to_host": round(q_s, 4), "probes_per_s": len(probes) / q_s,
+                      "candidates": int(rows.size)}), flush=True)
+    # b-bit Jaccard of candidate pairs on packed rows
+    blocks = ctx.bbit_pack(sig, 1)
+    pairs = np.stack([np.repeat(np.arange(len(offsets) - 1), np.diff(offsets)), rows], axis=1)[:2_000_000]
+    d_blocks, d_pairs, d_cnt = ctx.to_device(blocks), ctx.to_device(pairs), ctx.alloc(4 * len(pairs))
+    ms = timed(ctx, lambda: _native.check(ctx.lib.mhx_bbit_jaccard_pairs_dev(ctx.handle, d_blocks.ptr, d_blocks.ptr, k, 1, d_pairs.ptr, len(pairs), d_cnt.ptr)))
+    report(f"bbit_jaccard_pairs b=1 K={k}, {len(pairs)} pairs", ms, len(pairs), "pairs", len(pairs) * (2 * 32 + 16 + 4))
+
+
 def weighted_python_level(ctx, n, dim, s):
     """WeightedMinHashGenerator.minhash_many_arrays from Python on a dense matrix: the device-built CSR (dense
     entry point) against the scipy CSR the reference route needs first."""
@@ -300,6 +385,8 @@ def main():
         packing(ctx, args.sigs, 256)
     if args.only in ("", "refbench"):
         reference_gpu_benchmark(ctx)
+    if args.only in ("", "lsh", "lsh_index"):
+        lsh_index(ctx, args.sigs)
     if args.only in ("", "lsh"):
         lsh(ctx, args.sigs)
     if args.only in ("", "weighted", "weighted_py"):

@@ -9,8 +9,9 @@ mkdir -p "${OUT}"
 export TMPDIR=/tmp
 # the trace pass runs bench.py's own default step counts (20 timed, 3 warm-up) so that its per-kernel average
 # can be set against the bench line; the counter passes only need a few dispatches
+# (the trace keeps bench.py's extra configs 3/4/5 so that their kernels appear in the summary too)
 TRACE=(python bench.py --cpu-sample 0 --no-e2e --check-rows 0 "$@")
-BENCH=(python bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-e2e --check-rows 0 "$@")
+BENCH=(python bench.py --steps 5 --warmup 1 --cpu-sample 0 --no-e2e --no-extra --check-rows 0 "$@")
 rocprofv3 --kernel-trace --stats -d "${OUT}/trace" -o trace -- "${TRACE[@]}" > "${OUT}/trace.log" 2>&1
 echo "trace rc=$?"
 [[ "${PROFILE_ONLY:-}" == "trace" ]] && exit 0
