@@ -170,7 +170,7 @@ class WeightedMinHashGenerator:
 
     # rows per piece of the pipelined dense call, and the threads that take np.log ahead of the device
     _PIPE_ROWS_BYTES = 64 << 20
-    _PIPE_LOG_THREADS = 4
+    _PIPE_LOG_THREADS = 8
 
     def _dense_parity_pipelined(self, ctx, handle, x32: np.ndarray):
         """Parity mode on a dense matrix: ``np.log`` stays on the host (numpy's float32 log is what the reference

@@ -13,6 +13,14 @@ import sys
 from collections import defaultdict
 
 
+def short(name):
+    """Kernel name without namespaces and argument list, template arguments kept."""
+    name = name.replace("(anonymous namespace)::", "").replace("mhx::", "").replace("void ", "")
+    name = name.replace("unsigned long", "u64").replace("unsigned int", "u32")
+    cut = name.find(">(")
+    return (name[: cut + 1] if cut > 0 else name.split("(")[0])[:110]
+
+
 def trace_summary(db):
     con = sqlite3.connect(db)
     rows = con.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by sum(duration) desc").fetchall()
@@ -25,9 +33,9 @@ def trace_summary(db):
         durs = [d for (d,) in con.execute("select duration from kernels where name = ? order by start", (name,))]
         steady = durs[1:-1] if len(durs) > 3 else durs
         med = sorted(durs)[len(durs) // 2]
-        print(f"{calls:6d} {tot/1e3:12.1f} {avg/1e3:10.1f} {sum(steady)/len(steady)/1e3:10.1f} {med/1e3:10.1f} {mn/1e3:10.1f} {mx/1e3:10.1f} {100*tot/total:6.2f}  {name}")
+        print(f"{calls:6d} {tot/1e3:12.1f} {avg/1e3:10.1f} {sum(steady)/len(steady)/1e3:10.1f} {med/1e3:10.1f} {mn/1e3:10.1f} {mx/1e3:10.1f} {100*tot/total:6.2f}  {short(name)}")
     for r in con.execute("select name, vgpr_count, accum_vgpr_count, sgpr_count, grid_x, grid_y, workgroup_x, lds_size, scratch_size from kernels group by name"):
-        print(f"#   {r[0][:90]}: vgpr={r[1]} agpr={r[2]} sgpr={r[3]} grid=({r[4]},{r[5]}) wg={r[6]} lds={r[7]} scratch={r[8]}")
+        print(f"#   {short(r[0])}: vgpr={r[1]} agpr={r[2]} sgpr={r[3]} grid=({r[4]},{r[5]}) wg={r[6]} lds={r[7]} scratch={r[8]}")
 
 
 def pmc_summary(db):
@@ -38,7 +46,7 @@ def pmc_summary(db):
     print(f"# pmc: {db}")
     for (kernel, counter), d in sorted(per.items()):
         vals = list(d.values())
-        print(f"{counter:28s} mean/dispatch={sum(vals)/len(vals):18.1f}  dispatches={len(vals):3d}  {kernel[:80]}")
+        print(f"{counter:28s} mean/dispatch={sum(vals)/len(vals):18.1f}  dispatches={len(vals):3d}  {short(kernel)}")
 
 
 def main():
