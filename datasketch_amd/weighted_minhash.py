@@ -168,42 +168,48 @@ class WeightedMinHashGenerator:
             return ctx.weighted_minhash_many(handle, self.sample_size, indptr, indices, log_data, True)
         return self._minhash_many_host(indptr, indices, X.data)
 
-    # rows per piece of the pipelined dense call, and the threads that take np.log ahead of the device
-    _PIPE_ROWS_BYTES = 64 << 20
+    # bytes per piece of the pipelined dense call, and the threads that take np.log ahead of the device
+    _PIPE_PIECE_BYTES = 32 << 20
     _PIPE_LOG_THREADS = 8
 
     def _dense_parity_pipelined(self, ctx, handle, x32: np.ndarray):
         """Parity mode on a dense matrix: ``np.log`` stays on the host (numpy's float32 log is what the reference
         computes, weighted_minhash.py:212, and only the same binary reproduces it bit for bit), but it no longer
         serialises with the device: the matrix is cut into pieces of rows, a few threads take the logs of the pieces
-        ahead (numpy releases the GIL inside the ufunc loop) while this thread sends finished pieces through the
-        device call (ctypes releases the GIL too).  Config 4 (100k x 4096): 0.28 s -> about the PCIe + kernel time."""
+        ahead (numpy releases the GIL inside the ufunc loop) into a ring of reused buffers (a fresh 32 MB array per
+        piece costs its page faults every time) while this thread sends finished pieces through the device call
+        (ctypes releases the GIL too)."""
         n, dim = x32.shape
         s = self.sample_size
         out = np.zeros((n, s, 2), dtype=np.int64)
         nonempty = np.zeros(n, dtype=np.uint8)
-        rows = max(1024, self._PIPE_ROWS_BYTES // max(4 * dim, 1))
-        if n <= rows:
+        rows = max(256, self._PIPE_PIECE_BYTES // max(4 * dim, 1))
+        if n <= 2 * rows:
             with np.errstate(invalid="ignore", divide="ignore"):
                 logs = np.log(x32)
             return ctx.weighted_minhash_many_dense(handle, s, logs, True, out=out, nonempty=nonempty)
         from concurrent.futures import ThreadPoolExecutor
 
-        def take_log(lo):
+        ahead = self._PIPE_LOG_THREADS + 2
+        ring = [np.empty((rows, dim), dtype=np.float32) for _ in range(ahead)]
+
+        def take_log(i, lo):
+            hi = min(n, lo + rows)
+            buf = ring[i % ahead][: hi - lo]
             with np.errstate(invalid="ignore", divide="ignore"):
-                return np.log(x32[lo : lo + rows])
+                np.log(x32[lo:hi], out=buf)
+            return buf
 
         starts = list(range(0, n, rows))
         with ThreadPoolExecutor(self._PIPE_LOG_THREADS) as pool:
-            ahead = self._PIPE_LOG_THREADS + 1
-            futures = [pool.submit(take_log, lo) for lo in starts[:ahead]]
+            futures = [pool.submit(take_log, i, lo) for i, lo in enumerate(starts[:ahead])]
             for i, lo in enumerate(starts):
                 logs = futures[i].result()
                 futures[i] = None
-                if i + ahead < len(starts):
-                    futures.append(pool.submit(take_log, starts[i + ahead]))
                 hi = min(n, lo + rows)
                 ctx.weighted_minhash_many_dense(handle, s, logs, True, out=out[lo:hi], nonempty=nonempty[lo:hi])
+                if i + ahead < len(starts):  # buffer i % ahead is free again: the device call has returned
+                    futures.append(pool.submit(take_log, i + ahead, starts[i + ahead]))
         return out, nonempty.view(bool)
 
     def _minhash_many_host(self, indptr, indices, data):
