@@ -978,6 +978,111 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
     }
 }
 
+// ---- kernel C: several sets per wave for short signatures (num_perm <= 32) ----------------------------------
+// With one set per wave, lanes >= num_perm idle (K = 16: three quarters of the machine).  Here a wave takes
+// G = 64 / KP sets at once (KP = 8, 16 or 32 lanes per set, one permutation per lane).  The sets' tokens then differ
+// between the lane groups, so they cannot be scalar operands: every block of up to 256 tokens of each of the G sets
+// is copied, coalesced, into the group's own LDS tile (the tile of the rescan, now also the source of the hot loop:
+// a lane group reads the same address, a broadcast), and the sieve runs per lane exactly as in kernel A -- row minima
+// of 16 keys, tagged top-two fold, rescan of the best row, one exact candidate; the partial last row takes part with
+// its stale cells masked.  A set whose proof fails in any of its lanes is flagged for the dedup / pairwise launches.
+template <int KP, typename TokT, typename OutT>
+__global__ __launch_bounds__(256) void minhash_packed_kernel(const BulkArgs args) {
+    constexpr int G = kWave / KP;
+    constexpr int STRIDE = 36;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane / KP, k = lane % KP;
+    __shared__ __attribute__((aligned(16))) uint32_t stage[4 * G * kStageWordsPerWave];
+    uint32_t *tiles = stage + wave * (G * kStageWordsPerWave);
+    uint32_t *my_tile = tiles + g * kStageWordsPerWave;
+    const bool active = k < args.num_perm;
+    Perms<1> pm;
+    SievePerms<1> sp;
+    {
+        const uint64_t a = active ? args.a[k] : 0, b = active ? args.b[k] : 0;
+        pm.a_lo[0] = sp.a_lo[0] = (uint32_t)a;
+        pm.a_hi[0] = (uint32_t)(a >> 32);
+        pm.b[0] = b;
+        sp.b8[0] = b + 8;
+        sp.active[0] = active;
+    }
+    const TokT *hv_vec = static_cast<const TokT *>(args.hv);
+    OutT *__restrict__ out = static_cast<OutT *>(args.out);
+    const unsigned long long group_lanes = (KP == 64 ? ~0ull : ((1ull << KP) - 1ull)) << (g * KP);
+    const int64_t n_items = (args.n_sets + G - 1) / G;
+    for (int64_t item = (int64_t)blockIdx.x * 4 + wave; item < n_items; item += (int64_t)gridDim.x * 4) {
+        const int64_t set = item * G + g;  // per lane group
+        const bool has = set < args.n_sets;
+        int64_t beg = 0, end = 0;
+        if (has) {
+            beg = args.offsets ? args.offsets[set] : set * args.fixed_len;
+            end = args.offsets ? args.offsets[set + 1] : beg + args.fixed_len;
+        }
+        uint32_t res[1] = {kMaxHash};
+        bool fail = false;
+        for (int64_t boff = 0; __any(beg + boff < end); boff += kBlockRows * kRowTokens) {
+            const int64_t blk = beg + boff;
+            const int nb = (int)max((int64_t)0, min((int64_t)(kBlockRows * kRowTokens), end - blk));  // my set's tokens in this block
+            // the G tiles, filled by the whole wave one after the other: lane l carries tokens 4l .. 4l+3
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const int jnb = __builtin_amdgcn_readlane(nb, j * KP);
+                if (jnb == 0) continue;  // wave-uniform
+                const uint32_t blo = __builtin_amdgcn_readlane((int)(uint32_t)blk, j * KP);
+                const uint32_t bhi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)blk >> 32), j * KP);
+                const int64_t jblk = (int64_t)(((uint64_t)bhi << 32) | blo);
+                uint64_t t[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t[i] = 4 * lane + i < jnb ? (uint64_t)hv_vec[jblk + 4 * lane + i] : 0;
+                uint4 *dst = reinterpret_cast<uint4 *>(tiles + j * kStageWordsPerWave + (lane >> 2) * STRIDE + (lane & 3) * 8);
+                dst[0] = uint4{(uint32_t)t[0], (uint32_t)(t[0] >> 32), (uint32_t)t[1], (uint32_t)(t[1] >> 32)};
+                dst[1] = uint4{(uint32_t)t[2], (uint32_t)(t[2] >> 32), (uint32_t)t[3], (uint32_t)(t[3] >> 32)};
+            }
+            // (LDS operations of one wave complete in order: the tiles are written before they are read below)
+            const int nrows = nb >> 4, rest = nb & 15;
+            Two rows[1];
+            for (int r = 0; r < kBlockRows; ++r) {
+                if (!__any(r < nrows)) break;
+                if (r < nrows) {
+                    const uint32_t *rowp = my_tile + r * STRIDE;
+                    uint32_t row = kMaxHash;
+#pragma unroll
+                    for (int c = 0; c < kRowTokens; c += 2) {
+                        const uint32_t k0 = sieve_key(rowp[2 * c], sp.a_lo[0], sp.b8[0]);
+                        const uint32_t k1 = sieve_key(rowp[2 * c + 2], sp.a_lo[0], sp.b8[0]);
+                        row = c == 0 ? min(k0, k1) : umin3(row, k0, k1);
+                    }
+                    rows[0].add(tag16(row, (uint32_t)r));
+                }
+            }
+            if (__any(rest > 0)) {  // partial last rows (row index nrows <= 15: a full tile has no rest)
+                uint32_t row = kMaxHash;
+                const uint32_t *rowp = my_tile + nrows * STRIDE;
+                for (int c = 0; c < kRowTokens - 1; ++c) {
+                    if (!__any(c < rest)) break;
+                    if (c < rest) row = min(row, sieve_key(rowp[2 * c], sp.a_lo[0], sp.b8[0]));
+                }
+                if (rest > 0) rows[0].add(tag16(row, (uint32_t)nrows));
+            }
+            if (nb > 0) fail |= finish_block<1, STRIDE, 2, true>(rows, my_tile, pm, sp, res, (uint32_t)nrows, (uint32_t)rest);
+        }
+        const bool group_failed = (__ballot(fail && active) & group_lanes) != 0;
+        if (has && k == 0) args.redo[set] = group_failed ? 1 : 0;
+        if (has && active && !group_failed) {
+            uint64_t v;
+            if (args.init) {
+                const uint64_t iv = args.init[set * args.init_stride + k];
+                v = end > beg ? (uint64_t)min((iv >> 32) ? kMaxHash : (uint32_t)iv, res[0]) : iv;  // empty set: state untouched
+            } else {
+                v = end > beg ? res[0] : kMaxHash;
+            }
+            if (sizeof(OutT) == 4) v = v > kMaxHash ? kMaxHash : v;
+            out[set * args.num_perm + k] = (OutT)v;
+        }
+    }
+}
+
 // ---- kernel B: few long sets, split over waves, combined with atomic min ---------------------
 // out must already hold the initial state (init or 2^32-1).  grid.x = token slices of `slice`
 // tokens over the flat token array; a slice may span several sets.
@@ -1113,6 +1218,19 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_
             sieve_args.sieve_hint = ctx->d_work;
             const BulkArgs &args_s = sieve_args;
             const bool plain = !args.init && !args.stats && args.alias_mask < 0;
+            // short signatures: several sets per wave (kernel C) instead of a wave with most of its lanes idle
+            const bool packed = P == 1 && args.num_perm <= 32 && !args.stats && args.alias_mask < 0 && ctx->opt_minhash_packed != 1;
+            if (packed) {
+                const int kp = args.num_perm <= 8 ? 8 : args.num_perm <= 16 ? 16 : 32;
+                const int64_t items = (args.n_sets + 64 / kp - 1) / (64 / kp);
+                dim3 pgrid((unsigned)std::max<int64_t>(1, std::min<int64_t>((items + 3) / 4, max_blocks)), 1u);
+                if (kp == 8)
+                    hipLaunchKernelGGL((minhash_packed_kernel<8, TokT, OutT>), pgrid, dim3(256), 0, ctx->stream, args_s);
+                else if (kp == 16)
+                    hipLaunchKernelGGL((minhash_packed_kernel<16, TokT, OutT>), pgrid, dim3(256), 0, ctx->stream, args_s);
+                else
+                    hipLaunchKernelGGL((minhash_packed_kernel<32, TokT, OutT>), pgrid, dim3(256), 0, ctx->stream, args_s);
+            } else
             if (plain && !args.offsets && args.fixed_len % kRowTokens == 0)  // whole 16-token rows: no tail code in the kernel
                 hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN_FIXED_ROWS>), grid, dim3(256), 0, ctx->stream, args_s);
             else if (plain && !args.offsets)

@@ -438,3 +438,39 @@ def test_bbit_jaccard_pairs_on_the_device(ctx, k):
         y = bBitMinHash(MinHash(num_perm=k, hashvalues=sig[j]), 2, 0.25)
         assert e == x.jaccard(y)
     assert ctx.bbit_jaccard_pairs(pack_matrix(sig, 1, gpu_mode="always"), k, 1, np.empty((0, 2), np.int64)).size == 0
+
+
+# ------------------------------------------------------------------ several sets per wave (num_perm <= 32)
+@pytest.mark.parametrize("k", [1, 5, 8, 9, 16, 17, 31, 32])
+def test_packed_kernel_for_short_signatures(ctx, k):
+    """num_perm <= 32 runs kernel C (64 / KP sets per wave, tokens from per-group LDS tiles): against the C oracle and
+    against the one-set-per-wave path, on ragged sets (empty, shorter than a row, several 256-token blocks), with an
+    initial state, uint32 tokens, uint32 output, and a set count that is no multiple of the sets per wave."""
+    rng = np.random.RandomState(100 + k)
+    n = 4099
+    lens = rng.randint(0, 700, size=n)
+    lens[:8] = [0, 1, 15, 16, 17, 255, 256, 257]
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    hv = rng.randint(0, 2**32, int(offsets[-1]), dtype=np.uint64)
+    wide = rng.random_sample(hv.size) < 0.01
+    hv[wide] = rng.randint(0, 2**64, int(wide.sum()), dtype=np.uint64)
+    hv[offsets[20] : offsets[20] + 5] = hv[offsets[20]]          # repeated tokens: proofs fail, the set goes to the dedup launch
+    a, b = O.np_init_permutations(k, 3)
+    init = rng.randint(0, 2**32, (n, k), dtype=np.uint64)
+    init[3, 0] = 2**40                                            # survives only where nothing smaller arrives
+    want = O.c_minhash_bulk(hv, offsets, a, b)
+    want_init = O.c_minhash_bulk(hv, offsets, a, b, init)
+    for packed_off in (0, 1):
+        ctx.set_option("minhash.packed", packed_off)
+        ctx.set_option("minhash.split", 1)
+        try:
+            assert np.array_equal(ctx.minhash_bulk((a, b), hv, offsets, 0, n), want), packed_off
+            assert np.array_equal(ctx.minhash_bulk((a, b), hv, offsets, 0, n, init), want_init), packed_off
+            narrow = hv & np.uint64(0xFFFFFFFF)
+            got32 = ctx.minhash_bulk((a, b), narrow.astype(np.uint32), offsets, 0, n, out_dtype=np.uint32)
+            assert np.array_equal(got32.astype(np.uint64), O.c_minhash_bulk(narrow, offsets, a, b)), packed_off
+            dense = rng.randint(0, 2**32, (1001, 48), dtype=np.uint64)
+            assert np.array_equal(ctx.minhash_bulk((a, b), dense.reshape(-1), None, 48, 1001), O.c_minhash_bulk_dense(dense, a, b)), packed_off
+        finally:
+            ctx.set_option("minhash.packed", 0)
+            ctx.set_option("minhash.split", 0)
