@@ -1032,9 +1032,26 @@ __global__ __launch_bounds__(256) void minhash_packed_kernel(const BulkArgs args
                 const uint32_t blo = __builtin_amdgcn_readlane((int)(uint32_t)blk, j * KP);
                 const uint32_t bhi = __builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)blk >> 32), j * KP);
                 const int64_t jblk = (int64_t)(((uint64_t)bhi << 32) | blo);
-                uint64_t t[4];
+                uint64_t t[4] = {0, 0, 0, 0};
+                if (4 * lane + 3 < jnb) {  // the usual case: all four in range, one or two wide loads
+                    if constexpr (sizeof(TokT) == 8) {
+                        const uint4 *src = reinterpret_cast<const uint4 *>(hv_vec + jblk + 4 * lane);
+                        const uint4 lo = src[0], hi = src[1];
+                        t[0] = ((uint64_t)lo.y << 32) | lo.x;
+                        t[1] = ((uint64_t)lo.w << 32) | lo.z;
+                        t[2] = ((uint64_t)hi.y << 32) | hi.x;
+                        t[3] = ((uint64_t)hi.w << 32) | hi.z;
+                    } else {
+                        const uint4 v = *reinterpret_cast<const uint4 *>(hv_vec + jblk + 4 * lane);
+                        t[0] = v.x;
+                        t[1] = v.y;
+                        t[2] = v.z;
+                        t[3] = v.w;
+                    }
+                } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) t[i] = 4 * lane + i < jnb ? (uint64_t)hv_vec[jblk + 4 * lane + i] : 0;
+                    for (int i = 0; i < 4; ++i) t[i] = 4 * lane + i < jnb ? (uint64_t)hv_vec[jblk + 4 * lane + i] : 0;
+                }
                 uint4 *dst = reinterpret_cast<uint4 *>(tiles + j * kStageWordsPerWave + (lane >> 2) * STRIDE + (lane & 3) * 8);
                 dst[0] = uint4{(uint32_t)t[0], (uint32_t)(t[0] >> 32), (uint32_t)t[1], (uint32_t)(t[1] >> 32)};
                 dst[1] = uint4{(uint32_t)t[2], (uint32_t)(t[2] >> 32), (uint32_t)t[3], (uint32_t)(t[3] >> 32)};
@@ -1042,19 +1059,22 @@ __global__ __launch_bounds__(256) void minhash_packed_kernel(const BulkArgs args
             // (LDS operations of one wave complete in order: the tiles are written before they are read below)
             const int nrows = nb >> 4, rest = nb & 15;
             Two rows[1];
-            for (int r = 0; r < kBlockRows; ++r) {
-                if (!__any(r < nrows)) break;
-                if (r < nrows) {
-                    const uint32_t *rowp = my_tile + r * STRIDE;
-                    uint32_t row = kMaxHash;
+            // rows of every group in lock step up to the longest set of the wave: no divergent control flow around
+            // the LDS reads (a group that has run out of rows reads stale cells and its row is dropped by a select)
+            int max_rows = 0;
 #pragma unroll
-                    for (int c = 0; c < kRowTokens; c += 2) {
-                        const uint32_t k0 = sieve_key(rowp[2 * c], sp.a_lo[0], sp.b8[0]);
-                        const uint32_t k1 = sieve_key(rowp[2 * c + 2], sp.a_lo[0], sp.b8[0]);
-                        row = c == 0 ? min(k0, k1) : umin3(row, k0, k1);
-                    }
-                    rows[0].add(tag16(row, (uint32_t)r));
+            for (int j = 0; j < G; ++j) max_rows = max(max_rows, __builtin_amdgcn_readlane(nrows, j * KP));
+#pragma unroll 2
+            for (int r = 0; r < max_rows; ++r) {
+                const uint32_t *rowp = my_tile + r * STRIDE;
+                uint32_t row = kMaxHash;
+#pragma unroll
+                for (int c = 0; c < kRowTokens; c += 2) {
+                    const uint32_t k0 = sieve_key(rowp[2 * c], sp.a_lo[0], sp.b8[0]);
+                    const uint32_t k1 = sieve_key(rowp[2 * c + 2], sp.a_lo[0], sp.b8[0]);
+                    row = c == 0 ? min(k0, k1) : umin3(row, k0, k1);
                 }
+                rows[0].add(r < nrows ? tag16(row, (uint32_t)r) : kMaxHash);
             }
             if (__any(rest > 0)) {  // partial last rows (row index nrows <= 15: a full tile has no rest)
                 uint32_t row = kMaxHash;
