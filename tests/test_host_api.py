@@ -469,3 +469,34 @@ def test_bbit_jaccard_pairs_matches_the_object_method():
         jaccard_pairs(pack_matrix(sig, 1, gpu_mode="disable"), pairs, 100, 2, gpu_mode="disable")  # blocks of another b
     with pytest.raises(ValueError):
         jaccard_pairs(pack_matrix(sig, 1, gpu_mode="disable"), [[0, 40]], 100, 1, gpu_mode="disable")
+
+
+def test_bulk_signatures_out_dtype_and_uint32_tokens_on_the_numpy_path():
+    """out_dtype / uint32 token arrays are host-API additions (not in the reference); on gpu_mode='disable' they are
+    plain casts of the reference's arithmetic (minhash.py:293-297) and must agree with the uint64 result."""
+    rng = np.random.RandomState(4)
+    tok = rng.randint(0, 2**32, (50, 20), dtype=np.uint64)
+    want = MinHash.bulk_signatures(tok, num_perm=32, seed=2, hashfunc=prehashed, gpu_mode="disable")
+    assert want.dtype == np.uint64
+    got32 = MinHash.bulk_signatures(tok.astype(np.uint32), num_perm=32, seed=2, hashfunc=prehashed, gpu_mode="disable", out_dtype=np.uint32)
+    assert got32.dtype == np.uint32 and np.array_equal(got32.astype(np.uint64), want)
+    csr = (tok.reshape(-1), np.arange(0, 1001, 20))
+    assert np.array_equal(MinHash.bulk_signatures(csr, num_perm=32, seed=2, hashfunc=prehashed, gpu_mode="disable", out_dtype=np.uint32), got32)
+    sets = [[b"a", b"bb"], [], [b"ccc"]]
+    s32 = MinHash.bulk_signatures(sets, num_perm=8, seed=1, gpu_mode="disable", out_dtype=np.uint32)
+    assert s32.dtype == np.uint32 and np.array_equal(s32.astype(np.uint64), MinHash.bulk_signatures(sets, num_perm=8, seed=1, gpu_mode="disable"))
+    assert MinHash.bulk_signatures([], num_perm=8, gpu_mode="disable", out_dtype=np.uint32).shape == (0, 8)
+    with pytest.raises(ValueError):
+        MinHash.bulk_signatures(tok, num_perm=8, hashfunc=prehashed, gpu_mode="disable", out_dtype=np.float32)
+    big = MinHash(num_perm=8, seed=1, hashfunc=prehashed, hashvalues=np.full(8, 2**40, dtype=np.uint64))
+    with pytest.raises(ValueError):
+        MinHash.bulk_signatures(tok, num_perm=8, seed=1, hashfunc=prehashed, gpu_mode="disable", out_dtype=np.uint32, hashvalues=big.hashvalues)
+
+
+def test_serialize_matrix_rejects_values_that_do_not_fit_the_format():
+    sig = np.array([[1, 2, 2**32]], dtype=np.uint64)
+    with pytest.raises(struct.error):
+        serialize_matrix(sig, 1, gpu_mode="disable")
+    m = MinHash(num_perm=3, seed=1, hashvalues=sig[0])
+    with pytest.raises(struct.error):  # what the object method does for the same value (lean_minhash.py:174-175)
+        LeanMinHash(m).serialize(bytearray(LeanMinHash(m).bytesize()))
