@@ -12,7 +12,7 @@ FLAGS=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contr
 pids=()
 for src in mhx_api minhash_kernels weighted_kernels pack_kernels sha1_kernels lsh_kernels comm; do
   if [[ ! -f "${OBJ}/${src}.o" || "${HERE}/${src}.hip" -nt "${OBJ}/${src}.o" \
-        || "${HERE}/mhx_internal.h" -nt "${OBJ}/${src}.o" || "${HERE}/../../include/mhx.h" -nt "${OBJ}/${src}.o" ]]; then
+        || "${HERE}/mhx_internal.h" -nt "${OBJ}/${src}.o" || "${HERE}/band_digest.h" -nt "${OBJ}/${src}.o" || "${HERE}/../../include/mhx.h" -nt "${OBJ}/${src}.o" ]]; then
     "${HIPCC}" "${FLAGS[@]}" -c "${HERE}/${src}.hip" -o "${OBJ}/${src}.o" &
     pids+=($!)
   fi

@@ -13,6 +13,7 @@
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_select.hpp>
 
+#include "band_digest.h"
 #include "mhx_internal.h"
 
 namespace mhx {
@@ -52,6 +53,53 @@ __global__ __launch_bounds__(256) void gather_digests_kernel(const uint64_t *__r
                                                              uint64_t *__restrict__ sorted_digests) {
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x)
         sorted_digests[p] = digests[(int64_t)rows[p] * bands + p / n];
+}
+
+// ---- the whole digest rides through the sort (n <= 2^(32 - band_bits)) --------------------------------
+// The radix sort orders by the low sort_bits of a 64-bit key and moves the whole key and a 32-bit value every pass.
+// The key's upper 64 - sort_bits bits and the value's bits above the row number are free luggage: the digest bits
+// below the sorted prefix go there (the next 64 - sort_bits bits into the key, the last band_bits bits into the value
+// under the row), so that after the sort the full digests are rebuilt from the sorted keys and values in one
+// streaming pass -- instead of gathering them from the unsorted matrix by row (40 million random 8-byte reads: 0.8 ms
+// of the 3.2 ms of a 32 x 1.25M sort).
+__device__ __forceinline__ uint64_t low_bits(uint64_t x, int bits) { return bits >= 64 ? x : (bits <= 0 ? 0 : x & ((1ull << bits) - 1ull)); }
+
+// (fused with the digests: the [n, bands] digest matrix is never written or read)
+template <typename SigT>
+__global__ __launch_bounds__(256) void band_keys_with_luggage_kernel(const SigT *__restrict__ sig, int32_t k, int32_t r, int64_t n, int32_t bands,
+                                                                     int band_bits, int sort_bits, uint64_t *__restrict__ keys,
+                                                                     uint32_t *__restrict__ vals) {
+    const int64_t total = n * (int64_t)bands;
+    const int d_bits = sort_bits - band_bits;   // digest bits inside the sorted prefix
+    const int h_bits = 64 - sort_bits;          // digest bits that ride in the key's upper part
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = idx / bands;
+        const uint64_t dg = band_digest_of<SigT>(sig, row, (int)(idx - row * bands), k, r);
+        const uint64_t prefix = prefix_key(dg, (uint32_t)(idx - row * bands), band_bits, sort_bits);
+        const uint64_t hi = h_bits > 0 ? low_bits(dg >> band_bits, h_bits) : 0;  // bits [band_bits, band_bits + h_bits)
+        keys[idx] = prefix | (h_bits > 0 ? hi << sort_bits : 0);
+        vals[idx] = ((uint32_t)row << band_bits) | (uint32_t)low_bits(dg, band_bits);
+        (void)d_bits;
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_luggage_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+                                                             int64_t total, int band_bits, int sort_bits,
+                                                             uint64_t *__restrict__ sorted_keys_only, uint64_t *__restrict__ sorted_digests,
+                                                             uint32_t *__restrict__ sorted_rows) {
+    const int d_bits = sort_bits - band_bits, h_bits = 64 - sort_bits;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t key = keys[p];
+        const uint32_t val = vals[p];
+        const uint64_t top = low_bits(key, d_bits);                                  // digest bits [64 - d_bits, 64)
+        const uint64_t mid = h_bits > 0 ? key >> sort_bits : 0;                      // digest bits [band_bits, 64 - d_bits)
+        uint64_t dg = low_bits(val, band_bits) | (mid << band_bits);
+        if (d_bits > 0) dg |= top << (64 - d_bits);
+        sorted_digests[p] = dg;
+        sorted_rows[p] = val >> band_bits;
+        sorted_keys_only[p] = low_bits(key, sort_bits);  // what the clean-up kernels compare: the sorted prefix alone
+    }
 }
 
 // Runs of equal sort keys whose full digests are NOT all equal (different digests sharing the sorted
@@ -306,12 +354,12 @@ int launch_lsh_sort_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_
     int band_bits = 1;
     while (((int64_t)1 << band_bits) < bands) ++band_bits;
     if (band_bits > 16) return fail(MHX_ERR_UNSUPPORTED, "more than 65536 bands");
-    // bits handed to the radix sort: band + a digest prefix of about 2 log2(n) - 8 bits, rounded up to whole
-    // 8-bit passes -- at most ~2^7 pairs of different digests per band then share a prefix and are left to the
-    // clean-up kernel (n = 10^6, 32 bands: 40 bits, 2.5 ms; 48 bits 2.8 ms; 64 bits 3.4 ms; 24 bits 2.9 ms)
+    // bits handed to the radix sort: band + a digest prefix of log2(n) + 5 bits, rounded up to whole 8-bit passes -- about
+    // n/64 elements per band then share a prefix with another digest and are left to the clean-up kernels, which is
+    // cheaper than a fifth pass over all of them (32 bands x 1.25M rows: 32 bits 2.32 ms, 40 bits 2.64 ms, 24 bits 3.36 ms)
     int log_n = 1;
     while (((int64_t)1 << log_n) < n) ++log_n;
-    const int auto_bits = std::min(64, (band_bits + std::max(16, 2 * log_n - 8) + 7) / 8 * 8);
+    const int auto_bits = std::min(64, (band_bits + std::max(12, log_n + 5) + 7) / 8 * 8);
     const int sort_bits = (int)std::min<int64_t>(64, std::max<int64_t>(band_bits, ctx->opt_lsh_sort_bits > 0 ? ctx->opt_lsh_sort_bits : auto_bits));
     size_t tmp_bytes = 0;
     hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
@@ -326,15 +374,33 @@ int launch_lsh_sort_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_
     uint32_t *d_rows = (uint32_t *)((char *)ctx->scratch[3] + 3 * dig_bytes);
     uint8_t *d_mixed = (uint8_t *)((char *)ctx->scratch[3] + 3 * dig_bytes + row_bytes);
     void *d_tmp = (char *)ctx->scratch[3] + 3 * dig_bytes + row_bytes + mark_bytes;
-    if (int rc = launch_band_digests(ctx, d_sig, sig_dtype, n, k, bands, r, d_dig)) return rc;
     const dim3 grid(grid_for(ctx, total));
-    hipLaunchKernelGGL(band_keys_for_sort_kernel, grid, dim3(256), 0, ctx->stream, d_dig, n, bands, band_bits, sort_bits, d_keys, d_rows);
-    MHX_HIP_CHECK(hipGetLastError());
-    e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, (const uint64_t *)d_keys, d_keys_sorted, (const uint32_t *)d_rows,
-                                  d_sorted_rows, (size_t)total, 0, sort_bits, ctx->stream);
-    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
-    hipLaunchKernelGGL(gather_digests_kernel, grid, dim3(256), 0, ctx->stream, d_dig, d_sorted_rows, n, bands, total,
-                       d_sorted_digests);
+    const bool luggage = n <= ((int64_t)1 << (32 - band_bits)) && ctx->opt_lsh_gather != 1;  // the row and band_bits digest bits fit the 32-bit value
+    if (luggage) {
+        // the digest region receives the sorted values, d_sorted_rows the final rows
+        if (sig_dtype == MHX_U32)
+            hipLaunchKernelGGL(band_keys_with_luggage_kernel<uint32_t>, dim3(grid_for(ctx, total) ), dim3(256), 0, ctx->stream, (const uint32_t *)d_sig, k, r, n,
+                               bands, band_bits, sort_bits, d_keys, d_rows);
+        else
+            hipLaunchKernelGGL(band_keys_with_luggage_kernel<uint64_t>, dim3(grid_for(ctx, total)), dim3(256), 0, ctx->stream, (const uint64_t *)d_sig, k, r, n,
+                               bands, band_bits, sort_bits, d_keys, d_rows);
+        MHX_HIP_CHECK(hipGetLastError());
+        uint32_t *d_vals_sorted = reinterpret_cast<uint32_t *>(d_dig);
+        e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, (const uint64_t *)d_keys, d_keys_sorted, (const uint32_t *)d_rows,
+                                      d_vals_sorted, (size_t)total, 0, sort_bits, ctx->stream);
+        if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(unpack_luggage_kernel, grid, dim3(256), 0, ctx->stream, d_keys_sorted, d_vals_sorted, total, band_bits, sort_bits,
+                           d_keys_sorted, d_sorted_digests, d_sorted_rows);
+    } else {
+        if (int rc = launch_band_digests(ctx, d_sig, sig_dtype, n, k, bands, r, d_dig)) return rc;
+        hipLaunchKernelGGL(band_keys_for_sort_kernel, grid, dim3(256), 0, ctx->stream, d_dig, n, bands, band_bits, sort_bits, d_keys, d_rows);
+        MHX_HIP_CHECK(hipGetLastError());
+        e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, (const uint64_t *)d_keys, d_keys_sorted, (const uint32_t *)d_rows,
+                                      d_sorted_rows, (size_t)total, 0, sort_bits, ctx->stream);
+        if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
+        hipLaunchKernelGGL(gather_digests_kernel, grid, dim3(256), 0, ctx->stream, d_dig, d_sorted_rows, n, bands, total,
+                           d_sorted_digests);
+    }
     MHX_HIP_CHECK(hipMemsetAsync(d_mixed, 0, (size_t)total, ctx->stream));
     hipLaunchKernelGGL(mark_mixed_runs_kernel, grid, dim3(256), 0, ctx->stream, d_keys_sorted, d_sorted_digests, n, total, d_mixed);
     hipLaunchKernelGGL(order_mixed_runs_kernel, grid, dim3(256), 0, ctx->stream, d_keys_sorted, d_mixed, n, total,

@@ -60,6 +60,7 @@ struct mhx_ctx {
     int64_t opt_minhash_prefetch = 1; // warm L2 with the next set's tokens (vector load per set)
     int64_t opt_minhash_alias = -1; // profiling only: >= 0 makes set i read the tokens of set (i & mask)
     int64_t opt_weighted_path = 0;  // 0 auto (reciprocal-multiply quotient + row blocks), 1 IEEE division for every element
+    int64_t opt_lsh_gather = 0;     // mhx_lsh_sort_bands: 1 = gather the full digests after the sort (the fallback path) even when they could ride along
     int64_t opt_lsh_sort_bits = 0;  // mhx_lsh_sort_bands: bits of (band, digest) the radix sort orders by; 0 = from n
     int64_t opt_host_chunk_bytes = 0;  // mhx_minhash_bulk: bytes per pipelined piece; 0 auto (96 MiB, inputs > 256 MiB), < 0 never pipeline
 

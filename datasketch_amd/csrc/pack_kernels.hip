@@ -1,6 +1,7 @@
 // pack_kernels.hip -- HBM-bound re-packing of signature matrices for downstream consumers:
 // b-bit packing (bBitMinHash), MinHashLSH band keys (byte-swapped copy) and the LeanMinHash
 // wire format.  One wave walks whole rows; lanes read consecutive uint64 values (coalesced).
+#include "band_digest.h"
 #include "mhx_internal.h"
 
 namespace mhx {
@@ -112,59 +113,11 @@ __global__ __launch_bounds__(256) void lean_serialize_kernel(const uint64_t *__r
 template <typename SigT>
 __global__ __launch_bounds__(256) void band_digest_kernel(const SigT *__restrict__ sig, int64_t n, int32_t k,
                                                           int32_t bands, int32_t r, uint64_t *__restrict__ out) {
-    constexpr uint64_t kPrime = 0x100000001b3ull;
-    constexpr uint64_t kPrime4 = kPrime * kPrime * kPrime * kPrime;  // four zero bytes: h ^= 0 leaves h, so h *= prime^4
     const int64_t total = n * (int64_t)bands;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = idx / bands;
-        const int band = (int)(idx - row * bands);
-        const SigT *src = sig + row * k + (int64_t)band * r;
-        uint64_t h = 0xcbf29ce484222325ull;
-        const auto absorb = [&](uint64_t v) {
-            const uint32_t hi = (uint32_t)(v >> 32), lo = (uint32_t)v;
-            if (hi == 0) {  // every real hashvalue: the 4 leading key bytes are zero
-                h *= kPrime4;
-            } else {
-#pragma unroll
-                for (int byte = 3; byte >= 0; --byte) {
-                    h ^= (hi >> (8 * byte)) & 0xFFu;
-                    h *= kPrime;
-                }
-            }
-#pragma unroll
-            for (int byte = 3; byte >= 0; --byte) {  // big-endian byte order of the key
-                h ^= (lo >> (8 * byte)) & 0xFFu;
-                h *= kPrime;
-            }
-        };
-        if constexpr (sizeof(SigT) == 4) {
-            // uint32 signatures (the all-gather's wire format): the key bytes are those of the widened value
-            if (((r | k) & 3) == 0 && (reinterpret_cast<uintptr_t>(sig) & 15) == 0) {
-                const uint4 *src4 = reinterpret_cast<const uint4 *>(src);
-                for (int c = 0; c < r / 4; ++c) {
-                    const uint4 v = src4[c];
-                    absorb(v.x);
-                    absorb(v.y);
-                    absorb(v.z);
-                    absorb(v.w);
-                }
-            } else {
-                for (int c = 0; c < r; ++c) absorb(src[c]);
-            }
-        } else if (((r | k) & 1) == 0 && (reinterpret_cast<uintptr_t>(sig) & 15) == 0) {
-            // 16-byte loads: a lane's band is r*8 contiguous bytes, but neighbouring lanes are r*8 bytes
-            // apart, so every load instruction touches many lines -- fewer, wider loads it is
-            const ulonglong2 *src2 = reinterpret_cast<const ulonglong2 *>(src);
-            for (int c = 0; c < r / 2; ++c) {
-                const ulonglong2 v = src2[c];
-                absorb(v.x);
-                absorb(v.y);
-            }
-        } else {
-            for (int c = 0; c < r; ++c) absorb((uint64_t)src[c]);
-        }
-        out[idx] = h;
+        out[idx] = band_digest_of<SigT>(sig, row, (int)(idx - row * bands), k, r);
     }
 }
 
