@@ -66,12 +66,15 @@ MHX_API int mhx_ctx_synchronize(mhx_ctx *ctx);
 MHX_API int mhx_ctx_release_scratch(mhx_ctx *ctx);
 /* name: caller buffer (may be NULL); cus: compute units; hbm_bytes: total device memory */
 MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus, int64_t *hbm_bytes);
-/* Tuning / test knobs: ("minhash.path", 0 = auto: sieve with full-evaluation fallback,
+/* Tuning / test knobs: ("minhash.path", 0 = auto: sieve with dedup / pairwise fallback launches,
  * 1 = exact fold for every pair, 2 = fast fold with exact redo), ("minhash.split", 0 auto,
- * 1 wave per set, 2 split sets over waves), ("blocks_per_cu", n), ("minhash.prefetch", 0/1),
+ * 1 wave per set, 2 split sets over waves), ("minhash.packed", 0 auto: several sets per wave when
+ * num_perm <= 32, 1 = always one set per wave), ("blocks_per_cu", n), ("minhash.prefetch", 0/1),
+ * ("minhash.alias", profiling only: >= 0 makes set i read the tokens of set i & mask),
  * ("weighted.path", 0 auto, 1 IEEE division for every element), ("host.chunk_bytes", see
  * mhx_minhash_bulk), ("lsh.sort_bits", bits of (band, digest) mhx_lsh_sort_bands hands to the radix sort,
- * 0 = chosen from n; the order is exact for any value, fewer bits leave more to the clean-up pass). */
+ * 0 = chosen from n; the order is exact for any value, fewer bits leave more to the clean-up pass),
+ * ("lsh.gather", 1 = gather the full digests after the sort instead of letting them ride through it). */
 MHX_API int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value);
 /* Kernel event counters since the last call (synchronises the stream, then resets them):
  *   out[0] sets the sieve launch left to the full launch (failed proof, or skipped by the back-off),
