@@ -66,6 +66,9 @@ _PROTOTYPES = {
     "mhx_weighted_minhash_many_dense_dev": [_vp, _vp, _int, _i64, _vp, _vp],
     "mhx_weighted_minhash_many_dev": [_vp, _vp, _vp, _vp, _int, _i64, _i64, _vp, _vp],
     "mhx_weighted_logf": [_vp, _vp, _i64, _vp],
+    "mhx_weighted_dense_begin": [_vp, _int, _i64, ctypes.POINTER(_vp)],
+    "mhx_weighted_dense_feed": [_vp, _vp, _i64, _vp, _vp],
+    "mhx_weighted_dense_end": [_vp],
     "mhx_bbit_num_blocks": [_i32, _i32, ctypes.POINTER(_i32)],
     "mhx_bbit_pack_dev": [_vp, _vp, _i64, _i32, _i32, _vp],
     "mhx_bbit_pack": [_vp, _vp, _i64, _i32, _i32, _vp],
@@ -194,6 +197,56 @@ def gpu_available() -> bool:
 
 def _ptr(arr: Optional[np.ndarray]):
     return None if arr is None else arr.ctypes.data
+
+
+class WeightedFeed:
+    """``with ctx.weighted_dense_feed(...) as feed: feed.feed(x_piece, out_piece, nonempty_piece)`` -- the upload of a
+    piece overlaps the evaluation of the one before and the download of the one before that.  ``x_piece`` may be
+    overwritten as soon as ``feed`` returns; ``out_piece`` / ``nonempty_piece`` are complete after the next ``feed`` or
+    on leaving the ``with`` block."""
+
+    def __init__(self, ctx: "Context", h: int, sample_size: int, dim: int, values_are_logs: bool, piece_rows: int):
+        self.ctx, self.s, self.dim, self.piece_rows = ctx, int(sample_size), int(dim), int(piece_rows)
+        p = _vp()
+        check(ctx.lib.mhx_weighted_dense_begin(h, int(bool(values_are_logs)), self.piece_rows, ctypes.byref(p)))
+        self.handle = p.value
+
+    def feed(self, x: np.ndarray, out: np.ndarray, nonempty: np.ndarray) -> None:
+        n = x.shape[0]
+        if x.dtype != np.float32 or x.ndim != 2 or x.shape[1] != self.dim or not x.flags.c_contiguous:
+            raise ValueError("x must be a C-contiguous float32 array of shape (rows, dim)")
+        if out.shape != (n, self.s, 2) or out.dtype != np.int64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous int64 array of shape (rows, sample_size, 2)")
+        if nonempty.shape != (n,) or nonempty.dtype != np.uint8 or not nonempty.flags.c_contiguous:
+            raise ValueError("nonempty must be a C-contiguous uint8 array of shape (rows,)")
+        if self.handle is None:
+            raise MhxError("the feed has ended")
+        check(self.ctx.lib.mhx_weighted_dense_feed(self.handle, _ptr(x), n, _ptr(out), _ptr(nonempty)))
+
+    def end(self) -> None:
+        h, self.handle = self.handle, None
+        if h is not None:
+            check(self.ctx.lib.mhx_weighted_dense_end(h))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, exc_type, exc, tb):
+        if exc_type is None:
+            self.end()
+        else:  # release the buffers, keep the original exception
+            h, self.handle = self.handle, None
+            if h is not None:
+                self.ctx.lib.mhx_weighted_dense_end(h)
+        return False
+
+    def __del__(self):
+        try:
+            h, self.handle = self.handle, None
+            if h is not None:
+                self.ctx.lib.mhx_weighted_dense_end(h)
+        except Exception:
+            pass
 
 
 class DeviceBuffer:
@@ -492,6 +545,10 @@ class Context:
             raise ValueError("nonempty must be a C-contiguous uint8 array of shape (N,)")
         check(self.lib.mhx_weighted_minhash_many_dense(h, _ptr(x), int(bool(values_are_logs)), n, _ptr(out), _ptr(nonempty)))
         return out, nonempty.view(bool)
+
+    def weighted_dense_feed(self, h: int, sample_size: int, dim: int, values_are_logs: bool, piece_rows: int) -> "WeightedFeed":
+        """Dense rows in pieces (mhx_weighted_dense_begin/feed/end); use as a context manager."""
+        return WeightedFeed(self, h, sample_size, dim, values_are_logs, piece_rows)
 
     def weighted_logf(self, x: np.ndarray) -> np.ndarray:
         """The float32 log the device-log mode of the weighted path takes (mhx_weighted_logf)."""

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <system_error>
 #include <thread>
 #include <vector>
@@ -1255,6 +1256,134 @@ int mhx_weighted_minhash_many_dense_dev(mhx_wgen *gen, const float *d_x, int val
     return mhx::launch_weighted_dense(gen, d_x, values_are_logs, n_rows, d_out, d_nonempty);
 }
 
+}  // extern "C" (the feed's state and helpers are C++)
+
+// A dense weighted call in pieces: two device slots, so that the upload of piece i+1 (copy_in), the evaluation of
+// piece i (ctx->stream) and the download of piece i-1 (copy_out) run side by side.
+struct mhx_wfeed {
+    mhx_wgen *gen = nullptr;
+    int values_are_logs = 0;
+    int64_t piece_rows = 0;
+    float *d_x[2] = {nullptr, nullptr};
+    char *d_res[2] = {nullptr, nullptr};  // out int64[piece_rows, S, 2] | nonempty uint8[piece_rows]
+    size_t ne_off = 0;
+    hipEvent_t uploaded[2] = {nullptr, nullptr}, computed[2] = {nullptr, nullptr};
+    int64_t fed = 0;
+    // the piece fed last: evaluated (or being evaluated) on the device, results not yet on the host
+    int64_t *pend_out = nullptr;
+    uint8_t *pend_ne = nullptr;
+    int64_t pend_rows = 0;
+    int pend_slot = 0;
+};
+
+namespace {
+
+// bring the pending piece down (blocks until it is on the host)
+int feed_drain(mhx_wfeed *f) {
+    if (!f->pend_rows) return MHX_OK;
+    mhx_ctx *ctx = f->gen->ctx;
+    const int slot = f->pend_slot;
+    const size_t out_bytes = sizeof(int64_t) * 2 * (size_t)f->gen->sample_size * (size_t)f->pend_rows;
+    const int64_t rows = f->pend_rows;
+    f->pend_rows = 0;
+    MHX_HIP_CHECK(hipStreamWaitEvent(ctx->copy_out, f->computed[slot], 0));
+    MHX_HIP_CHECK(hipMemcpyAsync(f->pend_out, f->d_res[slot], out_bytes, hipMemcpyDeviceToHost, ctx->copy_out));
+    MHX_HIP_CHECK(hipMemcpyAsync(f->pend_ne, f->d_res[slot] + f->ne_off, (size_t)rows, hipMemcpyDeviceToHost, ctx->copy_out));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->copy_out));
+    return MHX_OK;
+}
+
+// rows per piece of a one-call dense evaluation: about 64 MiB of input + output, at least 4096 rows (fewer leave
+// CUs without a row block), whole row blocks of 8
+int64_t dense_piece_rows(const mhx_wgen *gen) {
+    const int64_t per_row = 4 * (int64_t)gen->dim + 16 * (int64_t)gen->sample_size;
+    return std::max<int64_t>(4096, ((64ll << 20) / per_row) & ~7ll);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mhx_weighted_dense_begin(mhx_wgen *gen, int values_are_logs, int64_t piece_rows, mhx_wfeed **feed) {
+    if (!gen) return fail(MHX_ERR_INVALID, "gen is NULL");
+    MHX_GUARD(gen->ctx);
+    MHX_REQUIRE(feed, "feed is NULL");
+    *feed = nullptr;
+    MHX_REQUIRE(piece_rows > 0, "piece_rows must be positive");
+    mhx_ctx *ctx = gen->ctx;
+    if (int rc = ctx->activate()) return rc;
+    if (int rc = ctx->ensure_copy_streams()) return rc;
+    mhx_wfeed *f = new (std::nothrow) mhx_wfeed();
+    if (!f) return fail(MHX_ERR_OOM, "out of host memory");
+    f->gen = gen;
+    f->values_are_logs = values_are_logs;
+    f->piece_rows = piece_rows;
+    const size_t x_bytes = sizeof(float) * (size_t)piece_rows * (size_t)gen->dim;
+    const size_t out_bytes = sizeof(int64_t) * 2 * (size_t)gen->sample_size * (size_t)piece_rows;
+    f->ne_off = (out_bytes + 255) & ~(size_t)255;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipMalloc(reinterpret_cast<void **>(&f->d_x[i]), x_bytes);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&f->d_res[i]), f->ne_off + (size_t)piece_rows);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&f->uploaded[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&f->computed[i], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        (void)mhx_weighted_dense_end(f);
+        return fail(e == hipErrorOutOfMemory ? MHX_ERR_OOM : MHX_ERR_HIP, "buffers for pieces of %lld rows: %s", (long long)piece_rows,
+                    hipGetErrorString(e));
+    }
+    *feed = f;
+    return MHX_OK;
+}
+
+int mhx_weighted_dense_feed(mhx_wfeed *f, const float *x, int64_t n_rows, int64_t *out, uint8_t *nonempty) {
+    if (!f) return fail(MHX_ERR_INVALID, "feed is NULL");
+    mhx_ctx *ctx = f->gen->ctx;
+    MHX_GUARD(ctx);
+    MHX_REQUIRE(n_rows >= 0 && n_rows <= f->piece_rows, "a piece holds at most %lld rows", (long long)f->piece_rows);
+    if (n_rows == 0) return MHX_OK;
+    MHX_REQUIRE(x && out && nonempty, "NULL host pointer");
+    if (int rc = ctx->activate()) return rc;
+    const int slot = (int)(f->fed & 1);
+    // the slot's input was read by the evaluation of the piece before last; its results came down during the last feed
+    if (f->fed >= 2) MHX_HIP_CHECK(hipEventSynchronize(f->computed[slot]));
+    const size_t x_bytes = sizeof(float) * (size_t)n_rows * (size_t)f->gen->dim;
+    MHX_HIP_CHECK(hipMemcpyAsync(f->d_x[slot], x, x_bytes, hipMemcpyHostToDevice, ctx->copy_in));
+    MHX_HIP_CHECK(hipEventRecord(f->uploaded[slot], ctx->copy_in));
+    MHX_HIP_CHECK(hipStreamWaitEvent(ctx->stream, f->uploaded[slot], 0));
+    if (int rc = mhx::launch_weighted_dense(f->gen, f->d_x[slot], f->values_are_logs, n_rows, reinterpret_cast<int64_t *>(f->d_res[slot]),
+                                            reinterpret_cast<uint8_t *>(f->d_res[slot] + f->ne_off)))
+        return rc;
+    MHX_HIP_CHECK(hipEventRecord(f->computed[slot], ctx->stream));
+    ++f->fed;
+    if (int rc = feed_drain(f)) return rc;  // the previous piece, while this one is evaluated
+    f->pend_out = out;
+    f->pend_ne = nonempty;
+    f->pend_rows = n_rows;
+    f->pend_slot = slot;
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->copy_in));  // a pinned x is copied asynchronously: it is free from here on
+    return MHX_OK;
+}
+
+int mhx_weighted_dense_end(mhx_wfeed *f) {
+    if (!f) return MHX_OK;
+    mhx_ctx *ctx = f->gen->ctx;
+    MHX_GUARD(ctx);
+    int rc = ctx->activate();
+    if (!rc) rc = feed_drain(f);
+    if (ctx->copy_in) (void)hipStreamSynchronize(ctx->copy_in);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 2; ++i) {
+        if (f->d_x[i]) (void)hipFree(f->d_x[i]);
+        if (f->d_res[i]) (void)hipFree(f->d_res[i]);
+        if (f->uploaded[i]) (void)hipEventDestroy(f->uploaded[i]);
+        if (f->computed[i]) (void)hipEventDestroy(f->computed[i]);
+    }
+    delete f;
+    return rc;
+}
+
 int mhx_weighted_minhash_many_dense(mhx_wgen *gen, const float *x, int values_are_logs, int64_t n_rows, int64_t *out,
                                     uint8_t *nonempty) {
     if (!gen) return fail(MHX_ERR_INVALID, "gen is NULL");
@@ -1264,6 +1393,19 @@ int mhx_weighted_minhash_many_dense(mhx_wgen *gen, const float *x, int values_ar
     MHX_REQUIRE(x && out && nonempty, "NULL host pointer");
     mhx_ctx *ctx = gen->ctx;
     if (int rc = ctx->activate()) return rc;
+    const int64_t piece = dense_piece_rows(gen);
+    if (n_rows >= 2 * piece && ctx->opt_host_chunk_bytes >= 0) {  // upload, evaluation and download side by side
+        mhx_wfeed *f = nullptr;
+        if (int rc = mhx_weighted_dense_begin(gen, values_are_logs, piece, &f)) return rc;
+        int rc = MHX_OK;
+        for (int64_t lo = 0; lo < n_rows && !rc; lo += piece) {
+            const int64_t rows = std::min(piece, n_rows - lo);
+            rc = mhx_weighted_dense_feed(f, x + (size_t)lo * (size_t)gen->dim, rows, out + (size_t)lo * 2 * (size_t)gen->sample_size,
+                                         nonempty + lo);
+        }
+        const int rc_end = mhx_weighted_dense_end(f);
+        return rc ? rc : rc_end;
+    }
     const size_t x_bytes = sizeof(float) * (size_t)n_rows * (size_t)gen->dim;
     const size_t out_bytes = sizeof(int64_t) * 2 * (size_t)gen->sample_size * (size_t)n_rows;
     const size_t ne_off = (out_bytes + 255) & ~(size_t)255;

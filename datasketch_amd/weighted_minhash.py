@@ -106,6 +106,7 @@ class WeightedMinHashGenerator:
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_dev"] = None
+        state.pop("_log_ring", None)
         return state
 
     # ------------------------------------------------------------------ single vector
@@ -168,49 +169,61 @@ class WeightedMinHashGenerator:
             return ctx.weighted_minhash_many(handle, self.sample_size, indptr, indices, log_data, True)
         return self._minhash_many_host(indptr, indices, X.data)
 
-    # bytes per piece of the pipelined dense call, and the threads that take np.log ahead of the device
-    _PIPE_PIECE_BYTES = 32 << 20
-    _PIPE_LOG_THREADS = 8
+    # rows per piece of the pipelined dense call (>= 4096: fewer leave compute units without a row block; about
+    # 64 MiB of values + results), and the threads that take np.log of the next piece while this one goes up
+    _PIPE_PIECE_BYTES = 64 << 20
+    _PIPE_LOG_THREADS = 4  # measured: 3-4 threads 0.050-0.056 s for 100k x 4096, 8 threads 0.066 (they compete with the upload for memory)
 
     def _dense_parity_pipelined(self, ctx, handle, x32: np.ndarray):
         """Parity mode on a dense matrix: ``np.log`` stays on the host (numpy's float32 log is what the reference
-        computes, weighted_minhash.py:212, and only the same binary reproduces it bit for bit), but it no longer
-        serialises with the device: the matrix is cut into pieces of rows, a few threads take the logs of the pieces
-        ahead (numpy releases the GIL inside the ufunc loop) into a ring of reused buffers (a fresh 32 MB array per
-        piece costs its page faults every time) while this thread sends finished pieces through the device call
-        (ctypes releases the GIL too)."""
+        computes, weighted_minhash.py:212, and only the same binary reproduces it bit for bit), but it does not
+        serialise with the device: the matrix is cut into pieces of rows; a few threads take the logs of piece
+        ``i+1`` (numpy releases the GIL inside the ufunc loop) into one of three reused buffers (a fresh buffer per
+        piece would cost its page faults every time; they are kept on the generator between calls) while this thread
+        feeds piece ``i`` to the device (``mhx_weighted_dense_feed``: upload of ``i``, evaluation of ``i``, download of
+        ``i-1`` side by side; ctypes releases the GIL too)."""
         n, dim = x32.shape
         s = self.sample_size
         out = np.zeros((n, s, 2), dtype=np.int64)
         nonempty = np.zeros(n, dtype=np.uint8)
-        rows = max(256, self._PIPE_PIECE_BYTES // max(4 * dim, 1))
-        if n <= 2 * rows:
+        rows = max(4096, (self._PIPE_PIECE_BYTES // (4 * dim + 16 * s)) & ~7)
+        if n < 2 * rows:
             with np.errstate(invalid="ignore", divide="ignore"):
                 logs = np.log(x32)
             return ctx.weighted_minhash_many_dense(handle, s, logs, True, out=out, nonempty=nonempty)
         from concurrent.futures import ThreadPoolExecutor
 
-        ahead = self._PIPE_LOG_THREADS + 2
-        ring = [np.empty((rows, dim), dtype=np.float32) for _ in range(ahead)]
+        ring = self.__dict__.pop("_log_ring", None)  # taken out while in use: a concurrent call makes its own
+        if ring is None or ring[0].shape != (rows, dim):
+            ring = [np.empty((rows, dim), dtype=np.float32) for _ in range(3)]
+        threads = self._PIPE_LOG_THREADS
+        starts = list(range(0, n, rows))
 
-        def take_log(i, lo):
-            hi = min(n, lo + rows)
-            buf = ring[i % ahead][: hi - lo]
+        def take_log(lo, hi, buf):
             with np.errstate(invalid="ignore", divide="ignore"):
                 np.log(x32[lo:hi], out=buf)
-            return buf
 
-        starts = list(range(0, n, rows))
-        with ThreadPoolExecutor(self._PIPE_LOG_THREADS) as pool:
-            futures = [pool.submit(take_log, i, lo) for i, lo in enumerate(starts[:ahead])]
+        def submit(pool, i):  # the logs of piece i, one slice of its rows per thread
+            lo, hi = starts[i], min(n, starts[i] + rows)
+            buf = ring[i % 3]
+            step = -(-(hi - lo) // threads)
+            return [pool.submit(take_log, a, min(hi, a + step), buf[a - lo : min(hi, a + step) - lo]) for a in range(lo, hi, step)]
+
+        with ThreadPoolExecutor(threads) as pool, ctx.weighted_dense_feed(handle, s, dim, True, rows) as feed:
+            pending = {i: submit(pool, i) for i in range(min(2, len(starts)))}
             for i, lo in enumerate(starts):
-                logs = futures[i].result()
-                futures[i] = None
+                for f in pending.pop(i):
+                    f.result()
                 hi = min(n, lo + rows)
-                ctx.weighted_minhash_many_dense(handle, s, logs, True, out=out[lo:hi], nonempty=nonempty[lo:hi])
-                if i + ahead < len(starts):  # buffer i % ahead is free again: the device call has returned
-                    futures.append(pool.submit(take_log, i + ahead, starts[i + ahead]))
+                feed.feed(ring[i % 3][: hi - lo], out[lo:hi], nonempty[lo:hi])
+                if i + 2 < len(starts):  # buffer (i + 2) % 3 held piece i - 1, which went up during the last feed
+                    pending[i + 2] = submit(pool, i + 2)
+        self._log_ring = ring
         return out, nonempty.view(bool)
+
+    def release_buffers(self) -> None:
+        """Drop the host buffers the pipelined dense call keeps between calls (3 pieces of about 64 MiB)."""
+        self._log_ring = None
 
     def _minhash_many_host(self, indptr, indices, data):
         """gpu_mode='disable': the reference's vectorised numpy evaluation, row by row."""

@@ -227,6 +227,20 @@ MHX_API int mhx_weighted_minhash_many_dense(mhx_wgen *gen, const float *x, int v
 MHX_API int mhx_weighted_minhash_many_dense_dev(mhx_wgen *gen, const float *d_x, int values_are_logs,
                                                 int64_t n_rows, int64_t *d_out, uint8_t *d_nonempty);
 
+/* Dense rows arriving in pieces (a host that takes np.log piece by piece ahead of the device -- parity mode of
+ * ref: weighted_minhash.py:212 -- or reads the matrix from disk):
+ *   begin  sizes the device buffers for pieces of up to piece_rows rows (two of them, so that piece i+1 goes up while
+ *          piece i is evaluated);
+ *   feed   uploads x[n_rows, dim] and returns as soon as x may be overwritten; the evaluation of this piece is queued
+ *          behind it and the results of the PREVIOUS piece are brought down meanwhile.  out / nonempty of a piece
+ *          (same layout as above, n_rows rows) are complete when the next feed, or end, has returned;
+ *   end    brings down the last piece and releases the buffers (also to be called after an error).
+ * One feed at a time per generator's context; other calls on the context may come in between. */
+typedef struct mhx_wfeed mhx_wfeed;
+MHX_API int mhx_weighted_dense_begin(mhx_wgen *gen, int values_are_logs, int64_t piece_rows, mhx_wfeed **feed);
+MHX_API int mhx_weighted_dense_feed(mhx_wfeed *feed, const float *x, int64_t n_rows, int64_t *out, uint8_t *nonempty);
+MHX_API int mhx_weighted_dense_end(mhx_wfeed *feed);
+
 /* out[i] = the float32 logarithm the device-log mode (values_are_logs == 0) takes of x[i]: the one place where the
  * fast mode can differ from numpy's float32 log (ref: weighted_minhash.py:212), exposed so that callers can check
  * the difference against their tolerance (BASELINE: 1e-6 relative). */

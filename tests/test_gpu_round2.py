@@ -285,6 +285,77 @@ def test_full_size_weighted_config4_input(ctx):
     assert np.array_equal(rev[::-1], out)
 
 
+def _weighted_oracle_rows(g, x, rows):
+    csr = sp.csr_matrix(x[rows])
+    csr.sort_indices()
+    return O.c_weighted_minhash_many(csr.indptr, csr.indices, csr.data, g.rs, g.ln_cs, g.betas)
+
+
+@pytest.mark.parametrize("values_are_logs", [True, False])
+def test_weighted_dense_feed_in_ragged_pieces(ctx, values_are_logs):
+    """mhx_weighted_dense_begin / feed / end: pieces of different sizes (one of a single row, one full, a partial last
+    one), rows without entries, buffers overwritten right after feed returns -- the same (k, t) as the one-call entry
+    and, in parity mode, as the oracle."""
+    n, dim, s, piece = 3517, 96, 40, 1000
+    rs_ = np.random.RandomState(5)
+    x = rs_.uniform(0, 50, (n, dim)).astype(np.float32)
+    x[rs_.rand(n, dim) < 0.6] = 0
+    x[[0, 17, 1000, n - 1]] = 0  # rows without entries, also first / last of a piece
+    g = WeightedMinHashGenerator(dim, s, seed=3, gpu_mode="always")
+    gctx, handle = g._device_handle()
+    with np.errstate(divide="ignore"):
+        values = np.log(x) if values_are_logs else x
+    want, want_ne = gctx.weighted_minhash_many_dense(handle, s, values, values_are_logs)
+    out = np.full((n, s, 2), -7, dtype=np.int64)
+    ne = np.full(n, 9, dtype=np.uint8)
+    cuts = [0, 1, 1001, 1500, 2500, 3400, n]
+    buf = np.empty((piece, dim), dtype=np.float32)
+    with gctx.weighted_dense_feed(handle, s, dim, values_are_logs, piece) as feed:
+        for lo, hi in zip(cuts[:-1], cuts[1:]):
+            buf[: hi - lo] = values[lo:hi]
+            feed.feed(buf[: hi - lo], out[lo:hi], ne[lo:hi])
+            buf[:] = np.nan  # the piece is on the device: the caller's buffer is free
+        with pytest.raises(ValueError, match="at most 1000 rows"):
+            feed.feed(np.zeros((piece + 1, dim), dtype=np.float32), np.zeros((piece + 1, s, 2), dtype=np.int64), np.zeros(piece + 1, dtype=np.uint8))
+    assert np.array_equal(ne.view(bool), want_ne) and np.array_equal(out, want)
+    assert not ne[[0, 17, 1000, n - 1]].any() and ne.sum() == n - 4
+    if values_are_logs:
+        rows = np.arange(0, n, 7)
+        wo, wn = _weighted_oracle_rows(g, x, rows)
+        assert np.array_equal(wn, want_ne[rows]) and np.array_equal(out[rows][wn], wo[wn])
+
+
+def test_weighted_one_call_and_python_paths_in_pieces(ctx):
+    """A matrix of more than two pieces (64 MiB each): the one-call host entry pipelines internally, the Python
+    parity path takes np.log of piece i+1 in threads while piece i is fed -- both equal the unpipelined call
+    (option host.chunk_bytes = -1) and the oracle on a sample of rows."""
+    n, dim, s = 300_000, 64, 16
+    rs_ = np.random.RandomState(11)
+    x = rs_.uniform(0, 100, (n, dim)).astype(np.float32)
+    x[rs_.rand(n, dim) < 0.3] = 0
+    x[[5, 131072, n - 1]] = 0
+    g = WeightedMinHashGenerator(dim, s, seed=2, gpu_mode="always")
+    assert n >= 2 * max(4096, ((64 << 20) // (4 * dim + 16 * s)) & ~7)
+    got, got_ne = g.minhash_many_arrays(x)  # Python: threads + feed
+    again, _ = g.minhash_many_arrays(x)     # the kept log buffers are reused
+    gctx, handle = g._device_handle()
+    with np.errstate(divide="ignore"):
+        logs = np.log(x)
+    piped, piped_ne = gctx.weighted_minhash_many_dense(handle, s, logs, True)
+    gctx.set_option("host.chunk_bytes", -1)
+    try:
+        plain, plain_ne = gctx.weighted_minhash_many_dense(handle, s, logs, True)
+    finally:
+        gctx.set_option("host.chunk_bytes", 0)
+    assert np.array_equal(plain_ne, piped_ne) and np.array_equal(plain_ne, got_ne)
+    assert np.array_equal(plain, piped) and np.array_equal(plain, got) and np.array_equal(plain, again)
+    assert not got_ne[[5, 131072, n - 1]].any()
+    rows = np.unique(np.concatenate([np.arange(0, 64), rs_.randint(0, n, 400), np.arange(131072 - 8, 131072 + 8), np.arange(n - 64, n)]))
+    wo, wn = _weighted_oracle_rows(g, x, rows)
+    assert np.array_equal(wn, got_ne[rows]) and np.array_equal(got[rows][wn], wo[wn])
+    g.release_buffers()
+
+
 # ------------------------------------------------------------------ one context, several threads
 def test_threads_sharing_the_process_context_get_right_answers(ctx):
     """ctypes releases the GIL during a libmhx call; the context serialises its callers (mhx_ctx::mu), so threads

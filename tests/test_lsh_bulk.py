@@ -236,3 +236,40 @@ def test_other_storages_take_the_per_key_path():
     assert all(keys[i] in got[i] for i in range(10)) and set(got[0]) >= {keys[0], keys[7], keys[14]}  # rows 0, 7, 14 ... are identical sets
     with pytest.raises(ValueError):
         LB.insert_bulk(idx, keys[:1], sig[:1], gpu_mode="disable")
+
+
+def test_insert_bulk_settle_choices(monkeypatch):
+    """The new containers are settled as asked: one full collection, gc.freeze(), or nothing -- and only when the
+    collector was on and the batch is big enough to matter."""
+    import collections
+    import gc
+
+    class Store:
+        def __init__(self, factory):
+            self._dict = collections.defaultdict(factory)
+
+    class Index:
+        h, b, r, prepickle, hashfunc = 64, 8, 8, False, None
+
+        def __init__(self):
+            self.keys = Store(list)
+            self.hashtables = [Store(set) for _ in range(8)]
+
+    sig = _signatures(n=120, k=64)
+    keys = [b"k%d" % i for i in range(120)]
+    calls = []
+    monkeypatch.setattr(gc, "collect", lambda *a: calls.append("collect") or 0)
+    monkeypatch.setattr(gc, "freeze", lambda: calls.append("freeze"))
+    monkeypatch.setattr(LB, "_SETTLE_MIN_KEYS", 100)
+    states = []
+    for settle in ("collect", "freeze", "leave"):
+        idx = Index()
+        LB.insert_bulk(idx, keys, sig, gpu_mode="disable", settle=settle)
+        states.append(dict(idx.hashtables[3]._dict))
+    assert calls == ["collect", "freeze"] and states[0] == states[1] == states[2]
+    monkeypatch.setattr(LB, "_SETTLE_MIN_KEYS", 1000)
+    LB.insert_bulk(Index(), keys, sig, gpu_mode="disable")
+    assert calls == ["collect", "freeze"]  # small batch: left alone
+    assert gc.isenabled()
+    with pytest.raises(ValueError):
+        LB.insert_bulk(Index(), keys, sig, gpu_mode="disable", settle="later")
