@@ -24,6 +24,8 @@
 //   * sets with few, long token lists (update_batch on one MinHash) are split over many waves
 //     and combined with 64-bit atomic min.
 // The kernels are VALU-bound (about 75 integer ops per input byte), not HBM-bound.
+#include <type_traits>
+
 #include "mhx_internal.h"
 
 namespace mhx {
@@ -49,6 +51,7 @@ struct BulkArgs {
     int32_t redo_match;         // the flag value this launch works on (MODE_DEDUP: 1, MODE_FULL after it: 2)
     unsigned int *sieve_hint;   // sieve launch: [0] sets tried, [1] proofs failed so far in this launch (zeroed before it)
     int32_t prefetch;        // warm the next set's tokens with a vector load (option minhash.prefetch)
+    int32_t ties;            // second launch: try the tie-tolerant sieve before the dedup pass (option minhash.ties)
     int64_t alias_mask;      // profiling only (option minhash.alias): sets read tokens of set (i & mask); -1 = off
     const uint64_t *init;
     int64_t init_stride;
@@ -329,6 +332,16 @@ struct Two {
     __device__ __forceinline__ bool apart() const { return k2 - k1 >= 32u; }  // k2 >= k1 always
 };
 
+// the three smallest: what the tie-tolerant proof of the second launch needs (see finish_block_ties)
+struct Three {
+    uint32_t k1 = kMaxHash, k2 = kMaxHash, k3 = kMaxHash;
+    __device__ __forceinline__ void add(uint32_t key) {
+        k3 = umed3(k2, k3, key);
+        k2 = umed3(k1, k2, key);
+        k1 = min(k1, key);
+    }
+};
+
 // fold the keys of one chunk into the row minimum; OPEN: the chunk starts the row
 template <int P, typename TokT, bool OPEN>
 __device__ __forceinline__ void sieve_chunk(const Chunk<TokT> &c, const SievePerms<P> &sp, uint32_t (&row)[P]) {
@@ -392,10 +405,66 @@ __device__ __forceinline__ bool finish_block(const Two (&rows)[P], const uint32_
     return fail;
 }
 
+// The same for a set the first launch could not settle, with a proof that tolerates ONE tie.  With B = the best key
+// rounded down to 16, a token is "in the window" when its tagged key is < B + 32; every token outside has a key
+// >= B + 32 while the token with the smallest exact value has a key <= min key + 8 < B + 24 -- so the exact minimum
+// is among the window's tokens, however many they are.  The first launch insists on one; here two are accepted
+// (hash both, take the smaller): either two cells of the best row (third smallest key of the row outside the
+// window) or the best cells of two rows (third smallest row outside; each of the two rows with a single cell in
+// the window -- the second row is rescanned for that).  That settles a token that occurs twice -- what defeats
+// the first launch on real token lists -- and two genuinely close keys, at ~1.2x the instructions of the plain sieve
+// instead of the dedup pass's 1.55x.  Three or more in the window (a token occurring three times): the set goes on
+// to the dedup pass.  (Keys near 2^32 are refused so that the 2^32-1 a fold starts from never looks like a tie.)
+template <int P, int STRIDE, int WPT>
+__device__ __forceinline__ bool finish_block_ties(const Three (&rows)[P], const uint32_t *tile, const Perms<P> &pm,
+                                                  const SievePerms<P> &sp, uint32_t (&res)[P]) {
+    bool fail = false;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const uint32_t base = rows[q].k1 & ~15u;
+        const uint32_t *rowp = tile + (rows[q].k1 & 15u) * STRIDE;  // per-lane LDS address
+        Three cols;
+#pragma unroll
+        for (int c = 0; c < kRowTokens; ++c) {
+            const uint32_t m = (uint32_t)((uint64_t)rowp[c * WPT] * sp.a_lo[q] + sp.b8[q]);
+            cols.add(tag16(m, (uint32_t)c));
+        }
+        const bool row_tie = rows[q].k2 - base < 32u;  // a second row reaches into the window
+        const bool col_tie = cols.k2 - base < 32u;     // a second cell of the best row does
+        bool ok = base >= 16u && base <= 0xFFFFFF00u && rows[q].k3 - base >= 32u && !(row_tie && col_tie) && cols.k3 - base >= 32u;
+        const uint32_t j1 = cols.k1 & 15u;
+        const uint64_t t1 = WPT == 2 ? *reinterpret_cast<const uint64_t *>(rowp + 2 * j1) : (uint64_t)rowp[j1];
+        const uint32_t j2 = col_tie ? (cols.k2 & 15u) : j1;
+        uint64_t t2 = WPT == 2 ? *reinterpret_cast<const uint64_t *>(rowp + 2 * j2) : (uint64_t)rowp[j2];
+        if (__any(row_tie)) {  // wave-uniform: rescan the second row where there is one (the other lanes go through the motions)
+            const uint32_t *row2 = tile + (rows[q].k2 & 15u) * STRIDE;
+            Two other;
+#pragma unroll
+            for (int c = 0; c < kRowTokens; ++c) {
+                const uint32_t m = (uint32_t)((uint64_t)row2[c * WPT] * sp.a_lo[q] + sp.b8[q]);
+                other.add(tag16(m, (uint32_t)c));
+            }
+            const uint32_t i1 = other.k1 & 15u;
+            const uint64_t u1 = WPT == 2 ? *reinterpret_cast<const uint64_t *>(row2 + 2 * i1) : (uint64_t)row2[i1];
+            if (row_tie) {
+                ok = ok && other.k2 - base >= 32u;
+                t2 = u1;
+            }
+        }
+        fail |= sp.active[q] && !ok;
+        uint32_t l0, h0, l1, h1;
+        mad_wide((uint32_t)t1, (uint32_t)(t1 >> 32), pm.a_lo[q], pm.a_hi[q], pm.b[q], l0, h0);
+        mad_wide((uint32_t)t2, (uint32_t)(t2 >> 32), pm.a_lo[q], pm.a_hi[q], pm.b[q], l1, h1);
+        res[q] = umin3(res[q], fold_exact(l0, h0), fold_exact(l1, h1));
+        __builtin_amdgcn_sched_barrier(0);  // one permutation at a time (registers)
+    }
+    return fail;
+}
+
 // Exact minima over the first nrows*16 tokens of [beg, ...) into res (min-combined); returns true
 // in lanes whose proof failed (the caller redoes the range).  All arguments wave-uniform except the
 // per-lane permutation registers.
-template <int P, typename TokT>
+template <int P, typename TokT, bool TIES = false>
 __device__ __forceinline__ bool sieve_range(const TokT MHX_CONST_AS *hv, const TokT *hv_vec, int64_t beg,
                                             int nrows, const Perms<P> &pm, const SievePerms<P> &sp,
                                             uint32_t *lds, int lane, uint32_t (&res)[P], int &nblocks) {
@@ -421,7 +490,7 @@ __device__ __forceinline__ bool sieve_range(const TokT MHX_CONST_AS *hv, const T
             st0 = src[0];
             if (WPT == 2) st1 = src[1];
         }
-        Two rows[P];
+        typename std::conditional<TIES, Three, Two>::type rows[P];
         // Scalar loads return out of order, so the only wait is lgkmcnt(0): wait for the current
         // chunk (a use BEFORE the next prefetch is issued), THEN issue the prefetch, then hash.
         if constexpr (CPR == 2) {
@@ -469,7 +538,10 @@ __device__ __forceinline__ bool sieve_range(const TokT MHX_CONST_AS *hv, const T
             dst[0] = st0;
             if (WPT == 2) dst[1] = st1;
         }
-        fail |= finish_block<P, STRIDE, WPT>(rows, lds, pm, sp, res);
+        if constexpr (TIES)
+            fail |= finish_block_ties<P, STRIDE, WPT>(rows, lds, pm, sp, res);
+        else
+            fail |= finish_block<P, STRIDE, WPT>(rows, lds, pm, sp, res);
         ++nblocks;
     }
     return fail;
@@ -497,7 +569,8 @@ __device__ __forceinline__ void load_quad(const TokT *hv_vec, int64_t blk, int64
     for (int i = 0; i < 4; ++i) t[i] = blk + 4 * lane + i < end ? (uint64_t)hv_vec[blk + 4 * lane + i] : 0;
 }
 
-// `first`: the quad of the first block, loaded by the caller while the previous set was being processed
+// `first`: the quad of the first block, loaded by the caller (fetching the NEXT flagged set's quad a set ahead was
+// measured: 8 VGPRs live across the whole loop, 92 -> 100, and 1-2 % slower on every corpus)
 template <int P, typename TokT>
 __device__ __forceinline__ bool dedup_sieve_range(const TokT *hv_vec, int64_t beg, int64_t end, const Perms<P> &pm,
                                                   const SievePerms<P> &sp, uint32_t *lds, int lane,
@@ -675,7 +748,7 @@ __device__ __forceinline__ Minima<P> full_minima(const TokT *hv_vec, int64_t beg
 // Sieve over the full 16-token rows of [beg,end) plus fast fold for the ragged tail.  Returns true
 // (wave-uniform) when a proof failed or a tail minimum is ambiguous: the caller then redoes the
 // range with full_minima.
-template <int P, typename TokT, bool TAIL = true>
+template <int P, typename TokT, bool TAIL = true, bool TIES = false>
 __device__ __forceinline__ bool sieve_minima(const TokT MHX_CONST_AS *hv, const TokT *hv_vec, int64_t beg,
                                              int64_t end, const Perms<P> &pm, const Perms<P> &pm_biased,
                                              const SievePerms<P> &sp, unsigned long long *stats, int lane,
@@ -687,7 +760,7 @@ __device__ __forceinline__ bool sieve_minima(const TokT MHX_CONST_AS *hv, const 
     bool bad = false;
     if (nrows > 0) {
         int nblocks = 0;
-        bad = sieve_range<P, TokT>(hv, hv_vec, beg, nrows, pm, sp, lds, lane, res, nblocks);
+        bad = sieve_range<P, TokT, TIES>(hv, hv_vec, beg, nrows, pm, sp, lds, lane, res, nblocks);
         if (stats && lane == 0) atomicAdd(stats + 2, (unsigned long long)nblocks);
     }
     const int64_t tail = beg + (int64_t)nrows * kRowTokens;
@@ -724,6 +797,22 @@ struct SieveBackoff {
         streak = 0;
         gap = 16;
     }
+};
+
+// The second launch tries the tie-tolerant sieve first and the dedup pass where that fails.  Trying pays while fewer
+// than about one set in five fails (1 360 instructions tried, 1 730 for the dedup pass): every failure adds 4 to a
+// score, every success takes 1 off; at 8 the wave stops trying for 32 sets, then looks again.
+struct TiesBackoff {
+    int skip = 0;
+    int score = 0;
+    __device__ __forceinline__ void failed() {
+        score += 4;
+        if (score >= 8) {
+            skip = 32;
+            score = 4;
+        }
+    }
+    __device__ __forceinline__ void succeeded() { score = max(score - 1, 0); }
 };
 
 // min over tokens [beg,end) of the exact fold, for the P permutations of this lane.
@@ -833,6 +922,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
     // one wave per 64 sets left 2.5 rounds of 64-set waves when everything was flagged)
     const int64_t n_items = flagged_only ? (args.n_sets + kWave - 1) / kWave * waves_per_block : args.n_sets;
     SieveBackoff backoff;
+    TiesBackoff ties;
     int tried = 0, failed = 0;  // MODE_SIEVE: this wave's contribution to args.sieve_hint
     if (MODE == MODE_SIEVE && args.sieve_hint) {
         // a launch over a corpus whose sets defeat the sieve (repeated tokens) should not find that out wave by wave
@@ -856,8 +946,6 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
           const bool mine = (lane % waves_per_block) == (int)(item0 % waves_per_block);  // every fourth flagged set of the group
           todo = __ballot(mine && cand < args.n_sets && args.redo[cand] == (uint8_t)args.redo_match);
       }
-      uint64_t quad[4] = {0, 0, 0, 0};  // MODE_FULL after a sieve launch: first tokens of the current set, fetched one set ahead
-      int64_t quad_set = -1;  // the set `quad` belongs to
       while (todo) {
         const int bit = __builtin_ctzll(todo);
         todo &= todo - 1;
@@ -876,7 +964,10 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
         uint32_t warm = 0;
         {
             const int64_t nset = flagged_only ? (todo ? item * kWave + __builtin_ctzll(todo) : args.n_sets) : item + stride;
-            if (args.prefetch && nset < args.n_sets) {
+            // (a wave that is skipping the sieve -- the corpus defeats it -- does not read the next set either: the
+            // warm-up loads of a skipping launch alone kept it at 0.18 ms per 500k sets, one pass over the corpus)
+            const bool skipping_on = MODE == MODE_SIEVE && backoff.skip > 1;
+            if (args.prefetch && nset < args.n_sets && !skipping_on) {
                 const int64_t nbeg = args.offsets ? offsets[nset] : nset * args.fixed_len;
                 const int64_t nend = args.offsets ? offsets[nset + 1] : nbeg + args.fixed_len;
                 const int64_t off = (int64_t)lane * 128;
@@ -915,26 +1006,25 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
                         // a flagged set gets the dedup sieve (repeated tokens are what usually broke the proof); what
                         // that cannot prove either is left to the pairwise launch
                         load_perms<P>(args, kc * (kWave * P), lane, pm, pm_biased, sp, kidx);
+                        // the sieve again with the proof that tolerates one tie (a token occurring twice, two close keys)
+                        bool open = true;
+                        if (!args.ties) {
+                        } else if (ties.skip > 0) {
+                            if (kc == kchunks - 1) --ties.skip;
+                        } else {
+                            open = sieve_minima<P, TokT, true, true>(hv, hv_vec, beg, end, pm, pm_biased, sp, nullptr, lane, lds, res);
+                            if (open) ties.failed(); else ties.succeeded();
+                        }
+                        if (open) {
 #pragma unroll
                         for (int p = 0; p < P; ++p) res[p] = kMaxHash;
                         uint64_t cur[4];
-                        if (quad_set == set && kc == 0) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) cur[i] = quad[i];
-                        } else {
-                            load_quad<TokT>(hv_vec, beg, end, lane, cur);
-                        }
-                        if (kc == kchunks - 1 && todo) {  // the next flagged set of this item: its tokens travel while this one is hashed
-                            const int64_t nset = item * kWave + __builtin_ctzll(todo);
-                            const int64_t nbeg = args.offsets ? offsets[nset] : nset * args.fixed_len;
-                            const int64_t nend = args.offsets ? offsets[nset + 1] : nbeg + args.fixed_len;
-                            load_quad<TokT>(hv_vec, nbeg, nend, lane, quad);
-                            quad_set = nset;
-                        }
+                        load_quad<TokT>(hv_vec, beg, end, lane, cur);
                         defer = __any(dedup_sieve_range<P, TokT>(hv_vec, beg, end, pm, sp, lds, lane, cur, res));
                         if (defer) {
                             if (args.stats && lane == 0) atomicAdd(args.stats + 3, 1ull);
                             break;
+                        }
                         }
                     } else {
                         const Minima<P> m = full_minima<P, TokT>(hv_vec, beg, end, args.a, args.b, args.num_perm,
@@ -1336,6 +1426,7 @@ int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const in
     args.sieve_hint = nullptr;
     args.alias_mask = ctx->opt_minhash_alias;
     args.prefetch = ctx->opt_minhash_prefetch != 0;
+    args.ties = ctx->opt_minhash_ties != 1;
     args.init = d_init;
     args.init_stride = init_stride;
     args.out = d_out;

@@ -356,6 +356,80 @@ def test_weighted_one_call_and_python_paths_in_pieces(ctx):
     g.release_buffers()
 
 
+# ------------------------------------------------------------------ the second launch's tie-tolerant proof
+@pytest.mark.parametrize("k,tok_dtype", [(128, np.uint64), (64, np.uint64), (256, np.uint64), (128, np.uint32), (200, np.uint32)])
+def test_repeated_tokens_in_every_position_pattern(ctx, k, tok_dtype):
+    """Sets with one repeated token (same row, another row, the ragged tail, another 256-token block), two
+    different repeated tokens, a token occurring three and four times, near-tied keys -- what the first launch's
+    uniqueness proof refuses.  The second launch settles the pairs with its tie-tolerant proof (two candidates
+    hashed exactly) and everything else with the dedup pass; all of it must equal the oracle bit for bit."""
+    rng = np.random.RandomState(21)
+    hi = 2**32
+    sets = []
+
+    def fresh(t):
+        return rng.randint(0, hi, t, dtype=np.uint64)
+
+    for t in (16, 32, 47, 256, 300, 600):
+        for rep in range(12):
+            base = fresh(t)
+            i, j = rng.choice(t, 2, replace=False)
+            v = base.copy(); v[j] = v[i]; sets.append(v)                        # a pair anywhere
+            v = base.copy(); r = (i // 16) * 16; v[r + (i + 1) % min(16, t - r) if t - r >= 16 else j] = v[i]; sets.append(v)  # same row where there is one
+            if t >= 48:
+                v = base.copy(); v[(i + 16) % t] = v[i]; sets.append(v)         # next row, same column
+                i2, j2 = rng.choice(t, 2, replace=False)
+                v = base.copy(); v[j] = v[i]; v[j2] = v[i2]; sets.append(v)     # two repeated tokens
+                v = base.copy(); v[j] = v[i]; v[(j + 7) % t] = v[i]; sets.append(v)   # three times
+                v = base.copy(); v[rng.choice(t, 4, replace=False)] = v[i]; sets.append(v)  # four times
+            if t > 256:
+                v = base.copy(); v[256 + (i % (t - 256))] = v[i % 256]; sets.append(v)  # across blocks
+            if t % 16:
+                v = base.copy(); v[t - 1] = v[i]; sets.append(v)                # repeat in the ragged tail
+    sets += [np.repeat(fresh(8), 2), np.tile(fresh(16), 2), np.tile(fresh(128), 2), fresh(256), np.zeros(64, np.uint64)]
+    lens = np.array([len(v) for v in sets], dtype=np.int64)
+    off = np.zeros(len(sets) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    hv = np.concatenate(sets)
+    a, b = O.np_init_permutations(k, 6)
+    want = O.c_minhash_bulk(hv, off, a, b)
+    ctx.set_option("minhash.split", 1)  # one wave per set: the launches under test
+    try:
+        if tok_dtype == np.uint32:
+            d_tok, d_off, d_out = ctx.to_device(hv.astype(np.uint32)), ctx.to_device(off), ctx.alloc(len(sets) * k * 8)
+            ctx.minhash_bulk_dev((a, b), d_tok.ptr, _native.MHX_U32, d_off.ptr, 0, len(sets), hv.size, None, 0, d_out.ptr, _native.MHX_U64)
+            ctx.synchronize()
+            got = d_out.download((len(sets), k), np.uint64)
+        else:
+            got = ctx.minhash_bulk((a, b), hv, off, 0, len(sets))
+    finally:
+        ctx.set_option("minhash.split", 0)
+    bad = np.flatnonzero((got != want).any(axis=1))
+    assert bad.size == 0, (bad[:10], lens[bad[:10]])
+
+
+def test_light_repeats_corpus_is_settled_without_the_pairwise_launch(ctx):
+    """1 % repeated tokens: nearly every set fails the first launch's proof (some permutation's minimum falls on a
+    repeated token) and nearly none needs more than the tie-tolerant proof: the pairwise launch sees (almost) nothing."""
+    rng = np.random.RandomState(8)
+    n, t, k = 20_000, 256, 128
+    hv = rng.randint(0, 2**32, n * t, dtype=np.uint64)
+    m = n * t // 100
+    dst = rng.randint(0, hv.size, m)
+    hv[dst] = hv[(dst // t) * t + rng.randint(0, t, m)]
+    a, b = O.np_init_permutations(k, 1)
+    ctx.counters(True)
+    got = ctx.minhash_bulk((a, b), hv, None, t, n)
+    c = ctx.counters(False)
+    assert np.array_equal(got[:3000], O.c_minhash_bulk_dense(hv[: 3000 * t].reshape(3000, t), a, b))
+    assert c["sieve_sets_redone"] > n // 2 and c["pairwise_sets"] <= n // 100, c
+    ctx.set_option("minhash.ties", 1)  # dedup pass only: the same signatures
+    try:
+        assert np.array_equal(ctx.minhash_bulk((a, b), hv, None, t, n), got)
+    finally:
+        ctx.set_option("minhash.ties", 0)
+
+
 # ------------------------------------------------------------------ one context, several threads
 def test_threads_sharing_the_process_context_get_right_answers(ctx):
     """ctypes releases the GIL during a libmhx call; the context serialises its callers (mhx_ctx::mu), so threads

@@ -380,8 +380,12 @@ def main():
     ap.add_argument("--weighted-rows", type=int, default=20000)
     ap.add_argument("--sigs", type=int, default=1_000_000)
     ap.add_argument("--only", default="")
+    ap.add_argument("--opt", action="append", default=[], help="context option key=value (mhx_ctx_set_option), repeatable")
     args = ap.parse_args()
     ctx = _native.context()
+    for kv in args.opt:
+        key, value = kv.split("=")
+        ctx.set_option(key, int(value))
     print(json.dumps(ctx.info()), flush=True)
     if args.only in ("", "minhash"):
         minhash_shapes(ctx)
