@@ -106,7 +106,7 @@ int mhx_ctx::ensure_redo(int64_t n_sets) {
 
 int mhx_ctx::ensure_work() {
     if (d_work) return MHX_OK;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_work), 64);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_work), mhx::kWorkBytes);
     if (e != hipSuccess) {
         d_work = nullptr;
         return fail(MHX_ERR_OOM, "work counter allocation failed: %s", hipGetErrorString(e));

@@ -29,6 +29,10 @@ int fail(int code, const char *fmt, ...);
         }                                                                                        \
     } while (0)
 
+// mhx_ctx::d_work: 16 counter words, then the list of sets the second MinHash launch leaves to the pairwise one
+constexpr unsigned int kPairListCap = 16384;
+constexpr size_t kWorkBytes = 64 + sizeof(unsigned int) * kPairListCap;
+
 // serialise the calls on one context (see mhx_ctx::mu)
 #define MHX_GUARD(ctxp) std::lock_guard<std::recursive_mutex> _mhx_guard((ctxp)->mu)
 
@@ -76,7 +80,8 @@ struct mhx_ctx {
     uint8_t *d_redo = nullptr;
     int64_t redo_capacity = 0;
     int ensure_redo(int64_t n_sets);
-    // work counters of the flagged launches + the sieve launch's running failure counts (4 words, zeroed per call)
+    // the sieve launch's running failure counts ([0], [1]), the number of sets left to the pairwise launch ([4]) -- zeroed
+    // per call -- and, from word 16 on, the list of those sets (kPairListCap entries)
     unsigned int *d_work = nullptr;
     int ensure_work();
 

@@ -50,6 +50,8 @@ struct BulkArgs {
                                 // == 2 <=> the dedup launch left it to the pairwise (full) launch
     int32_t redo_match;         // the flag value this launch works on (MODE_DEDUP: 1, MODE_FULL after it: 2)
     unsigned int *sieve_hint;   // sieve launch: [0] sets tried, [1] proofs failed so far in this launch (zeroed before it)
+    unsigned int *pair_count;   // flagged launches: [0] sets the dedup launch left to the pairwise one; the first kPairListCap of
+    unsigned int *pair_list;    // them are listed here (set numbers), so that the pairwise launch need not scan the flags for a handful
     int32_t prefetch;        // warm the next set's tokens with a vector load (option minhash.prefetch)
     int32_t ties;            // second launch: try the tie-tolerant sieve before the dedup pass (option minhash.ties)
     int64_t alias_mask;      // profiling only (option minhash.alias): sets read tokens of set (i & mask); -1 = off
@@ -907,7 +909,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
     Perms<P> pm, pm_biased;
     SievePerms<P> sp;
     int kidx[P];
-    if (MODE == MODE_SIEVE) load_perms<P>(args, 0, lane, pm, pm_biased, sp, kidx);
+    if (MODE == MODE_SIEVE || MODE == MODE_DEDUP) load_perms<P>(args, 0, lane, pm, pm_biased, sp, kidx);
 
     const TokT MHX_CONST_AS *hv = as_const(static_cast<const TokT *>(args.hv));
     const TokT *hv_vec = static_cast<const TokT *>(args.hv);
@@ -920,7 +922,15 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
     const bool flagged_only = MODE != MODE_SIEVE && args.redo != nullptr;
     // (the four waves of a workgroup share one group of 64 flags and take every fourth flagged set of it:
     // one wave per 64 sets left 2.5 rounds of 64-set waves when everything was flagged)
-    const int64_t n_items = flagged_only ? (args.n_sets + kWave - 1) / kWave * waves_per_block : args.n_sets;
+    // the pairwise launch takes its sets from the list when all of them fit in it (no flag scan: 41 -> ~15 us per step
+    // on a clean corpus, where it has a handful of sets among a million flags)
+    unsigned int listed_n = 0;
+    bool listed = false;
+    if (MODE == MODE_FULL && flagged_only && args.pair_list) {
+        listed_n = *as_const(args.pair_count);
+        listed = listed_n <= kPairListCap;
+    }
+    const int64_t n_items = listed ? (int64_t)listed_n : flagged_only ? (args.n_sets + kWave - 1) / kWave * waves_per_block : args.n_sets;
     SieveBackoff backoff;
     TiesBackoff ties;
     int tried = 0, failed = 0;  // MODE_SIEVE: this wave's contribution to args.sieve_hint
@@ -941,7 +951,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
     for (int64_t item0 = (int64_t)blockIdx.x * waves_per_block + wave; item0 < n_items; item0 += stride) {
       const int64_t item = flagged_only ? item0 / waves_per_block : item0;  // 64-flag group
       unsigned long long todo = 1;  // sets of this item still to do (bit i = set 64*item + i when flagged_only)
-      if (flagged_only) {
+      if (flagged_only && !listed) {
           const int64_t cand = item * kWave + lane;
           const bool mine = (lane % waves_per_block) == (int)(item0 % waves_per_block);  // every fourth flagged set of the group
           todo = __ballot(mine && cand < args.n_sets && args.redo[cand] == (uint8_t)args.redo_match);
@@ -949,7 +959,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
       while (todo) {
         const int bit = __builtin_ctzll(todo);
         todo &= todo - 1;
-        const int64_t set = flagged_only ? item * kWave + bit : item;
+        const int64_t set = listed ? (int64_t)as_const(args.pair_list)[item0] : flagged_only ? item * kWave + bit : item;
         int64_t beg, end;
         if (args.offsets) {
             beg = offsets[set];
@@ -963,7 +973,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
         // of the next iteration then hit on-chip instead of paying an HBM round trip each.
         uint32_t warm = 0;
         {
-            const int64_t nset = flagged_only ? (todo ? item * kWave + __builtin_ctzll(todo) : args.n_sets) : item + stride;
+            const int64_t nset = listed ? args.n_sets : flagged_only ? (todo ? item * kWave + __builtin_ctzll(todo) : args.n_sets) : item + stride;
             // (a wave that is skipping the sieve -- the corpus defeats it -- does not read the next set either: the
             // warm-up loads of a skipping launch alone kept it at 0.18 ms per 500k sets, one pass over the corpus)
             const bool skipping_on = MODE == MODE_SIEVE && backoff.skip > 1;
@@ -1005,7 +1015,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
                     if (MODE == MODE_DEDUP) {
                         // a flagged set gets the dedup sieve (repeated tokens are what usually broke the proof); what
                         // that cannot prove either is left to the pairwise launch
-                        load_perms<P>(args, kc * (kWave * P), lane, pm, pm_biased, sp, kidx);
+                        if (kchunks > 1) load_perms<P>(args, kc * (kWave * P), lane, pm, pm_biased, sp, kidx);
                         // the sieve again with the proof that tolerates one tie (a token occurring twice, two close keys)
                         bool open = true;
                         if (!args.ties) {
@@ -1057,7 +1067,13 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
             args.redo[set] = defer ? 1 : 0;
             if (defer && args.stats) atomicAdd(args.stats, 1ull);
         }
-        if (MODE == MODE_DEDUP && defer && lane == 0) args.redo[set] = 2;
+        if (MODE == MODE_DEDUP && defer && lane == 0) {
+            args.redo[set] = 2;
+            if (args.pair_list) {  // (rare: a few sets in 10^5 of a clean corpus, ~1 % of a corpus full of repeats)
+                const unsigned int slot = atomicAdd(args.pair_count, 1u);
+                if (slot < kPairListCap) args.pair_list[slot] = (unsigned int)set;
+            }
+        }
         asm volatile("" ::"v"(warm));  // the warm-up load retires here, a whole set later
       }
     }
@@ -1323,7 +1339,7 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_
             // sieve launch (writes a flag per set), then the flagged sets (usually a handful: those launches read
             // n_sets bytes of flags and return)
             if (int rc = ctx->ensure_work()) return rc;
-            MHX_HIP_CHECK(hipMemsetAsync(ctx->d_work, 0, 4 * sizeof(unsigned int), ctx->stream));
+            MHX_HIP_CHECK(hipMemsetAsync(ctx->d_work, 0, 8 * sizeof(unsigned int), ctx->stream));
             BulkArgs sieve_args = args;
             sieve_args.sieve_hint = ctx->d_work;
             const BulkArgs &args_s = sieve_args;
@@ -1355,10 +1371,14 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_
             const int64_t flag_groups = (args.n_sets + kWave - 1) / kWave;
             BulkArgs dedup = args;
             dedup.redo_match = 1;
+            if (args.n_sets <= 0xFFFFFFFFll) {
+                dedup.pair_count = ctx->d_work + 4;
+                dedup.pair_list = ctx->d_work + 16;
+            }
             hipLaunchKernelGGL((minhash_bulk_kernel<PF, TokT, OutT, MODE_DEDUP, SHAPE_GENERAL>),
                                dim3(resident_grid(ctx, (const void *)minhash_bulk_kernel<PF, TokT, OutT, MODE_DEDUP, SHAPE_GENERAL>, flag_groups)),
                                dim3(256), 0, ctx->stream, dedup);
-            BulkArgs rest = args;
+            BulkArgs rest = dedup;
             rest.redo_match = 2;
             hipLaunchKernelGGL((minhash_bulk_kernel<PF, TokT, OutT, MODE_FULL, SHAPE_GENERAL>),
                                dim3(resident_grid(ctx, (const void *)minhash_bulk_kernel<PF, TokT, OutT, MODE_FULL, SHAPE_GENERAL>, flag_groups)),
@@ -1425,6 +1445,8 @@ int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const in
     args.redo_match = 1;
     args.sieve_hint = nullptr;
     args.alias_mask = ctx->opt_minhash_alias;
+    args.pair_count = nullptr;
+    args.pair_list = nullptr;
     args.prefetch = ctx->opt_minhash_prefetch != 0;
     args.ties = ctx->opt_minhash_ties != 1;
     args.init = d_init;

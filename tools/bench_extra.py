@@ -145,6 +145,9 @@ def minhash_ragged(ctx, only_repeats=False):
     a, b = MinHash(num_perm=k, seed=1).permutations
     cases = (("ragged 32..480", 500_000, 32, 480, 0.0), ("ragged 1..100", 1_000_000, 1, 100, 0.0),
              ("dense 256 with 10% repeated tokens", 500_000, 256, 256, 0.1), ("dense 256 with 1% repeated tokens", 500_000, 256, 256, 0.01))
+    if only_repeats and os.environ.get("MHX_REPEATS_RATE"):  # one corpus only (kernel traces)
+        cases = tuple(c for c in cases if c[4] == float(os.environ["MHX_REPEATS_RATE"]))
+        only_repeats = False
     for name, n, lo, hi, dup in (cases[2:] if only_repeats else cases):
         lens = rng.randint(lo, hi + 1, size=n).astype(np.int64)
         off = np.zeros(n + 1, dtype=np.int64)
