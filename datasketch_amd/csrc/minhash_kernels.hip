@@ -1297,9 +1297,11 @@ __global__ void minhash_merge_kernel(const uint64_t *__restrict__ x, const uint6
         ulonglong2 xa[4], ya[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            if (i + u * stride < n2) {
-                xa[u] = x2[i + u * stride];
-                ya[u] = y2[i + u * stride];
+            if (i + u * stride < n2) {  // non-temporal both ways, 32 workgroups per CU: tools/ubench_stream.hip
+                xa[u].x = __builtin_nontemporal_load(&x2[i + u * stride].x);
+                xa[u].y = __builtin_nontemporal_load(&x2[i + u * stride].y);
+                ya[u].x = __builtin_nontemporal_load(&y2[i + u * stride].x);
+                ya[u].y = __builtin_nontemporal_load(&y2[i + u * stride].y);
             }
         }
 #pragma unroll
@@ -1308,7 +1310,8 @@ __global__ void minhash_merge_kernel(const uint64_t *__restrict__ x, const uint6
             ulonglong2 r;
             r.x = xa[u].x < ya[u].x ? xa[u].x : ya[u].x;
             r.y = xa[u].y < ya[u].y ? xa[u].y : ya[u].y;
-            o2[i + u * stride] = r;
+            __builtin_nontemporal_store(r.x, &o2[i + u * stride].x);
+            __builtin_nontemporal_store(r.y, &o2[i + u * stride].y);
         }
     }
     if ((count & 1) && blockIdx.x == 0 && threadIdx.x == 0)
@@ -1471,8 +1474,8 @@ int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const in
 int launch_minhash_merge(mhx_ctx *ctx, const uint64_t *d_x, const uint64_t *d_y, int64_t count,
                          uint64_t *d_out) {
     if (count == 0) return MHX_OK;
-    const int64_t want = ((count >> 1) + 255) / 256;
-    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * 8));
+    const int64_t want = ((count >> 1) + 1023) / 1024;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * 32));
     hipLaunchKernelGGL(minhash_merge_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_x, d_y,
                        count, d_out);
     MHX_HIP_CHECK(hipGetLastError());
