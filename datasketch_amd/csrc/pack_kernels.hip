@@ -102,6 +102,50 @@ __global__ __launch_bounds__(256) void bbit1_wide_kernel(const SigT *__restrict_
     }
 }
 
+// The same idea for the wider slots (2, 4, 8, 16 and, with uint64 input, 32 bits per value): a lane's V values go to
+// their slots of a 64-bit word, the per/V lanes of a block (16, 8, 4, 2 or 1) OR their words with DPP butterflies
+// (mirror inside the row / half row, then the two quad permutations), the first lane of the group stores.
+template <int LB>
+__device__ __forceinline__ uint32_t or_group(uint32_t x) {  // OR over aligned groups of LB lanes (LB <= 16), in every lane
+    if constexpr (LB >= 16) x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, false);  // row_mirror
+    if constexpr (LB >= 8) x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, false);   // row_half_mirror
+    if constexpr (LB >= 4) x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+    if constexpr (LB >= 2) x |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    return x;
+}
+
+template <typename SigT, int SLOT>
+__global__ __launch_bounds__(256) void bbit_wide_kernel(const SigT *__restrict__ sig, int64_t n, int32_t k, int32_t b,
+                                                        uint64_t *__restrict__ out) {
+    constexpr int V = 16 / (int)sizeof(SigT);  // values per lane
+    constexpr int PER = 64 / SLOT;             // values per block
+    constexpr int LB = PER / V;                // lanes per block (>= 1: the launcher sees to it)
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    const int i = lane & (LB - 1);
+    const uint32_t mask = b >= 32 ? 0xFFFFFFFFu : ((1u << b) - 1u);
+    const int nb = k / PER;
+    for (int64_t row = (int64_t)blockIdx.x * waves_per_block + wave; row < n; row += (int64_t)gridDim.x * waves_per_block) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(sig + row * k);
+        uint64_t *dst = out + row * nb;
+        for (int c0 = 0; c0 < k / V; c0 += kWave) {
+            const uint4 v = src[c0 + lane];
+            uint64_t word;
+            if (V == 4) {
+                const int top = 64 - SLOT * (4 * i + 1);  // shift of the lane's first value
+                word = ((uint64_t)(v.x & mask) << top) | ((uint64_t)(v.y & mask) << (top - SLOT)) |
+                       ((uint64_t)(v.z & mask) << (top - 2 * SLOT)) | ((uint64_t)(v.w & mask) << (top - 3 * SLOT));
+            } else {
+                const int top = 64 - SLOT * (2 * i + 1);
+                word = ((uint64_t)(v.x & mask) << top) | ((uint64_t)(v.z & mask) << (top - SLOT));
+            }
+            const uint32_t hi = or_group<LB>((uint32_t)(word >> 32)), lo = or_group<LB>((uint32_t)word);
+            if (i == 0) dst[(c0 * V) / PER + lane / LB] = ((uint64_t)hi << 32) | lo;
+        }
+    }
+}
+
 // ---- band keys ------------------------------------------------------------------------------
 // ref: datasketch/lsh.py:537-538 (_byteswap) over hashranges (:199): out[i, c] = bswap64(sig[i, c])
 __global__ __launch_bounds__(256) void band_keys_kernel(const uint64_t *__restrict__ sig, int64_t n,
@@ -264,6 +308,17 @@ int launch_bbit_pack(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, 
             hipLaunchKernelGGL(bbit1_wide_kernel<uint32_t>, row_grid(ctx, n), dim3(256), 0, ctx->stream, (const uint32_t *)d_sig, n, k, d_out);
         else
             hipLaunchKernelGGL(bbit1_wide_kernel<uint64_t>, row_grid(ctx, n), dim3(256), 0, ctx->stream, (const uint64_t *)d_sig, n, k, d_out);
+    } else if (slot > 1 && 64 / slot >= 16 / esize && k % (64 * (16 / esize)) == 0 && ((uintptr_t)d_sig & 15) == 0) {
+        const dim3 g = row_grid(ctx, n);
+#define MHX_WIDE(T, S) hipLaunchKernelGGL((bbit_wide_kernel<T, S>), g, dim3(256), 0, ctx->stream, (const T *)d_sig, n, k, b, d_out)
+        if (sig_dtype == MHX_U32) {
+            if (slot == 2) MHX_WIDE(uint32_t, 2); else if (slot == 4) MHX_WIDE(uint32_t, 4);
+            else if (slot == 8) MHX_WIDE(uint32_t, 8); else MHX_WIDE(uint32_t, 16);
+        } else {
+            if (slot == 2) MHX_WIDE(uint64_t, 2); else if (slot == 4) MHX_WIDE(uint64_t, 4);
+            else if (slot == 8) MHX_WIDE(uint64_t, 8); else if (slot == 16) MHX_WIDE(uint64_t, 16); else MHX_WIDE(uint64_t, 32);
+        }
+#undef MHX_WIDE
     } else
     if (sig_dtype == MHX_U32)
         hipLaunchKernelGGL(bbit_pack_kernel<uint32_t>, row_grid(ctx, n), dim3(256), 0, ctx->stream, (const uint32_t *)d_sig, n,

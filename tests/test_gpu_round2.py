@@ -121,8 +121,8 @@ def test_uint32_signatures_through_pack_digest_sort(ctx):
 
 
 @pytest.mark.parametrize("k", [128, 256, 384, 512, 768, 1024, 200])
-def test_one_bit_packing_with_wide_loads(ctx, k):
-    """b = 1 takes 16-byte loads when a row is whole groups of 64 * V values (V = 4 uint32 / 2 uint64 per lane): every
+def test_bbit_packing_with_wide_loads(ctx, k):
+    """Every slot width takes 16-byte loads when a row is whole groups of 64 * V values (V = 4 uint32 / 2 uint64 per lane): every
     such K, the K that fall back, odd row counts, against the oracle's bit order (b_bit_minhash.py:82-97)."""
     rng = np.random.RandomState(k)
     n = 3001
@@ -131,13 +131,14 @@ def test_one_bit_packing_with_wide_loads(ctx, k):
     sig[6] = 2**32 - 1
     sig[7, ::2] |= 1
     sig[7, 1::2] &= ~np.uint64(1)
-    want = O.c_bbit_pack(sig, 1)
-    nb = want.shape[1]
-    for dtype, code in ((np.uint64, _native.MHX_U64), (np.uint32, _native.MHX_U32)):
-        d_sig, out = ctx.to_device(sig.astype(dtype)), ctx.alloc(n * nb * 8)
-        _native.check(ctx.lib.mhx_bbit_pack_dev_typed(ctx.handle, d_sig.ptr, code, n, k, 1, out.ptr))
-        ctx.synchronize()
-        assert np.array_equal(out.download((n, nb), np.uint64), want), dtype
+    for b in (1, 2, 3, 4, 7, 8, 11, 16, 17, 32):  # slots of 1, 2, 4, 8, 16 and 32 bits
+        want = O.c_bbit_pack(sig, b)
+        nb = want.shape[1]
+        for dtype, code in ((np.uint64, _native.MHX_U64), (np.uint32, _native.MHX_U32)):
+            d_sig, out = ctx.to_device(sig.astype(dtype)), ctx.alloc(n * nb * 8)
+            _native.check(ctx.lib.mhx_bbit_pack_dev_typed(ctx.handle, d_sig.ptr, code, n, k, b, out.ptr))
+            ctx.synchronize()
+            assert np.array_equal(out.download((n, nb), np.uint64), want), (b, dtype)
 
 
 # ------------------------------------------------------------------ bulk query on the device
