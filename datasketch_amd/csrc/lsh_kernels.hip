@@ -72,9 +72,10 @@ __global__ __launch_bounds__(256) void band_keys_with_luggage_kernel(const SigT 
     const int64_t total = n * (int64_t)bands;
     const int d_bits = sort_bits - band_bits;   // digest bits inside the sorted prefix
     const int h_bits = 64 - sort_bits;          // digest bits that ride in the key's upper part
+    const int shift = (bands & (bands - 1)) == 0 ? __builtin_ctz((unsigned)bands) : -1;  // a 64-bit division per element otherwise
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = idx / bands;
+        const int64_t row = shift >= 0 ? idx >> shift : idx / bands;
         const uint64_t dg = band_digest_of<SigT>(sig, row, (int)(idx - row * bands), k, r);
         const uint64_t prefix = prefix_key(dg, (uint32_t)(idx - row * bands), band_bits, sort_bits);
         const uint64_t hi = h_bits > 0 ? low_bits(dg >> band_bits, h_bits) : 0;  // bits [band_bits, band_bits + h_bits)

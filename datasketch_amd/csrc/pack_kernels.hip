@@ -222,13 +222,15 @@ __global__ __launch_bounds__(256) void lean_serialize_kernel(const uint64_t *__r
 // uses as that band's dictionary key (ref: datasketch/lsh.py:199,344,537-538: the r hashvalues of the
 // band, each as 8 big-endian bytes).  It is what MinHashLSH(hashfunc=fnv1a_64) would store
 // (ref: lsh.py:540-543), in a form a device-side sort can group by.  One lane per (row, band).
-template <typename SigT>
+// (LOG2 >= 0: bands is that power of two -- the 64-bit division of idx by a run-time divisor was 60 of the kernel's ~290
+// VALU instructions per element)
+template <typename SigT, int LOG2>
 __global__ __launch_bounds__(256) void band_digest_kernel(const SigT *__restrict__ sig, int64_t n, int32_t k,
                                                           int32_t bands, int32_t r, uint64_t *__restrict__ out) {
     const int64_t total = n * (int64_t)bands;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = idx / bands;
+        const int64_t row = LOG2 >= 0 ? idx >> LOG2 : idx / bands;
         out[idx] = band_digest_of<SigT>(sig, row, (int)(idx - row * bands), k, r);
     }
 }
@@ -352,10 +354,18 @@ int launch_band_digests(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t 
                         uint64_t *d_out) {
     const int64_t want = (n * bands + 255) / 256;
     dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * 16)));
+#define MHX_DIGEST(T, L) hipLaunchKernelGGL((band_digest_kernel<T, L>), grid, dim3(256), 0, ctx->stream, (const T *)d_sig, n, k, bands, r, d_out)
+#define MHX_DIGEST_T(T)                                                                                                    \
+    do {                                                                                                                   \
+        if (bands == 16) MHX_DIGEST(T, 4); else if (bands == 32) MHX_DIGEST(T, 5); else if (bands == 64) MHX_DIGEST(T, 6);  \
+        else if (bands == 128) MHX_DIGEST(T, 7); else MHX_DIGEST(T, -1);                                                    \
+    } while (0)
     if (sig_dtype == MHX_U32)
-        hipLaunchKernelGGL(band_digest_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, (const uint32_t *)d_sig, n, k, bands, r, d_out);
+        MHX_DIGEST_T(uint32_t);
     else
-        hipLaunchKernelGGL(band_digest_kernel<uint64_t>, grid, dim3(256), 0, ctx->stream, (const uint64_t *)d_sig, n, k, bands, r, d_out);
+        MHX_DIGEST_T(uint64_t);
+#undef MHX_DIGEST_T
+#undef MHX_DIGEST
     MHX_HIP_CHECK(hipGetLastError());
     return MHX_OK;
 }
