@@ -451,6 +451,41 @@ def test_light_repeats_corpus_is_settled_without_the_pairwise_launch(ctx):
         ctx.set_option("minhash.ties", 0)
 
 
+@pytest.mark.parametrize("copies", [300, 20_000])
+def test_three_close_keys_reach_the_pairwise_launch(ctx, copies):
+    """Three DIFFERENT tokens whose keys under one permutation are the three smallest of the set and within 32 of each
+    other: the tie-tolerant proof has one candidate too many, the dedup pass finds nothing to drop, the set goes to the
+    pairwise launch -- from the list the second launch writes (a few hundred sets) or, beyond the list's 16 384 entries,
+    by the scan of the flags.  Bit-exact either way."""
+    k = 128
+    a, b = O.np_init_permutations(k, 4)
+    rng = np.random.RandomState(31)
+    protos = []
+    for pi in range(40):
+        a_lo, b8 = int(a[pi]) & 0xFFFFFFFF, (int(b[pi]) + 8) & 0xFFFFFFFF
+        if a_lo % 2 == 0:
+            continue
+        inv = pow(a_lo, -1, 1 << 32)
+        lows = [((m - b8) * inv) % 2**32 for m in (1000, 1007, 1021)]  # keys 1000, 1007, 1021 for permutation pi
+        filler = rng.randint(0, 2**32, 253, dtype=np.uint64)
+        s_ = np.concatenate([filler, np.array(lows, dtype=np.uint64)])
+        rng.shuffle(s_)
+        protos.append(s_)
+    protos = np.stack(protos[:8])
+    want_proto = O.c_minhash_bulk_dense(protos, a, b)
+    reps = -(-copies // len(protos))
+    tok = np.tile(protos, (reps, 1))[:copies]
+    ctx.set_option("minhash.split", 1)
+    try:
+        ctx.counters(True)
+        got = ctx.minhash_bulk((a, b), tok.reshape(-1), None, 256, copies)
+        c = ctx.counters(False)
+    finally:
+        ctx.set_option("minhash.split", 0)
+    assert np.array_equal(got, np.tile(want_proto, (reps, 1))[:copies])
+    assert c["pairwise_sets"] == copies, c
+
+
 # ------------------------------------------------------------------ one context, several threads
 def test_threads_sharing_the_process_context_get_right_answers(ctx):
     """ctypes releases the GIL during a libmhx call; the context serialises its callers (mhx_ctx::mu), so threads
