@@ -945,6 +945,53 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
             backoff.streak = 2;
         }
     }
+    // The pairwise launch over a list: a lone wave per set would pay one memory round trip per 64-byte scalar load, one
+    // after the other (~20 us for 256 tokens, and a clean corpus leaves this launch a handful of sets and nothing to
+    // hide that behind).  So the four waves of a workgroup take a quarter of the set's tokens each and combine their
+    // minima through LDS.
+    if (MODE == MODE_FULL && listed) {
+        uint32_t *comb = stage;  // [4 waves][P][64 lanes]
+        for (int64_t it = blockIdx.x; it < (int64_t)listed_n; it += gridDim.x) {
+            const int64_t set = (int64_t)as_const(args.pair_list)[it];
+            const int64_t beg = args.offsets ? offsets[set] : set * args.fixed_len;
+            const int64_t end = args.offsets ? offsets[set + 1] : beg + args.fixed_len;
+            const int64_t share = (end - beg + 31) / 32 * 8;  // whole 8-token chunks
+            const int64_t wbeg = min(end, beg + wave * share), wend = min(end, wbeg + share);
+            for (int kc = 0; kc < kchunks; ++kc) {
+                uint32_t mine[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p) mine[p] = kMaxHash;
+                if (wend > wbeg) {
+                    const Minima<P> m = full_minima<P, TokT>(hv_vec, wbeg, wend, args.a, args.b, args.num_perm, kc * (kWave * P),
+                                                             args.path == 1, args.stats);
+#pragma unroll
+                    for (int p = 0; p < P; ++p) mine[p] = m.v[p];
+                }
+#pragma unroll
+                for (int p = 0; p < P; ++p) comb[(wave * P + p) * kWave + lane] = mine[p];
+                __syncthreads();
+                if (wave == 0) {
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const int k = kc * (kWave * P) + p * kWave + lane;
+                        if (k >= args.num_perm) continue;
+                        uint32_t r = mine[p];
+#pragma unroll
+                        for (int w = 1; w < 4; ++w) r = min(r, comb[(w * P + p) * kWave + lane]);
+                        uint64_t v = r;
+                        if (args.init) {
+                            const uint64_t iv = args.init[set * args.init_stride + k];
+                            v = end > beg ? (uint64_t)min((iv >> 32) ? kMaxHash : (uint32_t)iv, r) : iv;
+                        }
+                        if (sizeof(OutT) == 4) v = v > kMaxHash ? kMaxHash : v;
+                        out[set * args.num_perm + k] = (OutT)v;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        return;
+    }
     // flagged launches: the (flag group, wave) items go round the waves of a grid that is exactly as large as what
     // is resident at once (one atomic counter handing them out one by one serialises: 62 500 items at ~90 dequeues per
     // microsecond cost 0.7 ms per launch; a larger static grid leaves its last round of workgroups running alone)
