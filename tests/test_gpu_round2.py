@@ -455,8 +455,8 @@ def test_light_repeats_corpus_is_settled_without_the_pairwise_launch(ctx):
 def test_three_close_keys_reach_the_pairwise_launch(ctx, copies):
     """Three DIFFERENT tokens whose keys under one permutation are the three smallest of the set and within 32 of each
     other: the tie-tolerant proof has one candidate too many, the dedup pass finds nothing to drop, the set goes to the
-    pairwise launch -- from the list the second launch writes (a few hundred sets) or, beyond the list's 16 384 entries,
-    by the scan of the flags.  Bit-exact either way."""
+    pairwise launch -- from the list the second launch writes (a few hundred sets: the workgroup-per-set kernels of a
+    clean corpus) or, beyond the list's 16 384 entries, by the scan of the flags.  Bit-exact either way."""
     k = 128
     a, b = O.np_init_permutations(k, 4)
     rng = np.random.RandomState(31)
@@ -468,9 +468,9 @@ def test_three_close_keys_reach_the_pairwise_launch(ctx, copies):
         inv = pow(a_lo, -1, 1 << 32)
         lows = [((m - b8) * inv) % 2**32 for m in (1000, 1007, 1021)]  # keys 1000, 1007, 1021 for permutation pi
         filler = rng.randint(0, 2**32, 253, dtype=np.uint64)
-        s_ = np.concatenate([filler, np.array(lows, dtype=np.uint64)])
-        rng.shuffle(s_)
-        protos.append(s_)
+        at = 64 * int(rng.randint(0, 4)) + int(rng.randint(0, 61))  # all three inside one quarter of the set
+        # next to each other: also the workgroup-per-set kernel, which proves quarter by quarter, sees all three in one quarter
+        protos.append(np.concatenate([filler[:at], np.array(lows, dtype=np.uint64), filler[at:]]))
     protos = np.stack(protos[:8])
     want_proto = O.c_minhash_bulk_dense(protos, a, b)
     reps = -(-copies // len(protos))
