@@ -7,6 +7,7 @@ a device is missing it raises, it does not fall back to a CPU implementation.
 from __future__ import annotations
 
 import ctypes
+import weakref
 import os
 import threading
 from typing import Optional
@@ -38,6 +39,8 @@ _PROTOTYPES = {
     "mhx_ctx_counters": [_vp, _int, ctypes.POINTER(ctypes.c_uint64)],
     "mhx_dev_alloc": [_vp, _sz, ctypes.POINTER(_vp)],
     "mhx_dev_free": [_vp, _vp],
+    "mhx_host_alloc": [_vp, _sz, ctypes.POINTER(_vp)],
+    "mhx_host_free": [_vp, _vp],
     "mhx_memcpy_h2d": [_vp, _vp, _vp, _sz],
     "mhx_memcpy_d2h": [_vp, _vp, _vp, _sz],
     "mhx_memcpy_d2d": [_vp, _vp, _vp, _sz],
@@ -545,6 +548,19 @@ class Context:
             raise ValueError("nonempty must be a C-contiguous uint8 array of shape (N,)")
         check(self.lib.mhx_weighted_minhash_many_dense(h, _ptr(x), int(bool(values_are_logs)), n, _ptr(out), _ptr(nonempty)))
         return out, nonempty.view(bool)
+
+    def pinned_empty(self, shape, dtype) -> np.ndarray:
+        """An uninitialised array in page-locked host memory (mhx_host_alloc): what is filled and uploaded again and
+        again goes up by DMA straight from it.  The memory is released when the array (and every view of it) is gone."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        p = _vp()
+        check(self.lib.mhx_host_alloc(self.handle, n, ctypes.byref(p)))
+        buf = (ctypes.c_char * max(n, 1)).from_address(p.value)
+        ptr = p.value
+        # (not at interpreter exit, when the context may be gone already: the process's pages go back anyway)
+        weakref.finalize(buf, lambda: self.handle and self.lib.mhx_host_free(self.handle, ptr)).atexit = False
+        return np.frombuffer(buf, dtype=dtype, count=n // dtype.itemsize).reshape(shape)
 
     def weighted_dense_feed(self, h: int, sample_size: int, dim: int, values_are_logs: bool, piece_rows: int) -> "WeightedFeed":
         """Dense rows in pieces (mhx_weighted_dense_begin/feed/end); use as a context manager."""

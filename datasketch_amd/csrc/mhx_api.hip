@@ -279,6 +279,30 @@ int mhx_dev_free(mhx_ctx *ctx, void *dptr) {
     return MHX_OK;
 }
 
+int mhx_host_alloc(mhx_ctx *ctx, size_t bytes, void **ptr) {
+    if (!ctx || !ptr) return fail(MHX_ERR_INVALID, "ctx/ptr is NULL");
+    MHX_GUARD(ctx);
+    *ptr = nullptr;
+    if (int rc = ctx->activate()) return rc;
+    hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(MHX_ERR_OOM, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+    return MHX_OK;
+}
+
+int mhx_host_free(mhx_ctx *ctx, void *ptr) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    if (!ptr) return MHX_OK;
+    if (int rc = ctx->activate()) return rc;
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (ctx->copy_in) MHX_HIP_CHECK(hipStreamSynchronize(ctx->copy_in));
+    MHX_HIP_CHECK(hipHostFree(ptr));
+    return MHX_OK;
+}
+
 int mhx_memcpy_h2d(mhx_ctx *ctx, void *dst, const void *src, size_t bytes) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
     MHX_GUARD(ctx);

@@ -172,14 +172,14 @@ class WeightedMinHashGenerator:
     # rows per piece of the pipelined dense call (>= 4096: fewer leave compute units without a row block; about
     # 64 MiB of values + results), and the threads that take np.log of the next piece while this one goes up
     _PIPE_PIECE_BYTES = 64 << 20
-    _PIPE_LOG_THREADS = 4  # measured: 3-4 threads 0.050-0.056 s for 100k x 4096, 8 threads 0.066 (they compete with the upload for memory)
+    _PIPE_LOG_THREADS = 3  # measured for 100k x 4096: 3 threads 0.044-0.051 s, 4 threads 0.052-0.060, 8 threads 0.056-0.066 (they compete with the upload for memory)
 
     def _dense_parity_pipelined(self, ctx, handle, x32: np.ndarray):
         """Parity mode on a dense matrix: ``np.log`` stays on the host (numpy's float32 log is what the reference
         computes, weighted_minhash.py:212, and only the same binary reproduces it bit for bit), but it does not
         serialise with the device: the matrix is cut into pieces of rows; a few threads take the logs of piece
-        ``i+1`` (numpy releases the GIL inside the ufunc loop) into one of three reused buffers (a fresh buffer per
-        piece would cost its page faults every time; they are kept on the generator between calls) while this thread
+        ``i+1`` (numpy releases the GIL inside the ufunc loop) into one of three reused page-locked buffers (a fresh
+        buffer per piece would cost its page faults every time; they are kept on the generator between calls) while this thread
         feeds piece ``i`` to the device (``mhx_weighted_dense_feed``: upload of ``i``, evaluation of ``i``, download of
         ``i-1`` side by side; ctypes releases the GIL too)."""
         n, dim = x32.shape
@@ -194,8 +194,8 @@ class WeightedMinHashGenerator:
         from concurrent.futures import ThreadPoolExecutor
 
         ring = self.__dict__.pop("_log_ring", None)  # taken out while in use: a concurrent call makes its own
-        if ring is None or ring[0].shape != (rows, dim):
-            ring = [np.empty((rows, dim), dtype=np.float32) for _ in range(3)]
+        if ring is None or ring[0].shape != (rows, dim):  # page-locked: a piece goes up by DMA straight from it
+            ring = [ctx.pinned_empty((rows, dim), np.float32) for _ in range(3)]
         threads = self._PIPE_LOG_THREADS
         starts = list(range(0, n, rows))
 

@@ -312,6 +312,25 @@ def _weighted_oracle_rows(g, x, rows):
     return O.c_weighted_minhash_many(csr.indptr, csr.indices, csr.data, g.rs, g.ln_cs, g.betas)
 
 
+def test_page_locked_host_arrays(ctx):
+    """mhx_host_alloc through Context.pinned_empty: an ordinary numpy array as far as numpy is concerned, accepted by
+    the host entry points, released with its last view."""
+    import gc
+
+    x = ctx.pinned_empty((1000, 96), np.float32)
+    assert x.shape == (1000, 96) and x.dtype == np.float32 and x.flags.c_contiguous and x.flags.writeable
+    x[:] = np.random.RandomState(3).uniform(1, 9, x.shape)
+    d = ctx.to_device(x)
+    assert np.array_equal(d.download(x.shape, np.float32), x)
+    view = x[10:20]
+    del x
+    gc.collect()
+    assert float(view.sum()) > 0  # the buffer lives as long as a view does
+    del view
+    gc.collect()
+    assert ctx.pinned_empty((0,), np.uint8).size == 0
+
+
 @pytest.mark.parametrize("values_are_logs", [True, False])
 def test_weighted_dense_feed_in_ragged_pieces(ctx, values_are_logs):
     """mhx_weighted_dense_begin / feed / end: pieces of different sizes (one of a single row, one full, a partial last
