@@ -178,6 +178,32 @@ def test_sorted_bands_index_query_is_the_reference_query(ctx, dtype, n, bands, r
         idx.query(probes[:, :8].astype(dtype))
 
 
+@pytest.mark.parametrize("dtype", [np.uint64, np.uint32])
+def test_sorted_bands_index_grown_in_batches(ctx, dtype):
+    """SortedBandsIndex.extend: an index grown in three batches (the first one empty) answers like the index built
+    from the whole matrix and like the brute-force band comparison; row numbers continue across batches."""
+    rng = np.random.RandomState(17)
+    n, k, bands, r = 9000, 64, 16, 4
+    sig = rng.randint(0, 2**32, (n, k), dtype=np.uint64).astype(dtype)
+    sig[5000:5200, :32] = sig[100:300, :32]      # rows of the second batch share half their bands with rows of the first
+    sig[8000:8100] = sig[6000:6100]              # duplicates inside the last batch's span
+    probes = np.concatenate([sig[rng.randint(0, n, 300)], rng.randint(0, 2**32, (50, k), dtype=np.uint64).astype(dtype)])
+    whole = LB.SortedBandsIndex(sig, bands, r)
+    grown = LB.SortedBandsIndex(sig[:0], bands, r)
+    assert list(grown.extend(sig[:4000])) == list(range(0, 4000))
+    assert grown.extend(sig[4000:4000]) == range(4000, 4000)
+    assert grown.extend(sig[4000:7500]) == range(4000, 7500)
+    assert grown.extend(sig[7500:]) == range(7500, n) and grown.n == n
+    off_w, rows_w = whole.query(probes)
+    off_g, rows_g = grown.query(probes)
+    assert np.array_equal(off_w, off_g) and np.array_equal(rows_w, rows_g)
+    brute = _brute_query(sig.astype(np.uint64), probes.astype(np.uint64), bands, r)
+    for i in (0, 7, 150, 299, 320):
+        assert np.array_equal(rows_g[off_g[i] : off_g[i + 1]], brute[i])
+    with pytest.raises(ValueError):
+        grown.extend(sig[:10, :32])
+
+
 def test_query_verification_rejects_digest_only_matches(ctx):
     """A probe is located by its 64-bit band digest; with the index matrix given, a candidate counts only if the band's
     values are equal.  Forced here by handing the kernel sorted bands of a DIFFERENT matrix than the one it verifies
