@@ -246,7 +246,7 @@ class WeightedFeed:
     def __del__(self):
         try:
             h, self.handle = self.handle, None
-            if h is not None:
+            if h is not None and self.ctx.handle is not None:  # (a closed context has taken its generators along)
                 self.ctx.lib.mhx_weighted_dense_end(h)
         except Exception:
             pass
