@@ -473,6 +473,17 @@ class Context:
         buf, byte_offsets = Context.pack_tokens([t for s in sets for t in s])
         return buf, byte_offsets, set_offsets
 
+    @staticmethod
+    def pack_int_sets(sets):
+        """Lists / tuples of exact Python ints -> (uint64 values, int64 set offsets) by the C helper, or None when it
+        does not apply (helper missing, other element types): the caller takes the numpy route then."""
+        if _mhxpack is None or not hasattr(_mhxpack, "pack_int_sets"):
+            return None
+        packed = _mhxpack.pack_int_sets(sets)
+        if packed is None:
+            return None
+        return np.frombuffer(packed[0], dtype=np.uint64), np.frombuffer(packed[1], dtype=np.int64)
+
     def sha1_tokens(self, buf: np.ndarray, byte_offsets: np.ndarray, bits: int = 32) -> np.ndarray:
         """sha1_hash32 / sha1_hash64 of every token of a packed byte corpus (host in, host out)."""
         n = byte_offsets.size - 1

@@ -163,7 +163,62 @@ done:
     return result;
 }
 
+/* Sets (lists / tuples) of exact Python ints -> (uint64 values, int64 set offsets), what numpy's
+ * np.array(tokens, dtype=uint64) makes of every set (ref: datasketch/minhash.py:294), at ~10 ns per token instead of ~90.
+ * None when anything else turns up (numpy arrays, numpy scalars, floats, other iterables): the caller then takes the
+ * numpy route, with numpy's own conversions and errors.  OverflowError for values outside uint64, as numpy raises. */
+static PyObject *pack_int_sets(PyObject *self, PyObject *arg) {
+    (void)self;
+    if (!PyList_CheckExact(arg) && !PyTuple_CheckExact(arg)) Py_RETURN_NONE;
+    const Py_ssize_t n_sets = PySequence_Fast_GET_SIZE(arg);
+    PyObject **sets = PySequence_Fast_ITEMS(arg);
+    int64_t n_tokens = 0;
+    for (Py_ssize_t s = 0; s < n_sets; ++s) {
+        if (!PyList_CheckExact(sets[s]) && !PyTuple_CheckExact(sets[s])) Py_RETURN_NONE;
+        n_tokens += PySequence_Fast_GET_SIZE(sets[s]);
+    }
+    PyObject *set_offs = new_offsets(n_sets + 1), *vals = NULL, *result = NULL;
+    if (!set_offs) return NULL;
+    vals = PyByteArray_FromStringAndSize(NULL, (Py_ssize_t)n_tokens * (Py_ssize_t)sizeof(uint64_t));
+    if (!vals) goto done;
+    {
+        int64_t *set_offsets = (int64_t *)PyByteArray_AS_STRING(set_offs);
+        uint64_t *out = (uint64_t *)PyByteArray_AS_STRING(vals);
+        int64_t pos = 0;
+        for (Py_ssize_t s = 0; s < n_sets; ++s) {
+            const Py_ssize_t n = PySequence_Fast_GET_SIZE(sets[s]);
+            PyObject **items = PySequence_Fast_ITEMS(sets[s]);
+            set_offsets[s] = pos;
+            if (pos + n > n_tokens) {  /* a set grew under our feet */
+                PyErr_SetString(PyExc_RuntimeError, "a set changed size while it was being packed");
+                goto done;
+            }
+            for (Py_ssize_t i = 0; i < n; ++i) {
+                if (!PyLong_CheckExact(items[i])) {  /* bool, numpy scalar, float ...: numpy decides */
+                    result = Py_None;
+                    Py_INCREF(result);
+                    goto done;
+                }
+                const unsigned long long v = PyLong_AsUnsignedLongLong(items[i]);
+                if (v == (unsigned long long)-1 && PyErr_Occurred()) goto done;  /* OverflowError: negative or >= 2^64 */
+                out[pos++] = (uint64_t)v;
+            }
+        }
+        set_offsets[n_sets] = pos;
+        if (pos != n_tokens) {
+            PyErr_SetString(PyExc_RuntimeError, "a set changed size while it was being packed");
+            goto done;
+        }
+        result = PyTuple_Pack(2, vals, set_offs);
+    }
+done:
+    Py_XDECREF(vals);
+    Py_XDECREF(set_offs);
+    return result;
+}
+
 static PyMethodDef methods[] = {
+    {"pack_int_sets", pack_int_sets, METH_O, "lists of Python ints -> (uint64 values bytearray, int64 set offsets bytearray) or None"},
     {"pack_tokens", pack_tokens, METH_O, "tokens -> (data bytearray, int64 byte offsets bytearray)"},
     {"pack_sets", pack_sets, METH_O, "sets of tokens -> (data, int64 byte offsets, int64 set offsets)"},
     {NULL, NULL, 0, NULL},

@@ -261,8 +261,12 @@ class MinHash:
 
     def _hash_sets(self, sets: List) -> Tuple[np.ndarray, np.ndarray]:
         """Apply ``hashfunc`` per token on the host and pack the result as CSR (values, offsets)."""
-        offsets = np.zeros(len(sets) + 1, dtype=np.int64)
         f = self.hashfunc
+        if f is prehashed:
+            packed = _native.Context.pack_int_sets(sets)  # lists of Python ints: the C helper, ~10x np.array per set
+            if packed is not None:
+                return packed
+        offsets = np.zeros(len(sets) + 1, dtype=np.int64)
         if f is prehashed:
             parts = [_as_hash_array(s).reshape(-1) if not isinstance(s, np.ndarray) or s.dtype != np.uint64 else s.reshape(-1) for s in sets]
         else:

@@ -500,3 +500,27 @@ def test_serialize_matrix_rejects_values_that_do_not_fit_the_format():
     m = MinHash(num_perm=3, seed=1, hashvalues=sig[0])
     with pytest.raises(struct.error):  # what the object method does for the same value (lean_minhash.py:174-175)
         LeanMinHash(m).serialize(bytearray(LeanMinHash(m).bytesize()))
+
+
+def test_prehashed_lists_of_ints_take_the_c_packer_and_keep_numpy_semantics():
+    """hashfunc=prehashed on lists / tuples of Python ints: packed by csrc/pack_module.c (pack_int_sets); anything else
+    (numpy arrays, floats, bools, numpy scalars) goes the numpy way with numpy's conversions, values outside uint64 raise
+    OverflowError as np.array(..., dtype=uint64) does (ref: datasketch/minhash.py:294)."""
+    from datasketch_amd import _native
+
+    m = MinHash(num_perm=16, seed=1, hashfunc=prehashed, gpu_mode="disable")
+    rng = np.random.RandomState(4)
+    sets = [list(map(int, rng.randint(0, 2**32, n))) for n in (5, 0, 1, 40)] + [(2**64 - 1, 0, 2**63)]
+    hv, off = m._hash_sets(sets)
+    assert hv.dtype == np.uint64 and off.tolist() == [0, 5, 5, 6, 46, 49]
+    assert np.array_equal(hv, np.concatenate([np.array(s, dtype=np.uint64) for s in sets]))
+    if _native._mhxpack is not None:
+        assert _native.Context.pack_int_sets(sets) is not None
+        for other in ([np.array([1, 2])], [[1.0, 2]], [[True, 2]], [[np.uint64(3)]], [iter([1, 2])], [{1, 2}]):
+            assert _native.Context.pack_int_sets(other) is None
+    assert m._hash_sets([[1, 2.0], np.array([7, 8]), [True]])[0].tolist() == [1, 2, 7, 8, 1]
+    for bad in ([[1, -2]], [[2**64]]):
+        with pytest.raises(OverflowError):
+            m._hash_sets(bad)
+    want = MinHash.bulk_signatures([np.array(s, dtype=np.uint64) for s in sets], num_perm=16, seed=1, hashfunc=prehashed, gpu_mode="disable")
+    assert np.array_equal(MinHash.bulk_signatures(sets, num_perm=16, seed=1, hashfunc=prehashed, gpu_mode="disable"), want)
