@@ -223,6 +223,9 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "minhash.alias")) ctx->opt_minhash_alias = value;
     else if (!strcmp(key, "minhash.prefetch")) ctx->opt_minhash_prefetch = value;
     else if (!strcmp(key, "weighted.path")) ctx->opt_weighted_path = value;
+    else if (!strcmp(key, "weighted.rows")) ctx->opt_weighted_rows = value;
+    else if (!strcmp(key, "weighted.cols")) ctx->opt_weighted_cols = value;
+    else if (!strcmp(key, "weighted.debug")) ctx->opt_weighted_debug = value;
     else if (!strcmp(key, "host.chunk_bytes")) ctx->opt_host_chunk_bytes = value;
     else if (!strcmp(key, "lsh.sort_bits")) ctx->opt_lsh_sort_bits = value;
     else if (!strcmp(key, "lsh.gather")) ctx->opt_lsh_gather = value;
@@ -1161,8 +1164,17 @@ int mhx_wgen_create(mhx_ctx *ctx, const float *rs, const float *ln_cs, const flo
         const float m = fabsf(rs[j]);
         g->table_fast = m >= 0x1p-40f && m <= 0x1p40f;  // false for NaN / inf / 0 as well
     }
+    g->table_filter = g->table_fast;  // the candidate filter's bound also wants r > 0, a moderate ln_c and 0 <= beta <= 1
+    for (size_t j = 0; j < n && g->table_filter; ++j)
+        g->table_filter = rs[j] > 0.0f && fabsf(ln_cs[j]) <= 0x1p40f && betas[j] >= 0.0f && betas[j] <= 1.0f;
+    const size_t w_bytes = sizeof(float) * (size_t)g->s_pad * (size_t)((dim + 3) & ~3);
+    const size_t a_bytes = sizeof(float) * 4 * (size_t)g->s_pad * (size_t)dim;
     hipError_t e = hipMalloc((void **)&g->d_params, t_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&g->d_wtab, w_bytes);
+    if (e == hipSuccess) e = hipMalloc((void **)&g->d_aos, a_bytes);
     if (e != hipSuccess) {
+        (void)hipFree(g->d_params);
+        (void)hipFree(g->d_wtab);
         delete g;
         return fail(MHX_ERR_OOM, "hipMalloc for weighted parameters failed: %s", hipGetErrorString(e));
     }
@@ -1179,6 +1191,8 @@ int mhx_wgen_create(mhx_ctx *ctx, const float *rs, const float *ln_cs, const flo
     }
     if (rc != MHX_OK) {
         (void)hipFree(g->d_params);
+        (void)hipFree(g->d_wtab);
+        (void)hipFree(g->d_aos);
         delete g;
         return rc;
     }
@@ -1192,6 +1206,8 @@ int mhx_wgen_destroy(mhx_wgen *gen) {
     (void)hipSetDevice(gen->ctx->device);
     (void)hipStreamSynchronize(gen->ctx->stream);
     (void)hipFree(gen->d_params);
+    (void)hipFree(gen->d_wtab);
+    (void)hipFree(gen->d_aos);
     delete gen;
     return MHX_OK;
 }
