@@ -223,8 +223,7 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "minhash.alias")) ctx->opt_minhash_alias = value;
     else if (!strcmp(key, "minhash.prefetch")) ctx->opt_minhash_prefetch = value;
     else if (!strcmp(key, "weighted.path")) ctx->opt_weighted_path = value;
-    else if (!strcmp(key, "weighted.rows")) ctx->opt_weighted_rows = value;
-    else if (!strcmp(key, "weighted.cols")) ctx->opt_weighted_cols = value;
+    else if (!strcmp(key, "weighted.direct")) ctx->opt_weighted_direct = value;
     else if (!strcmp(key, "weighted.debug")) ctx->opt_weighted_debug = value;
     else if (!strcmp(key, "host.chunk_bytes")) ctx->opt_host_chunk_bytes = value;
     else if (!strcmp(key, "lsh.sort_bits")) ctx->opt_lsh_sort_bits = value;
@@ -1164,17 +1163,26 @@ int mhx_wgen_create(mhx_ctx *ctx, const float *rs, const float *ln_cs, const flo
         const float m = fabsf(rs[j]);
         g->table_fast = m >= 0x1p-40f && m <= 0x1p40f;  // false for NaN / inf / 0 as well
     }
-    g->table_filter = g->table_fast;  // the candidate filter's bound also wants r > 0, a moderate ln_c and 0 <= beta <= 1
-    for (size_t j = 0; j < n && g->table_filter; ++j)
-        g->table_filter = rs[j] > 0.0f && fabsf(ln_cs[j]) <= 0x1p40f && betas[j] >= 0.0f && betas[j] <= 1.0f;
-    const size_t w_bytes = sizeof(float) * (size_t)g->s_pad * (size_t)((dim + 3) & ~3);
+    // the walk's bound wants r > 0 and finite ln_c, beta (monotone ln_a); its table builder sorts a sample's columns in LDS
+    g->walk_ok = g->table_fast && dim <= 16384;
+    for (size_t j = 0; j < n && g->walk_ok; ++j)
+        g->walk_ok = rs[j] > 0.0f && fabsf(ln_cs[j]) < __builtin_inff() && fabsf(betas[j]) < __builtin_inff();
     const size_t a_bytes = sizeof(float) * 4 * (size_t)g->s_pad * (size_t)dim;
+    const float plan0[4] = {__builtin_nanf(""), 0.0f, 0.0f, 0.0f};  // WalkPlan: no tables yet
     hipError_t e = hipMalloc((void **)&g->d_params, t_bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&g->d_wtab, w_bytes);
     if (e == hipSuccess) e = hipMalloc((void **)&g->d_aos, a_bytes);
+    if (e == hipSuccess && g->walk_ok) e = hipMalloc((void **)&g->d_walk_a, a_bytes);
+    if (e == hipSuccess && g->walk_ok) e = hipMalloc((void **)&g->d_walk_c, a_bytes / 4);
+    if (e == hipSuccess && g->walk_ok) e = hipMalloc(&g->d_walk_plan, sizeof(plan0));
+    if (e == hipSuccess && g->walk_ok) e = hipMemcpyAsync(g->d_walk_plan, plan0, sizeof(plan0), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && g->walk_ok) e = hipMemsetAsync(g->d_walk_a, 0, a_bytes, ctx->stream);  // lanes behind sample_size load from here too
+    if (e == hipSuccess && g->walk_ok) e = hipMemsetAsync(g->d_walk_c, 0, a_bytes / 4, ctx->stream);
     if (e != hipSuccess) {
         (void)hipFree(g->d_params);
-        (void)hipFree(g->d_wtab);
+        (void)hipFree(g->d_aos);
+        (void)hipFree(g->d_walk_a);
+        (void)hipFree(g->d_walk_c);
+        (void)hipFree(g->d_walk_plan);
         delete g;
         return fail(MHX_ERR_OOM, "hipMalloc for weighted parameters failed: %s", hipGetErrorString(e));
     }
@@ -1191,8 +1199,10 @@ int mhx_wgen_create(mhx_ctx *ctx, const float *rs, const float *ln_cs, const flo
     }
     if (rc != MHX_OK) {
         (void)hipFree(g->d_params);
-        (void)hipFree(g->d_wtab);
         (void)hipFree(g->d_aos);
+        (void)hipFree(g->d_walk_a);
+        (void)hipFree(g->d_walk_c);
+        (void)hipFree(g->d_walk_plan);
         delete g;
         return rc;
     }
@@ -1206,8 +1216,10 @@ int mhx_wgen_destroy(mhx_wgen *gen) {
     (void)hipSetDevice(gen->ctx->device);
     (void)hipStreamSynchronize(gen->ctx->stream);
     (void)hipFree(gen->d_params);
-    (void)hipFree(gen->d_wtab);
     (void)hipFree(gen->d_aos);
+    (void)hipFree(gen->d_walk_a);
+    (void)hipFree(gen->d_walk_c);
+    (void)hipFree(gen->d_walk_plan);
     delete gen;
     return MHX_OK;
 }

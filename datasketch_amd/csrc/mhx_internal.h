@@ -64,10 +64,9 @@ struct mhx_ctx {
     int64_t opt_blocks_per_cu = 0;  // 0 auto
     int64_t opt_minhash_prefetch = 1; // warm L2 with the next set's tokens (vector load per set)
     int64_t opt_minhash_alias = -1; // profiling only: >= 0 makes set i read the tokens of set (i & mask)
-    int64_t opt_weighted_path = 0;  // 0 auto (dense rows: candidate filter; CSR: reciprocal-multiply quotient + row blocks), 1 IEEE division for every element, 2 no candidate filter (dense rows compacted to CSR: the round-2 path)
-    int64_t opt_weighted_rows = 0;  // dense filter kernel: rows per wave (8 or 16); 0 auto
-    int64_t opt_weighted_cols = 0;  // dense filter kernel: columns per group (2 or 4); 0 auto
-    int64_t opt_weighted_debug = 0; // profiling only: 1 = no test ever passes (the streaming loop alone; results are wrong)
+    int64_t opt_weighted_path = 0;  // 0 auto (dense rows: bound-ordered walk; CSR: reciprocal-multiply quotient + row blocks), 1 IEEE division for every element, 2 every element evaluated (dense rows compacted to CSR: the round-2 path)
+    int64_t opt_weighted_debug = 0;  // profiling only (results are wrong): 1 = rows staged and scanned, not walked; 2 = staged without the scan
+    int64_t opt_weighted_direct = 0; // walk kernel: rows storing at most this many per mille of the columns are evaluated entry by entry; 0 auto
     int64_t opt_lsh_gather = 0;     // mhx_lsh_sort_bands: 1 = gather the full digests after the sort (the fallback path) even when they could ride along
     int64_t opt_lsh_sort_bits = 0;  // mhx_lsh_sort_bands: bits of (band, digest) the radix sort orders by; 0 = from n
     int64_t opt_host_chunk_bytes = 0;  // mhx_minhash_bulk: bytes per pipelined piece; 0 auto (96 MiB, inputs > 256 MiB), < 0 never pipeline
@@ -110,11 +109,15 @@ struct mhx_wgen {
     // every r is finite with 2^-40 <= |r| <= 2^40: the reciprocal-multiply quotient is proven exact
     // (weighted_kernels.hip); otherwise every element takes the IEEE division
     bool table_fast = false;
-    // tables of the dense filter kernel: lower-bound words [ceil(dim/4)][S_pad][4] and {r, ln_c, beta, 0} [dim][S_pad]
-    float *d_wtab = nullptr;
+    // {r, ln_c, beta, 0} [dim][S_pad]: one 16-byte load per lane for a wave-uniform column
     float *d_aos = nullptr;
-    // additionally r > 0, |ln_c| <= 2^40 and 0 <= beta <= 1 everywhere: the filter's lower bound is proven
-    bool table_filter = false;
+    // the walk kernel's tables (weighted_kernels.hip): per 64-sample chunk, the columns in the order of a lower bound of
+    // ln_a -- {bound, r, ln_c, beta} and the column, [S_pad / 64][dim][64] each -- and the device-resident plan they
+    // were built for.  walk_ok: r > 0, ln_c and beta finite everywhere (the bound's monotonicity) and dim <= 16384 (LDS)
+    float *d_walk_a = nullptr;
+    uint32_t *d_walk_c = nullptr;
+    void *d_walk_plan = nullptr;
+    bool walk_ok = false;
 };
 
 struct mhx_event {

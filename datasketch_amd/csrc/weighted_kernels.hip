@@ -53,35 +53,26 @@ constexpr int kWave = 64;
 constexpr int kRowBlock = 8;   // rows hashed together when they share their column list
 constexpr int kColChunk = 2;   // columns per software-pipeline stage (2: 72 VGPRs, 7 waves/SIMD; 4 is 10 % slower, 1 and 3 in between)
 constexpr int kWords = 5;      // table words per (column, sample)
-constexpr float kKappa = 0x1p-19f;  // relative slack of the candidate filter's lower bound (32 float32 roundoff units)
 #define MHX_CONST_AS __attribute__((address_space(4)))
 
 enum : uint8_t { kFlagSamePattern = 1, kFlagSane = 2 };
 
-// [S, dim] x3  ->  [dim][5][S_pad], and the two tables of the dense filter kernel (below):
-//   wtab[ceil(dim/4)][S_pad][4]   lower-bound words w' (see "dense rows with a candidate filter"), +inf for padding
-//   aos[dim][S_pad] = {r, ln_c, beta, 0}   one 16-byte gather per candidate
+// [S, dim] x3  ->  params[dim][5][S_pad] (the row-block kernels) and aos[dim][S_pad] = {r, ln_c, beta, 0}: one
+// 16-byte load per lane for a wave-uniform column (the walk kernel's direct evaluations and its table builder)
 __global__ void wgen_transpose_kernel(const float *__restrict__ rs, const float *__restrict__ ln_cs,
                                       const float *__restrict__ betas, int32_t s, int32_t dim,
-                                      int32_t s_pad, float *__restrict__ params, float *__restrict__ wtab,
-                                      float4 *__restrict__ aos) {
-    const int32_t dim_pad = (dim + 3) & ~3;
-    const int64_t total = (int64_t)dim_pad * s_pad;
+                                      int32_t s_pad, float *__restrict__ params, float4 *__restrict__ aos) {
+    const int64_t total = (int64_t)dim * s_pad;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int j = (int)(idx / s_pad);
         const int i = (int)(idx - (int64_t)j * s_pad);
         float r = 1.0f, c = 0.0f, be = 0.0f;
-        const bool real = i < s && j < dim;
-        if (real) {
+        if (i < s) {
             r = rs[(int64_t)i * dim + j];
             c = ln_cs[(int64_t)i * dim + j];
             be = betas[(int64_t)i * dim + j];
         }
-        // w' <= ln_c - r - kappa (|ln_c| + r + 1), rounded DOWN to float32 (double arithmetic, then v_cvt toward -inf)
-        const double w = (double)c - (double)r - (double)kKappa * (fabs((double)c) + (double)r + 1.0);
-        wtab[((int64_t)(j >> 2) * s_pad + i) * 4 + (j & 3)] = real ? __double2float_rd(w) : __builtin_inff();
-        if (j >= dim) continue;
         float *p = params + (int64_t)j * kWords * s_pad;
         reinterpret_cast<double *>(p)[i] = 1.0 / (double)r;  // correctly rounded (IEEE double division)
         p[2 * s_pad + i] = r;
@@ -350,113 +341,40 @@ __global__ __launch_bounds__(256) void weighted_rows_kernel(const int64_t *__res
 }
 
 
-// ==== dense rows with a candidate filter ============================================================
-// weighted_minhash.py:216-218 evaluates every (sample, column).  Almost none of them can be the argmin, and one
-// subtraction proves it.  In real arithmetic t = floor(L/r + beta) <= L/r + beta, so ln_y = (t - beta + 1) r lies in
-// (L, L + r] and
-//         ln_a = ln_c - ln_y  >=  (ln_c - r) - L.
-// With float32 roundings (one per operation, relative error <= u = 2^-24 each; no overflow or underflow for the
-// ranges checked below) the same chain gives, with A = |L/r|:
-//     t - beta      <= L/r + u (2.01 A + 1)                      (quotient, sum; floor only lowers)
-//     u1 = t - beta <= L/r + u (3.02 A + 3),    v = u1 + 1 <= L/r + 1 + u (4.03 A + 6.01)
-//     ln_y = v r    <= L + r + u (5.04 |L| + 9.02 r)
-//     ln_a          >= (ln_c - r - L) - u (6.05 |L| + 12.04 r + |ln_c|).
-// The table word  w' = RD(ln_c - r - kappa (|ln_c| + r + 1)),  kappa = 32 u, is computed once in double and rounded
-// down; a wave tests  RN(w' - L) < thr'  with  thr' >= thr + kappa max|L|  (max over the finite logs of its rows,
-// from the pre-pass; thr = the smallest ln_a evaluated so far for that (row, sample), or +inf).  RN(w' - L) is at
-// most u (|w'| + |L|) above w' - L, so an element that fails the test has
-//     ln_a >= thr + (32 - 1 - 12.04) u (|L| + |ln_c| + r + 1) > thr >= the row's final minimum:
-// it is not the argmin and cannot tie with it.  Elements that pass ("candidates", 0.9 % of config 4) are evaluated
-// exactly as weighted_minhash.py does, so (k, t) is bit-identical whatever the filter lets through.
-// Ranges (checked: table at creation, logs by the pre-pass; anything else takes the exact kernel below):
-// 2^-40 <= r <= 2^40, |ln_c| <= 2^40, 0 <= beta <= 1; L = 0, +-inf or 2^-60 <= |L| <= 2^60, no NaN.
-// An absent entry of a dense row is L = -inf: w' - L = +inf never passes, no compaction to CSR is needed.
+// ==== dense rows: a walk over the columns in the order of a lower bound ===========================
+// weighted_minhash.py:216-229 evaluates every (sample, column) of a row and takes the argmin.  Here a row's argmin
+// costs a handful of evaluations per sample, and the (k, t) pairs are the reference's bit for bit.
 //
-// SIMD shape.  Samples on lanes; a wave owns R rows x 64 samples.  Per column group it loads the rows' logs
-// through the scalar path (wave-uniform) and w' for its lanes, and does one v_sub + one v_cmp per (row, column).
-// Candidates are rare per lane (1 %) but not per wave (28 % of the tests have one in SOME lane), so they are not
-// evaluated in place: the passing lanes append (lane, row, column) to a wave-private LDS queue (ballot + mbcnt
-// compaction), and when the queue fills it is drained 64 entries at a time, every lane evaluating whichever entry it
-// is handed (table entry and log by one gather each, IEEE division).  Results meet in LDS by a 64-bit atomic min of
-// (ordered ln_a << 32 | column): smallest ln_a, then smallest column -- np.argmin's first minimum, in any order.
+// The bound.  For one table entry (r > 0, ln_c, beta) the computed ln_a is a non-increasing function of the log L:
+// every step of :216-218 -- L / r, + beta, floor, - beta, + 1, * r, ln_c - . -- is a correctly rounded (hence
+// monotone) float32 operation or an exact monotone one, and r > 0.  So for every stored entry with L <= Lcut
+//         ln_a(L)  >=  LB = ln_a(Lcut)          (the same float32 arithmetic, evaluated once per table entry)
+// -- an exact inequality between float32 numbers, no slack.  Per sample the columns are sorted by LB (walk_build_kernel,
+// once per Lcut, kept on the generator).  A lane walks its sample's list from the smallest bound, evaluates the row's
+// entry at each column it meets (exactly: IEEE division, one rounding per operation) and keeps the smallest ln_a, ties
+// to the smaller column (np.argmin's first minimum).  It stops at the first column whose LB is larger than what it
+// holds: every column from there on has ln_a >= LB > best and can neither win nor tie.  Which columns can win is mostly a
+// property of the table (a small ln_c - r (1 - beta) ...), so the walk is short: 1.9 columns per (row, sample) on
+// config 4 (lock step of 64 lanes: 7 rounds) against 4096 evaluations.
+// Entries above Lcut ("outliers"; Lcut is a high quantile of a sample of the call's logs, walk_plan_kernel) are
+// evaluated first, directly.  A row with few stored entries (or too many outliers, or a NaN) is evaluated entry by
+// entry -- for a NaN row with numpy's rule (the first NaN wins).  Only speed depends on Lcut and on the data.
+//
+// SIMD shape.  One workgroup per row, one wave per 64 samples.  The row's logs are staged in LDS (taken here in
+// device-log mode; -inf = not stored: no CSR is built) while they are scanned for NaNs, outliers and the number of
+// stored entries: the matrix is read from HBM once, which is what bounds the kernel.  The walk tables are
+// [chunk][position][lane]: lanes are at the same position, so a round's table load is one coalesced 1-KB read; the
+// row's entries are per-lane LDS reads.
+struct WalkPlan {  // device-resident, owned by the generator
+    float lcut;       // the tables in d_walk_a / d_walk_c are sorted for this cut (NaN: never built)
+    int32_t rebuild;  // walk_plan_kernel's verdict for walk_build_kernel
+    float sample_max, sample_quantile;  // what the last plan saw (diagnostics)
+};
 
-typedef float vec2f __attribute__((ext_vector_type(2)));
-typedef float vec4f __attribute__((ext_vector_type(4)));
-typedef float vec16f __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ bool filter_sane_log(float l) {
-    const float m = fabsf(l);
-    return l == 0.0f || (m >= 0x1p-60f && m <= 0x1p60f) || m == __builtin_inff();  // false for NaN
-}
-
-// Where the pre-pass puts the log of (row r, column c) of a block of R rows, in floats from the block's start:
-// column pairs, then rows, then the two columns of the pair -- (L[r][c], L[r][c+1]) are one aligned 8-byte pair (the
-// scalar operand of a packed subtraction) and the R rows of a column pair one run of 2R floats (one scalar load).
-template <int R> __device__ __forceinline__ int64_t log_slot(int64_t c, int r) { return ((c >> 1) * R + r) * 2 + (c & 1); }
-
-// Pre-pass over a dense matrix, one wave per block of R rows: the logs (taken here in device-log mode) in the layout
-// above.  (Row-major logs fetched one row at a time did not fit the scalar cache: R rows x the waves of two CUs.)
-// A row missing from the last block and the odd column behind the last one are -inf (nothing stored).  Per block:
-// "bad" (a value the filter's proof does not cover) and the largest finite |log|; per row: whether it stores anything.
-template <bool LOGS, int R>
-__global__ __launch_bounds__(256) void weighted_dense_prepare_kernel(const float *__restrict__ x, int64_t n_rows, int32_t dim,
-                                                                     float *__restrict__ lt, uint8_t *__restrict__ blockbad,
-                                                                     float *__restrict__ blockmax, uint8_t *__restrict__ nonempty) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t n_blocks = (n_rows + R - 1) / R;
-    const int32_t dim2 = (dim + 1) & ~1;
-    for (int64_t blk = wave; blk < n_blocks; blk += n_waves) {
-        const int64_t row0 = blk * R;
-        bool bad = false;
-        uint32_t present = 0;  // bit r: row r stores something in this lane's columns
-        float maxabs = 0.0f;
-        for (int c0 = 0; c0 < dim2; c0 += kWave) {
-            const int c = c0 + lane;
-            float l[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const bool in = c < dim && row0 + r < n_rows;
-                const float v = in ? x[(row0 + r) * dim + c] : (LOGS ? -__builtin_inff() : 0.0f);
-                l[r] = LOGS ? v : logf(v);
-                if (LOGS ? !(l[r] == -__builtin_inff()) : (v != 0.0f)) present |= 1u << r;
-                bad |= !filter_sane_log(l[r]);
-                const float m = fabsf(l[r]);
-                if (m < __builtin_inff()) maxabs = fmaxf(maxabs, m);
-            }
-            // the even lane of a column pair stores the pair's rows 0 .. R/2-1, the odd lane rows R/2 .. R-1: R floats each
-            float mine[R / 2], theirs[R / 2];
-#pragma unroll
-            for (int h = 0; h < R / 2; ++h) {
-                const float keep = (lane & 1) ? l[R / 2 + h] : l[h];
-                const float give = (lane & 1) ? l[h] : l[R / 2 + h];
-                mine[h] = keep;
-                theirs[h] = __shfl_xor(give, 1);
-            }
-            if (c < dim2) {
-                float *dst = lt + (blk * dim2 + (c & ~1)) * R + (lane & 1) * R;
-#pragma unroll
-                for (int h = 0; h < R / 2; h += 2) {
-                    const vec4f q = (lane & 1) ? vec4f{theirs[h], mine[h], theirs[h + 1], mine[h + 1]}
-                                               : vec4f{mine[h], theirs[h], mine[h + 1], theirs[h + 1]};
-                    *reinterpret_cast<vec4f *>(dst + 2 * h) = q;
-                }
-            }
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            maxabs = fmaxf(maxabs, __shfl_xor(maxabs, o));
-            present |= (uint32_t)__shfl_xor((int)present, o);
-        }
-        bad = __any(bad);
-        if (lane == 0) {
-            blockbad[blk] = bad ? 1 : 0;
-            blockmax[blk] = maxabs;
-        }
-        if (lane < R && row0 + lane < n_rows) nonempty[row0 + lane] = (present >> lane) & 1u;
-    }
-}
+constexpr int kHistBits = 14;  // sign, exponent and 5 mantissa bits of the order-preserving integer image of a float
+constexpr float kCutTail = 0.005f;   // Lcut = the (1 - kCutTail) quantile of the sampled logs ...
+constexpr float kCutSlack = 0.7f;    // ... or their maximum when that is less than this above the quantile
+constexpr float kCutKeep = 0.35f;    // tables built for a cut in [wanted, wanted + kCutKeep] are kept
 
 __device__ __forceinline__ uint32_t ordered_bits(float f) {  // unsigned order == float order (no NaN here)
     const uint32_t b = __float_as_uint(f);
@@ -466,283 +384,364 @@ __device__ __forceinline__ float from_ordered_bits(uint32_t o) {
     return __uint_as_float(o ^ ((o >> 31) ? 0x80000000u : 0xFFFFFFFFu));
 }
 
-// d = (w - l) - (t, t): two tests in two packed instructions; w per lane, l a scalar pair, t one float of a per-lane
-// pair (HI selects which).  One rounding per subtraction, as the proof in the header assumes.
-template <int HI> __device__ __forceinline__ vec2f two_tests(vec2f w, vec2f l, vec2f t) {
-    vec2f d;
-    if constexpr (HI == 0)
-        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
-            "v_pk_add_f32 %0, %0, %3 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]"
-            : "=&v"(d) : "v"(w), "s"(l), "v"(t));
-    else
-        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
-            "v_pk_add_f32 %0, %0, %3 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]"
-            : "=&v"(d) : "v"(w), "s"(l), "v"(t));
-    return d;
+__device__ __forceinline__ Entry entry_of(const float4 e) {
+    Entry en;
+    en.rcp = 0.0;
+    en.r = e.x;
+    en.ln_c = e.y;
+    en.beta = e.z;
+    return en;
 }
 
-// The filter kernel: one wave per (block of R rows, 64 samples).  A batch is 4 columns x R rows = 32 tests (R = 8); the
-// signs of the 32 differences are shifted into one mask per lane (v_alignbit), so the hot loop is branch-free
-// packed arithmetic: a branch per test costs a wave ~50 cycles between the compare and the jump
-// (tools/ubench_filter.hip).  After the batch the set bits are appended to the wave's queue: one round per bit of the
-// fullest lane (ballot + mbcnt compaction).
-template <int R>
-__global__ __launch_bounds__(64) void weighted_dense_filter_kernel(const float *__restrict__ lt_, int64_t n_rows, int32_t dim,
-                                                                   const uint8_t *__restrict__ blockbad_,
-                                                                   const float *__restrict__ blockmax_,
-                                                                   const float *__restrict__ wtab,
-                                                                   const float4 *__restrict__ aos, int32_t sample_size,
-                                                                   int32_t s_pad, int64_t *__restrict__ out, int32_t debug) {
-    static_assert(R == 8, "a batch of 4 columns x R rows fills one 32-bit mask");
-    constexpr unsigned long long kEmpty = ~0ull;
-    constexpr int kCap = 512;  // queue entries; drained before an append could overflow it
-    __shared__ unsigned long long state[R * kWave];
-    __shared__ uint32_t queue[kCap];
-    const int lane = threadIdx.x;
-    const uint8_t MHX_CONST_AS *blockbad = (const uint8_t MHX_CONST_AS *)blockbad_;
-    const float MHX_CONST_AS *blockmax = (const float MHX_CONST_AS *)blockmax_;
-    const int32_t chunks = s_pad / kWave;
-    const int32_t dim2 = (dim + 1) & ~1;
-    const int32_t dim4 = (dim + 3) & ~3;
-    const int64_t n_blocks = (n_rows + R - 1) / R;
-    // a wave keeps its 64 samples and walks over blocks: the columns that won in its previous block are evaluated first in
-    // the next one (below); gridDim.x is a multiple of chunks
-    const int32_t ch = (int32_t)(blockIdx.x % (uint32_t)chunks);
-    uint32_t prevc[R];
-    bool have_prev = false;
-    for (int64_t blk = blockIdx.x / (uint32_t)chunks; blk < n_blocks; blk += gridDim.x / (uint32_t)chunks) {
-        if (blockbad[blk]) continue;  // weighted_dense_exact_kernel's rows
-        const int64_t row0 = blk * R;
-        const float slack = kKappa * blockmax[blk];
-        const int32_t my = ch * kWave + lane;  // sample of this lane
-        const float MHX_CONST_AS *ls = (const float MHX_CONST_AS *)(lt_ + blk * dim2 * R);
-        const float *lv_base = lt_ + blk * dim2 * R;
-        vec2f thr[R / 2];  // thr[r / 2][r % 2]
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            // "no bound yet" is the largest finite float, not +inf: an absent entry's +inf minus +inf would be a NaN, whose sign
-            // bit (set, on this hardware) would count as a pass
-            thr[r / 2][r % 2] = debug == 1 ? -__builtin_inff() : __FLT_MAX__;  // debug 1 (profiling only): nothing ever passes
-            state[r * kWave + lane] = kEmpty;
+// One workgroup: histogram of n_seg runs of seg_len values spread over v[0 .. total), then the cut.
+template <bool LOGS>
+__global__ __launch_bounds__(1024) void walk_plan_kernel(const float *__restrict__ v, int64_t total, int32_t seg_len, int32_t n_seg,
+                                                         WalkPlan *__restrict__ plan) {
+    __shared__ uint32_t hist[1 << kHistBits];
+    __shared__ uint32_t part[1024];
+    __shared__ uint32_t s_top, s_cut, s_total;
+    const int tid = threadIdx.x;
+    for (int b = tid; b < (1 << kHistBits); b += 1024) hist[b] = 0;
+    if (tid == 0) s_top = 0, s_cut = 0, s_total = 0;
+    __syncthreads();
+    const int64_t span = total - seg_len;
+    for (int sgm = 0; sgm < n_seg; ++sgm) {
+        const int64_t start = n_seg > 1 ? span * sgm / (n_seg - 1) : 0;
+        for (int j = tid; j < seg_len; j += 1024) {
+            float l = v[start + j];
+            if (!LOGS) l = logf(l);
+            if (fabsf(l) < __builtin_inff()) atomicAdd(&hist[ordered_bits(l) >> (32 - kHistBits)], 1u);  // finite, not NaN
         }
-        uint32_t count = 0;  // queue entries; wave-uniform (kept in an SGPR by the readfirstlane at every update)
-        __builtin_amdgcn_wave_barrier();
-
-        // the thresholds of this lane's sample from the state: the smallest ln_a evaluated so far + the filter's slack
-        const auto refresh = [&]() {
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const uint32_t hi = (uint32_t)(state[r * kWave + lane] >> 32);
-                const float best = from_ordered_bits(hi);
-                float up = best + slack;
-                up = up + fabsf(up) * 0x1p-22f;  // at least one float above thr + slack
-                thr[r / 2][r % 2] = hi == 0xFFFFFFFFu ? __FLT_MAX__ : (fabsf(best) == __builtin_inff() ? best : up);
-                if (debug == 1) thr[r / 2][r % 2] = -__builtin_inff();
-            }
-        };
-        // Four queue entries per lane and round: their gathers are in flight together (a round is a chain of two
-        // dependent memory accesses otherwise).  A lane without an entry works on a copy of entry 0 and drops the result.
-        // An entry is (test number << 6 | lane), test number = batch * 32 + column pair * 16 + row * 2 + column in the pair.
-        const auto drain = [&]() {
-            __builtin_amdgcn_wave_barrier();
-            constexpr int kU = 4;
-            for (uint32_t b = 0; b < count; b += kU * kWave) {
-                uint32_t e[kU];
-                float4 ent[kU];
-                float lv[kU];
-#pragma unroll
-                for (int u = 0; u < kU; ++u) {
-                    const uint32_t idx = b + u * kWave + lane;
-                    e[u] = queue[idx < count ? idx : 0];
-                }
-#pragma unroll
-                for (int u = 0; u < kU; ++u) {
-                    const uint32_t il = e[u] & 63u, t = e[u] >> 6;
-                    const uint32_t c = (t >> 5) * 4 + ((t >> 3) & 2) + (t & 1), r = (t >> 1) & 7;
-                    ent[u] = aos[(int64_t)(c < (uint32_t)dim ? c : 0u) * s_pad + ch * kWave + il];
-                    lv[u] = lv_base[log_slot<R>(c, (int)r)];
-                }
-#pragma unroll
-                for (int u = 0; u < kU; ++u) {
-                    const uint32_t idx = b + u * kWave + lane;
-                    const uint32_t il = e[u] & 63u, t = e[u] >> 6;
-                    const uint32_t c = (t >> 5) * 4 + ((t >> 3) & 2) + (t & 1), r = (t >> 1) & 7;
-                    Entry en;
-                    en.rcp = 0.0;
-                    en.r = ent[u].x;
-                    en.ln_c = ent[u].y;
-                    en.beta = ent[u].z;
-                    float tt, ln_a;
-                    evaluate<false>(lv[u], en, tt, ln_a);
-                    const unsigned long long key = ((unsigned long long)ordered_bits(ln_a + 0.0f) << 32) | c;
-                    // c >= dim: a padding column let through by a NaN (inf - inf against whatever lies behind the block's logs)
-                    const bool real = idx < count && c < (uint32_t)dim;
-                    atomicMin(&state[real ? r * kWave + il : (uint32_t)lane], real ? key : kEmpty);
-                }
-            }
-            count = 0;
-            __builtin_amdgcn_wave_barrier();
-            refresh();
-        };
-
-        // Warm-up: the columns that won the R rows of this wave's previous block, evaluated here for every row before the
-        // scan.  Which columns win is mostly a property of the table (a small ln_c - r (1 - beta)), so the thresholds start
-        // within rounding of their final values and the scan queues 10 candidates per (row, sample) instead of 36
-        // (config 4; 8.1 if the minimum were known in advance).  Only efficiency depends on it.
-        if (have_prev) {
-#pragma unroll
-            for (int k = 0; k < R; ++k) {
-                const uint32_t c = prevc[k];
-                const float4 ent = aos[(int64_t)c * s_pad + my];
-                Entry en;
-                en.rcp = 0.0;
-                en.r = ent.x;
-                en.ln_c = ent.y;
-                en.beta = ent.z;
-                const vec4f *src = reinterpret_cast<const vec4f *>(lv_base + (int64_t)(c >> 1) * (2 * R));  // the pair's 2R logs
-#pragma unroll
-                for (int q = 0; q < R / 2; ++q) {
-                    const vec4f v = src[q];  // rows 2q, 2q + 1: (c & ~1, c | 1) each
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const int r = 2 * q + h;
-                        const float lv = (c & 1) ? v[2 * h + 1] : v[2 * h];
-                        float tt, ln_a;
-                        evaluate<false>(lv, en, tt, ln_a);
-                        const unsigned long long key = ((unsigned long long)ordered_bits(ln_a + 0.0f) << 32) | c;
-                        unsigned long long &st = state[r * kWave + lane];
-                        if (!(lv == -__builtin_inff()) && key < st) st = key;  // an absent entry is never a candidate
-                    }
-                }
-            }
-            refresh();
-        }
-
-        // 16 tests: R rows x one column pair; bit 15 - t of the result is the sign of test t = row * 2 + column
-        const auto half_batch = [&](const vec16f &l, vec2f w) {
-            uint32_t ma = 0, mb = 0;  // two chains of dependent alignbits
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const vec2f lr = {l[2 * r], l[2 * r + 1]};
-                const vec2f d = (r & 1) ? two_tests<1>(w, lr, thr[r / 2]) : two_tests<0>(w, lr, thr[r / 2]);
-                uint32_t &m = r < R / 2 ? ma : mb;
-                m = __builtin_amdgcn_alignbit(m, __float_as_uint(d.x), 31);
-                m = __builtin_amdgcn_alignbit(m, __float_as_uint(d.y), 31);
-            }
-            return (ma << 8) | mb;
-        };
-        // the set bits of the lanes' masks -> queue entries, one round per bit of the fullest lane
-        const auto append = [&](uint32_t mask, uint32_t batch_no) {
-            for (;;) {
-                const unsigned long long m = __ballot(mask != 0);
-                if (!m) break;
-                const uint32_t pc = (uint32_t)__popcll(m);
-                if (count + pc > (uint32_t)kCap) drain();
-                if (mask != 0) {
-                    const uint32_t t = (uint32_t)__builtin_clz(mask);
-                    const uint32_t slot = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    queue[count + slot] = ((batch_no * 32u + t) << 6) | (uint32_t)lane;
-                    mask &= ~(0x80000000u >> t);
-                }
-                count = __builtin_amdgcn_readfirstlane(count + pc);
-            }
-        };
-        const auto load_w = [&](int32_t c) {  // the 4 table words of this lane, columns c .. c + 3 (c a multiple of 4)
-            return *reinterpret_cast<const vec4f *>(wtab + ((int64_t)(c >> 2) * s_pad + my) * 4);
-        };
-        const auto load_l = [&](int32_t c) {  // 2 columns x R rows (c even): one scalar load
-            return *reinterpret_cast<const vec16f MHX_CONST_AS *>(ls + (int64_t)c * R);
-        };
-
-        // dim4 columns in whole batches (the table is padded with +inf words, the log tile with -inf: they never pass;
-        // behind the block's last column pair the tile reads into the next block or the buffer's padding)
-        // The two column pairs' tiles are reloaded as soon as their 16 tests are done (two tiles of SGPRs, not four); the
-        // scheduling barriers keep the loads where they are written: a whole half batch ahead of their use.
-        vec16f l01 = load_l(0), l23 = load_l(2);
-        vec4f w = load_w(0), w1 = load_w(4 < dim4 ? 4 : 0);  // the table words run two batches ahead
-        for (int32_t c = 0; c < dim4; c += 4) {
-            const int32_t cn = c + 4 < dim4 ? c + 4 : c;  // clamped prefetches
-            const vec4f w2 = load_w(c + 8 < dim4 ? c + 8 : c);
-            const uint32_t m01 = half_batch(l01, vec2f{w.x, w.y});
-            __builtin_amdgcn_sched_barrier(0);
-            l01 = load_l(cn);
-            __builtin_amdgcn_sched_barrier(0);
-            const uint32_t m23 = half_batch(l23, vec2f{w.z, w.w});
-            __builtin_amdgcn_sched_barrier(0);
-            l23 = load_l(cn + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            append((m01 << 16) | m23, (uint32_t)c >> 2);
-            w = w1, w1 = w2;
-        }
-        drain();
-
-        // the winners: (k, t) of every (row, sample); t is recomputed from the winning column (same arithmetic)
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if (row0 + r < n_rows) {
-                const unsigned long long key = state[r * kWave + lane];
-                int64_t k = 0, tt = 0;
-                if (key != kEmpty) {
-                    const uint32_t c = (uint32_t)key;
-                    const float4 ent = aos[(int64_t)c * s_pad + my];
-                    const float lv = lv_base[log_slot<R>(c, r)];
-                    Entry en;
-                    en.rcp = 0.0;
-                    en.r = ent.x;
-                    en.ln_c = ent.y;
-                    en.beta = ent.z;
-                    float t, ln_a;
-                    evaluate<false>(lv, en, t, ln_a);
-                    k = c;
-                    tt = (int64_t)t;
-                }
-                if (my < sample_size) {
-                    int64_t *o = out + ((row0 + r) * sample_size + my) * 2;
-                    o[0] = k;
-                    o[1] = tt;
-                }
-            }
-            const unsigned long long key = state[r * kWave + lane];
-            prevc[r] = key != kEmpty ? (uint32_t)key : (have_prev ? prevc[r] : 0u);
-        }
-        have_prev = true;
-        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // thread t owns bins [16 t, 16 t + 16); suffix sums over the threads, then inside the thread's bins from the top
+    constexpr int kPer = (1 << kHistBits) / 1024;
+    uint32_t mine = 0;
+    for (int b = 0; b < kPer; ++b) mine += hist[tid * kPer + b];
+    part[tid] = mine;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {  // inclusive suffix scan (Hillis-Steele)
+        const uint32_t add = tid + o < 1024 ? part[tid + o] : 0;
+        __syncthreads();
+        part[tid] += add;
+        __syncthreads();
+    }
+    const uint32_t all = part[0];
+    uint32_t above = tid + 1 < 1024 ? part[tid + 1] : 0;  // values in bins above this thread's
+    const uint32_t tail = (uint32_t)((float)all * kCutTail);
+    for (int b = kPer - 1; b >= 0; --b) {
+        const uint32_t h = hist[tid * kPer + b];
+        if (h) atomicMax(&s_top, (uint32_t)(tid * kPer + b));
+        if (above <= tail && above + h > tail) s_cut = (uint32_t)(tid * kPer + b);  // the bin holding the quantile: one thread
+        above += h;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // the largest float of a bin: every sampled value of the bin is <= it
+        const auto upper = [](uint32_t bin) { return from_ordered_bits(((bin + 1u) << (32 - kHistBits)) - 1u); };
+        float top = all ? upper(s_top) : 0.0f, q = all ? upper(s_cut) : 0.0f;
+        if (!(top < __builtin_inff())) top = __FLT_MAX__;
+        if (!(q < __builtin_inff())) q = __FLT_MAX__;
+        const float want = top - q < kCutSlack ? top : q;
+        const float have = plan->lcut;
+        const bool keep = have >= want && have - want <= kCutKeep;  // false for the initial NaN
+        plan->rebuild = keep ? 0 : 1;
+        if (!keep) plan->lcut = want;
+        plan->sample_max = top;
+        plan->sample_quantile = q;
     }
 }
 
-// rows of blocks the filter kernel leaves alone (a NaN or a log outside the proven range somewhere in the block):
-// every stored entry evaluated with the IEEE division, numpy's NaN rule; one wave per (row, 64 samples)
-template <int R>
-__global__ __launch_bounds__(256) void weighted_dense_exact_kernel(const float *__restrict__ lt_, int64_t n_rows, int32_t dim,
-                                                                   const uint8_t *__restrict__ blockbad_,
-                                                                   const float *__restrict__ params, int32_t sample_size,
-                                                                   int32_t s_pad, int64_t *__restrict__ out) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int waves_per_block = blockDim.x >> 6;
-    const int i = blockIdx.y * kWave + lane;
-    const uint8_t MHX_CONST_AS *blockbad = (const uint8_t MHX_CONST_AS *)blockbad_;
-    const float MHX_CONST_AS *lt = (const float MHX_CONST_AS *)lt_;
-    for (int64_t row = (int64_t)blockIdx.x * waves_per_block + wave; row < n_rows; row += (int64_t)gridDim.x * waves_per_block) {
-        const int64_t blk = row / R;
-        if (!blockbad[blk]) continue;  // done by the filter kernel
-        const int32_t dim2 = (dim + 1) & ~1;
-        const float MHX_CONST_AS *l = lt + blk * dim2 * R;
-        const int rr = (int)(row - blk * R);
-        Best best;
-        best.ln_a = 0.0f;
-        best.t = 0.0f;
-        best.k = -1;
-        for (int32_t c = 0; c < dim; ++c) {
-            const float lv = l[log_slot<R>(c, rr)];
-            if (lv == -__builtin_inff()) continue;  // not stored
-            consider(best, lv, load_entry(params, c, s_pad, i), c);
+// One workgroup per sample: LB of every column at the plan's cut, a bitonic sort of (LB, column) in LDS, the walk
+// tables.  P = dim rounded up to a power of two (8 P bytes of LDS).
+__global__ __launch_bounds__(256) void walk_build_kernel(const WalkPlan *__restrict__ plan, const float4 *__restrict__ aos, int32_t dim,
+                                                         int32_t p2, int32_t s_pad, float4 *__restrict__ walk_a,
+                                                         uint32_t *__restrict__ walk_c) {
+    extern __shared__ unsigned long long keys[];
+    if (!plan->rebuild) return;
+    const float lcut = plan->lcut;
+    const int i = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < p2; c += 256) {
+        unsigned long long key = ~0ull;
+        if (c < dim) {
+            float t, ln_a;
+            evaluate<false>(lcut, entry_of(aos[(int64_t)c * s_pad + i]), t, ln_a);
+            key = ((unsigned long long)ordered_bits(ln_a + 0.0f) << 32) | (uint32_t)c;
         }
-        if (i < sample_size) {
-            int64_t *o = out + (row * sample_size + i) * 2;
-            o[0] = best.k < 0 ? 0 : best.k;
-            o[1] = best.k < 0 ? 0 : (int64_t)best.t;
+        keys[c] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= p2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < p2 / 2; t += 256) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const unsigned long long a = keys[lo], b = keys[hi];
+                const bool up = (lo & k) == 0;
+                if ((a > b) == up) {
+                    keys[lo] = b;
+                    keys[hi] = a;
+                }
+            }
+            __syncthreads();
         }
+    }
+    const int64_t base = (int64_t)(i / kWave) * dim * kWave + (i % kWave);
+    for (int k = tid; k < dim; k += 256) {
+        const uint32_t c = (uint32_t)keys[k];
+        const float4 e = aos[(int64_t)c * s_pad + i];
+        walk_a[base + (int64_t)k * kWave] = make_float4(from_ordered_bits((uint32_t)(keys[k] >> 32)), e.x, e.y, e.z);
+        walk_c[base + (int64_t)k * kWave] = c;
+    }
+}
+
+// what a lane holds for its sample: the smallest ln_a so far, its column (ties: the smaller one) and its t
+struct Held {
+    float ln_a = __builtin_inff();
+    float t = 0.0f;
+    uint32_t c = 0xFFFFFFFFu;
+    __device__ __forceinline__ void take(float a, float tt, uint32_t col) {
+        if (a < ln_a || (a == ln_a && col < c)) ln_a = a, t = tt, c = col;
+    }
+    __device__ __forceinline__ void offer(float l, const float4 e, uint32_t col) {  // e = {r, ln_c, beta, .}
+        float tt, a;
+        evaluate<false>(l, entry_of(e), tt, a);
+        take(a, tt, col);
+    }
+};
+
+constexpr int kWalkCached = 8;  // list positions per 64-sample chunk a workgroup keeps in LDS (1.25 KB each)
+constexpr int kCachedChunks = 4;
+
+// The second half of a row, one wave per 64 samples: the row's logs are in LDS (row[c]; -inf: not stored), `list` holds
+// n_list columns -- every stored one (all_listed: the row is evaluated entry by entry) or the ones above the cut, which
+// are evaluated before the walk.
+__device__ __forceinline__ void walk_row(const float *row, const uint16_t *list, int n_list, bool all_listed, int32_t dim, int32_t ch,
+                                         int32_t my, int32_t sample_size, const float4 *__restrict__ walk_a,
+                                         const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos, int32_t s_pad,
+                                         const float4 *cache_a, const uint32_t *cache_c, int64_t &k_out, int64_t &t_out) {
+    Held held;
+    int j = 0;
+    for (; j + 4 <= n_list; j += 4) {  // four table entries in flight
+        uint32_t c[4];
+        float4 e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = list[j + u], e[u] = aos[(int64_t)c[u] * s_pad + my];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) held.offer(row[c[u]], e[u], c[u]);
+    }
+    for (; j < n_list; ++j) {
+        const uint32_t c = list[j];
+        held.offer(row[c], aos[(int64_t)c * s_pad + my], c);
+    }
+    if (!all_listed) {
+        const int lane = my & (kWave - 1);
+        const float4 *wa = walk_a + (int64_t)ch * dim * kWave + lane;
+        const uint32_t *wc = walk_c + (int64_t)ch * dim * kWave + lane;
+        bool done = my >= sample_size;
+        int32_t k = 0;
+        // the first positions of the lists are the same for every row: this workgroup keeps them in LDS (a load from the
+        // L2 behind the rows' stream takes microseconds; most walks end inside the cached positions)
+        constexpr int kU = 4;  // positions per round: evaluated side by side (independent division chains), then taken in order
+        const int32_t n_cached = cache_a ? (dim < kWalkCached ? dim : kWalkCached) / kU * kU : 0;
+        for (; k < n_cached; k += kU) {
+            float4 e[kU];
+            uint32_t c[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) e[u] = cache_a[(k + u) * kWave + lane], c[u] = cache_c[(k + u) * kWave + lane];
+            done = done || e[0].x > held.ln_a;  // an equal bound may still hide a tie at a smaller column
+            if (!__any(!done)) break;
+            if (!done) {
+                float l[kU], t[kU], a[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    l[u] = row[c[u]];
+                    evaluate<false>(l[u], entry_of(make_float4(e[u].y, e[u].z, e[u].w, 0.0f)), t[u], a[u]);  // e = {LB, r, ln_c, beta}
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    done = done || e[u].x > held.ln_a;
+                    if (!done && !(l[u] == -__builtin_inff())) held.take(a[u], t[u], c[u]);
+                }
+            }
+        }
+        if (k == n_cached && k < dim && __any(!done)) {
+            float4 e = wa[(int64_t)k * kWave];
+            uint32_t c = wc[(int64_t)k * kWave];
+            for (; k < dim; ++k) {
+                const int32_t kn = k + 1 < dim ? k + 1 : k;  // the next position's entry is on its way
+                const float4 e_next = wa[(int64_t)kn * kWave];
+                const uint32_t c_next = wc[(int64_t)kn * kWave];
+                done = done || e.x > held.ln_a;
+                if (!__any(!done)) break;
+                if (!done) {
+                    const float l = row[c];
+                    if (!(l == -__builtin_inff())) held.offer(l, make_float4(e.y, e.z, e.w, 0.0f), c);
+                }
+                e = e_next, c = c_next;
+            }
+        }
+    }
+    k_out = held.c, t_out = (int64_t)held.t;
+}
+
+// a row with a NaN among its logs: numpy's argmin, the first NaN wins (every stored entry, in column order)
+__device__ __forceinline__ void nan_row(const float *row, int32_t dim, int32_t my, const float4 *__restrict__ aos, int32_t s_pad,
+                                        int64_t &k_out, int64_t &t_out) {
+    Best best;
+    best.ln_a = 0.0f, best.t = 0.0f, best.k = -1;
+    for (int32_t c = 0; c < dim; ++c) {
+        const float l = row[c];
+        if (l == -__builtin_inff()) continue;
+        consider(best, l, entry_of(aos[(int64_t)c * s_pad + my]), c);
+    }
+    k_out = best.k, t_out = (int64_t)best.t;
+}
+
+constexpr int kPre = 4;    // 16-byte loads per thread that hold a row (256 threads: dim <= 4096)
+constexpr int kAhead = 3;  // rows fetched ahead of the one being walked: the bytes in flight that HBM wants (48 KB per workgroup)
+
+template <bool LOGS, bool AHEAD>
+__global__ __launch_bounds__(256) void weighted_walk_dense_kernel(const float *__restrict__ x, int64_t n_rows, int32_t dim,
+                                                                  const WalkPlan *__restrict__ plan,
+                                                                  const float4 *__restrict__ walk_a,
+                                                                  const uint32_t *__restrict__ walk_c,
+                                                                  const float4 *__restrict__ aos, int32_t sample_size,
+                                                                  int32_t s_pad, int32_t list_cap, int32_t direct_permille,
+                                                                  int64_t *__restrict__ out, uint8_t *__restrict__ nonempty, int32_t debug) {
+    extern __shared__ float row[];                                             // dim logs of the row (-inf: not stored)
+    uint16_t *list = reinterpret_cast<uint16_t *>(row + ((dim + 3) & ~3));    // columns (list_cap of them)
+    __shared__ int s_nnz, s_nout, s_nan;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), n_waves = blockDim.x >> 6;
+    const int32_t chunks = s_pad / kWave;
+    const float lcut = plan->lcut;
+    // behind the row and the list (16-byte aligned): the cached list positions of the first n_cc chunks
+    const int32_t n_cc = chunks < kCachedChunks ? chunks : kCachedChunks;
+    float4 *s_cache_a = reinterpret_cast<float4 *>(row + ((dim + 3) & ~3) + ((list_cap + 7) & ~7) / 2);
+    uint32_t *s_cache_c = reinterpret_cast<uint32_t *>(s_cache_a + n_cc * kWalkCached * kWave);
+    for (int j = tid; j < n_cc * kWalkCached * kWave; j += blockDim.x) {
+        const int ch = j / (kWalkCached * kWave), k = j / kWave % kWalkCached;
+        if (ch < chunks && k < dim) {
+            s_cache_a[j] = walk_a[((int64_t)ch * dim + k) * kWave + (j & (kWave - 1))];
+            s_cache_c[j] = walk_c[((int64_t)ch * dim + k) * kWave + (j & (kWave - 1))];
+        }
+    }
+    // AHEAD: 16-byte loads and a whole row in kPre of them per thread (the launcher checked): rows are fetched kAhead rows
+    // ahead, into registers.  Every thread always issues exactly kPre loads per row (clamped to the matrix), so that the
+    // number of loads in flight behind a row's is known at compile time: otherwise the wait for a row's registers is a
+    // wait for every load issued since, the next rows' included, and nothing is ahead of anything.
+    const bool wide = AHEAD || ((dim & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    const int64_t stride = gridDim.x;
+    const auto fetch = [&](float4 (&pre)[kPre], int64_t d) {
+        const float *src = x + (d < n_rows ? d : n_rows - 1) * dim;
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int c = (u * (int)blockDim.x + tid) * 4;
+            pre[u] = *reinterpret_cast<const float4 *>(src + (c < dim ? c : dim - 4));
+        }
+    };
+    // one row: its logs from `pre` (or memory) into LDS, then `pre` refilled with the row kAhead strides on, then the walk
+    const auto one_row = [&](float4 (&pre)[kPre], int64_t d) {
+        if (tid == 0) s_nnz = 0, s_nout = 0, s_nan = 0;
+        __syncthreads();
+        int nnz = 0;
+        bool nan = false;
+        const auto take = [&](int c, float v) -> float {
+            const float l = LOGS ? v : logf(v);
+            const bool stored = LOGS ? !(l == -__builtin_inff()) : (v != 0.0f);  // scipy's nonzero(): NaN stays
+            nnz += stored;
+            nan |= l != l;
+            if (l > lcut) {  // +inf too
+                const int at = atomicAdd(&s_nout, 1);
+                if (at < list_cap) list[at] = (uint16_t)c;
+            }
+            return stored ? l : -__builtin_inff();
+        };
+        const auto take4 = [&](int c, const float4 v) {
+            if (debug == 2) {  // profiling only: the copy without the scan
+                *reinterpret_cast<float4 *>(row + c) = v;
+                nnz += 4;
+                return;
+            }
+            float4 l;
+            l.x = take(c, v.x), l.y = take(c + 1, v.y), l.z = take(c + 2, v.z), l.w = take(c + 3, v.w);
+            *reinterpret_cast<float4 *>(row + c) = l;
+        };
+        if (AHEAD) {
+#pragma unroll
+            for (int u = 0; u < kPre; ++u) {
+                const int c = (u * (int)blockDim.x + tid) * 4;
+                if (c < dim) take4(c, pre[u]);
+            }
+        } else if (wide) {
+            for (int c = tid * 4; c < dim; c += blockDim.x * 4) take4(c, *reinterpret_cast<const float4 *>(x + d * dim + c));
+        } else {
+            for (int c = tid; c < dim; c += blockDim.x) row[c] = take(c, x[d * dim + c]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) nnz += __shfl_xor(nnz, o);
+        if (lane == 0 && nnz) atomicAdd(&s_nnz, nnz);
+        if (__any(nan) && lane == 0) s_nan = 1;
+        __syncthreads();
+        const int n_stored = s_nnz, n_out = s_nout;
+        int n_list = n_out;
+        const bool has_nan = s_nan != 0;
+        // A row with few stored entries is cheaper entry by entry than through the walk, which meets its absent columns
+        // too; a row with more entries above the cut than the list holds has no valid stop rule: entry by entry as well.
+        bool by_entry = n_out > list_cap || (int64_t)n_stored * 1000 <= (int64_t)direct_permille * dim;
+        const bool listable = by_entry && !has_nan && n_stored > 0 && n_stored <= list_cap;
+        if (listable) {  // list the stored columns (in any order)
+            __syncthreads();
+            if (tid == 0) s_nout = 0;
+            __syncthreads();
+            for (int c = tid; c < dim; c += blockDim.x)
+                if (!(row[c] == -__builtin_inff())) list[atomicAdd(&s_nout, 1)] = (uint16_t)c;
+            __syncthreads();
+            n_list = n_stored;
+        }
+        for (int32_t ch = wave; ch < chunks; ch += n_waves) {
+            const int32_t my = ch * kWave + lane;
+            int64_t k_out = 0, t_out = 0;
+            if (n_stored == 0) {
+                // nothing stored: (0, 0), and the row is reported empty
+            } else if (has_nan) {
+                nan_row(row, dim, my, aos, s_pad, k_out, t_out);
+            } else if (by_entry && !listable) {  // every stored entry, in column order
+                Held held;
+                for (int32_t c = 0; c < dim; ++c) {
+                    const float l = row[c];
+                    if (!(l == -__builtin_inff())) held.offer(l, aos[(int64_t)c * s_pad + my], (uint32_t)c);
+                }
+                k_out = held.c, t_out = (int64_t)held.t;
+            } else if (debug != 1) {
+                walk_row(row, list, n_list, by_entry, dim, ch, my, sample_size, walk_a, walk_c, aos, s_pad,
+                         ch < n_cc ? s_cache_a + ch * kWalkCached * kWave : nullptr,
+                         ch < n_cc ? s_cache_c + ch * kWalkCached * kWave : nullptr, k_out, t_out);
+            }
+            if (my < sample_size) {
+                int64_t *o = out + (d * sample_size + my) * 2;
+                o[0] = k_out;
+                o[1] = t_out;
+            }
+        }
+        if (tid == 0) nonempty[d] = n_stored > 0 ? 1 : 0;
+        // The refill goes out behind the walk, not before it: vector loads complete in order, so a wait for one of the
+        // walk's own loads would otherwise sit out the whole HBM latency of a row that is not needed for three rows.
+        if (AHEAD) fetch(pre, d + kAhead * stride);
+        __syncthreads();
+    };
+    float4 pre0[kPre], pre1[kPre], pre2[kPre];
+    static_assert(kAhead == 3, "three register buffers below");
+    const int64_t d0 = blockIdx.x;
+    if (AHEAD) {
+        fetch(pre0, d0);
+        fetch(pre1, d0 + stride);
+        fetch(pre2, d0 + 2 * stride);
+    }
+    for (int64_t d = d0; d < n_rows; d += kAhead * stride) {
+        one_row(pre0, d);
+        if (d + stride < n_rows) one_row(pre1, d + stride);
+        if (d + 2 * stride < n_rows) one_row(pre2, d + 2 * stride);
     }
 }
 
@@ -750,11 +749,10 @@ __global__ __launch_bounds__(256) void weighted_dense_exact_kernel(const float *
 
 int launch_wgen_transpose(mhx_wgen *gen, const float *d_rs, const float *d_lncs, const float *d_betas) {
     mhx_ctx *ctx = gen->ctx;
-    const int64_t total = (int64_t)((gen->dim + 3) & ~3) * gen->s_pad;
+    const int64_t total = (int64_t)gen->dim * gen->s_pad;
     const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, (int64_t)ctx->num_cus * 8));
     hipLaunchKernelGGL(wgen_transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_rs, d_lncs,
-                       d_betas, gen->sample_size, gen->dim, gen->s_pad, gen->d_params, gen->d_wtab,
-                       reinterpret_cast<float4 *>(gen->d_aos));
+                       d_betas, gen->sample_size, gen->dim, gen->s_pad, gen->d_params, reinterpret_cast<float4 *>(gen->d_aos));
     MHX_HIP_CHECK(hipGetLastError());
     return MHX_OK;
 }
@@ -811,42 +809,46 @@ __global__ __launch_bounds__(256) void dense_compact_kernel(const float *__restr
     }
 }
 
-// dense rows through the candidate filter: no CSR is built (an absent entry is a log of -inf)
-static int launch_weighted_dense_filtered(mhx_wgen *gen, const float *d_x, int values_are_logs, int64_t n_rows, int64_t *d_out,
-                                          uint8_t *d_nonempty) {
-    constexpr int R = 8;
+// dense rows through the bound-ordered walk: plan (the cut for this call's data), tables (only when the cut moved), rows
+static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int values_are_logs, int64_t n_rows, int64_t *d_out,
+                                      uint8_t *d_nonempty) {
     mhx_ctx *ctx = gen->ctx;
     const int32_t dim = gen->dim;
-    const int64_t dim2 = (dim + 1) & ~1;
-    const int64_t n_blocks = (n_rows + R - 1) / R;
-    // scratch slot 3: blockbad u8[n_blocks] | blockmax f32[n_blocks] | the logs in the pre-pass's layout + two column pairs of padding
-    const size_t bad_bytes = ((size_t)n_blocks + 255) & ~(size_t)255;
-    const size_t max_bytes = (sizeof(float) * (size_t)n_blocks + 255) & ~(size_t)255;
-    const size_t lt_bytes = sizeof(float) * ((size_t)n_blocks * (size_t)dim2 * R + 4 * R);
-    if (int rc = ctx->ensure_scratch(3, bad_bytes + max_bytes + lt_bytes + 256)) return rc;
-    uint8_t *d_bad = (uint8_t *)ctx->scratch[3];
-    float *d_max = (float *)((char *)ctx->scratch[3] + bad_bytes);
-    float *d_lt = (float *)((char *)ctx->scratch[3] + bad_bytes + max_bytes);
-    const unsigned prep_blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((n_blocks + 3) / 4, (int64_t)ctx->num_cus * 32));
+    WalkPlan *plan = reinterpret_cast<WalkPlan *>(gen->d_walk_plan);
+    const int64_t total = n_rows * (int64_t)dim;
+    const int32_t n_seg = (int32_t)std::min<int64_t>(n_rows, std::max<int64_t>(1, (16 << 10) / dim));  // about 16k sampled logs
     if (values_are_logs)
-        hipLaunchKernelGGL((weighted_dense_prepare_kernel<true, R>), dim3(prep_blocks), dim3(256), 0, ctx->stream, d_x, n_rows, dim, d_lt,
-                           d_bad, d_max, d_nonempty);
+        hipLaunchKernelGGL(walk_plan_kernel<true>, dim3(1), dim3(1024), 0, ctx->stream, d_x, total, dim, n_seg, plan);
     else
-        hipLaunchKernelGGL((weighted_dense_prepare_kernel<false, R>), dim3(prep_blocks), dim3(256), 0, ctx->stream, d_x, n_rows, dim, d_lt,
-                           d_bad, d_max, d_nonempty);
+        hipLaunchKernelGGL(walk_plan_kernel<false>, dim3(1), dim3(1024), 0, ctx->stream, d_x, total, dim, n_seg, plan);
     MHX_HIP_CHECK(hipGetLastError());
-    const int64_t items = n_blocks * (gen->s_pad / kWave);
-    const int64_t per_cu = ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu : 24;
-    const int64_t chunks_ = gen->s_pad / kWave;
-    const unsigned blocks = (unsigned)std::max<int64_t>(chunks_, std::min<int64_t>(items, per_cu * ctx->num_cus / chunks_ * chunks_));
-    hipLaunchKernelGGL((weighted_dense_filter_kernel<R>), dim3(blocks), dim3(64), 0, ctx->stream, d_lt, n_rows, dim, d_bad,
-                       d_max, gen->d_wtab, reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, d_out,
-                       (int32_t)ctx->opt_weighted_debug);
+    int32_t p2 = 1;
+    while (p2 < dim) p2 <<= 1;
+    float4 *walk_a = reinterpret_cast<float4 *>(gen->d_walk_a);
+    hipLaunchKernelGGL(walk_build_kernel, dim3((unsigned)gen->sample_size), dim3(256), sizeof(unsigned long long) * (size_t)p2, ctx->stream, plan,
+                       reinterpret_cast<const float4 *>(gen->d_aos), dim, p2, gen->s_pad, walk_a, gen->d_walk_c);
     MHX_HIP_CHECK(hipGetLastError());
-    const unsigned chunks = (unsigned)(gen->s_pad / kWave);
-    const int64_t want = (n_rows + 3) / 4;
-    hipLaunchKernelGGL((weighted_dense_exact_kernel<R>), dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * 8)), chunks),
-                       dim3(256), 0, ctx->stream, d_lt, n_rows, dim, d_bad, gen->d_params, gen->sample_size, gen->s_pad, d_out);
+    const unsigned threads = 256;  // four waves stage a row; its chunks of 64 samples are then shared out among them
+    const int32_t list_cap = std::max(64, dim / 4);
+    const int32_t direct_permille = ctx->opt_weighted_direct > 0 ? (int32_t)ctx->opt_weighted_direct : 60;  // rows storing less than 6 % of the columns: entry by entry (measured crossover)
+    const int32_t n_cc = std::min<int32_t>(gen->s_pad / kWave, kCachedChunks);
+    const size_t lds = sizeof(float) * (size_t)((dim + 3) & ~3) + sizeof(uint16_t) * (size_t)((list_cap + 7) & ~7) + 20 * (size_t)n_cc * kWalkCached * kWave;
+    const int64_t per_cu = ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu
+                                                      : std::max<int64_t>(1, std::min<int64_t>(4, (int64_t)((160 << 10) / (lds + 64))));
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_rows, per_cu * ctx->num_cus));
+    const bool ahead = (dim & 3) == 0 && (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 && dim >= 4 && dim <= kPre * 4 * (int)threads;
+#define MHX_WALK_DENSE(LOGS, AHEAD)                                                                                                    \
+    hipLaunchKernelGGL((weighted_walk_dense_kernel<LOGS, AHEAD>), dim3(blocks), dim3(threads), lds, ctx->stream, d_x, n_rows, dim, plan, walk_a, \
+                       gen->d_walk_c, reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, list_cap, direct_permille, \
+                       d_out, d_nonempty, (int32_t)ctx->opt_weighted_debug)
+    if (values_are_logs) {
+        if (ahead) MHX_WALK_DENSE(true, true);
+        else MHX_WALK_DENSE(true, false);
+    } else {
+        if (ahead) MHX_WALK_DENSE(false, true);
+        else MHX_WALK_DENSE(false, false);
+    }
+#undef MHX_WALK_DENSE
     MHX_HIP_CHECK(hipGetLastError());
     return MHX_OK;
 }
@@ -855,8 +857,7 @@ int launch_weighted_dense(mhx_wgen *gen, const float *d_x, int values_are_logs, 
                           uint8_t *d_nonempty) {
     mhx_ctx *ctx = gen->ctx;
     const int32_t dim = gen->dim;
-    if (gen->table_filter && ctx->opt_weighted_path == 0 && dim <= (1 << 22))
-        return launch_weighted_dense_filtered(gen, d_x, values_are_logs, n_rows, d_out, d_nonempty);
+    if (gen->walk_ok && ctx->opt_weighted_path == 0) return launch_weighted_dense_walk(gen, d_x, values_are_logs, n_rows, d_out, d_nonempty);
     // scratch[4]: counts i64[n+1] | indptr i64[n+1] | scan temporary | indices i32[n*dim] | values f32[n*dim]
     const size_t ptr_bytes = ((sizeof(int64_t) * (size_t)(n_rows + 1)) + 255) & ~(size_t)255;
     const size_t cell_bytes = ((sizeof(float) * (size_t)n_rows * (size_t)dim) + 255) & ~(size_t)255;

@@ -72,9 +72,9 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * num_perm <= 32, 1 = always one set per wave), ("minhash.ties", 0 auto: the second launch tries the
  * tie-tolerant sieve before the dedup pass, 1 = dedup pass only), ("blocks_per_cu", n), ("minhash.prefetch", 0/1),
  * ("minhash.alias", profiling only: >= 0 makes set i read the tokens of set i & mask),
- * ("weighted.path", 0 auto: dense rows through the candidate filter, CSR rows through the row-block kernels,
- * 1 IEEE division for every element, 2 = no candidate filter: dense rows compacted to CSR first),
- * ("weighted.rows", rows per wave of the dense filter kernel: 8 or 16, 0 auto), ("host.chunk_bytes", see
+ * ("weighted.path", 0 auto: dense rows through the bound-ordered walk, CSR rows through the row-block kernels,
+ * 1 IEEE division for every element, 2 = every element evaluated: dense rows compacted to CSR first),
+ * ("host.chunk_bytes", see
  * mhx_minhash_bulk), ("lsh.sort_bits", bits of (band, digest) mhx_lsh_sort_bands hands to the radix sort,
  * 0 = chosen from n; the order is exact for any value, fewer bits leave more to the clean-up pass),
  * ("lsh.gather", 1 = gather the full digests after the sort instead of letting them ride through it). */

@@ -2,7 +2,7 @@
 """tools/bench_weighted.py -- config 4 (dense weighted rows) kernel timings under option sets, on one box.
 
     python tools/bench_weighted.py [--rows 100000] [--dim 4096] [--samples 128] [--check 2048]
-                                   [--variants "path=0;path=0,rows=16;path=2"] [--density 1.0]
+                                   [--variants "path=0;path=2"] [--density 1.0]
 
 Every variant runs mhx_weighted_minhash_many_dense_dev on the same resident logs (HIP events on the context's
 stream) and is compared with the first variant's result; `--check` rows are compared with the C oracle (tests'
@@ -29,7 +29,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--density", type=float, default=1.0, help="fraction of stored entries (the rest are zeros)")
     ap.add_argument("--dist", default="uniform", help="uniform | lognormal | sorted (columns by increasing weight)")
-    ap.add_argument("--variants", default="path=0;path=0,rows=16;path=2")
+    ap.add_argument("--variants", default="path=0;path=2")
     args = ap.parse_args()
 
     from datasketch_amd import WeightedMinHashGenerator, _native
@@ -61,9 +61,8 @@ def main():
     for variant in args.variants.split(";"):
         opts = dict(kv.split("=") for kv in variant.split(",") if kv)
         ctx.set_option("weighted.path", int(opts.get("path", 0)))
-        ctx.set_option("weighted.rows", int(opts.get("rows", 0)))
         ctx.set_option("blocks_per_cu", int(opts.get("bpc", 0)))
-        ctx.set_option("weighted.cols", int(opts.get("cols", 0)))
+        ctx.set_option("weighted.direct", int(opts.get("direct", 0)))
         ctx.set_option("weighted.debug", int(opts.get("debug", 0)))
 
         def call():
@@ -102,9 +101,8 @@ def main():
             rec["equal_to_first"] = bool(np.array_equal(hv, first[0]) and np.array_equal(ne, first[1]))
         print(json.dumps(rec), flush=True)
     ctx.set_option("weighted.path", 0)
-    ctx.set_option("weighted.rows", 0)
     ctx.set_option("blocks_per_cu", 0)
-    ctx.set_option("weighted.cols", 0)
+    ctx.set_option("weighted.direct", 0)
     ctx.set_option("weighted.debug", 0)
 
 
