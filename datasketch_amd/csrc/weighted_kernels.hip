@@ -745,6 +745,157 @@ __global__ __launch_bounds__(256) void weighted_walk_dense_kernel(const float *_
     }
 }
 
+// ---- CSR rows ---------------------------------------------------------------------------------------
+// A row that stores few of the columns is evaluated entry by entry (weighted_csr_direct_kernel: one wave per row and
+// 64 samples, four table entries in flight); a row that stores many is spread out in LDS (-inf where nothing is stored)
+// and walked like a dense row (weighted_walk_csr_kernel: one workgroup per row).  The two kernels share the rows out by
+// the same test on the row's length.
+__device__ __forceinline__ bool csr_row_is_walked(int64_t nnz, int32_t dim, int32_t direct_permille) {
+    return nnz * 1000 > (int64_t)direct_permille * dim;
+}
+
+// every stored entry of a CSR row with numpy's argmin (first minimum; the first NaN wins); entries come through the
+// scalar path, four table entries are in flight.  The table words are the three 4-byte ones of params[column][5][S_pad]
+// (12 bytes per lane and entry; this loop is bound by the L2's bandwidth).
+__device__ __forceinline__ Entry entry3(const float *__restrict__ params, int32_t col, int32_t s_pad, int32_t i) {
+    const char *base = reinterpret_cast<const char *>(params) + (int64_t)col * (kWords * 4) * s_pad;
+    const uint32_t li = (uint32_t)i, sp = (uint32_t)s_pad;
+    Entry e;
+    e.rcp = 0.0;
+    e.r = *reinterpret_cast<const float *>(base + (size_t)(sp * 8u + li * 4u));
+    e.ln_c = *reinterpret_cast<const float *>(base + (size_t)(sp * 12u + li * 4u));
+    e.beta = *reinterpret_cast<const float *>(base + (size_t)(sp * 16u + li * 4u));
+    return e;
+}
+
+__device__ __forceinline__ void csr_row_by_entry(const int32_t MHX_CONST_AS *indices, const float MHX_CONST_AS *logs, int64_t beg,
+                                                 int64_t end, const float *__restrict__ params, int32_t s_pad, int32_t my,
+                                                 int64_t &k_out, int64_t &t_out) {
+    Best best;
+    best.ln_a = 0.0f, best.t = 0.0f, best.k = -1;
+    int64_t j = beg;
+    for (; j + 4 <= end; j += 4) {
+        int32_t c[4];
+        Entry e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) c[u] = indices[j + u], e[u] = entry3(params, c[u], s_pad, my);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) consider(best, logs[j + u], e[u], c[u]);
+    }
+    for (; j < end; ++j) {
+        const int32_t c = indices[j];
+        consider(best, logs[j], entry3(params, c, s_pad, my), c);
+    }
+    k_out = best.k, t_out = (int64_t)best.t;
+}
+
+// One wave per (row, 64 samples).  The chunk of 64 samples is blockIdx.x % chunks: workgroups go round the 8 XCDs in
+// turn, so when chunks divides 8 an XCD only ever reads its chunks' part of the table -- at 128 samples x 4096 columns
+// 3.1 MB of r, ln_c, beta, which its 4 MB L2 holds; the whole table (6.3 MB) does not fit.
+__global__ __launch_bounds__(256) void weighted_csr_direct_kernel(const int64_t *__restrict__ indptr_, const int32_t *__restrict__ indices_,
+                                                                  const float *__restrict__ logs_, int64_t n_rows, int32_t dim,
+                                                                  int32_t direct_permille, const float *__restrict__ params,
+                                                                  int32_t sample_size, int32_t s_pad, int64_t *__restrict__ out,
+                                                                  uint8_t *__restrict__ nonempty) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int waves_per_block = blockDim.x >> 6;
+    const uint32_t chunks = (uint32_t)s_pad / kWave;
+    const uint32_t ch = blockIdx.x % chunks;
+    const int32_t my = (int32_t)ch * kWave + lane;
+    const int64_t MHX_CONST_AS *indptr = (const int64_t MHX_CONST_AS *)indptr_;
+    const int32_t MHX_CONST_AS *indices = (const int32_t MHX_CONST_AS *)indices_;
+    const float MHX_CONST_AS *logs = (const float MHX_CONST_AS *)logs_;
+    for (int64_t row = (int64_t)(blockIdx.x / chunks) * waves_per_block + wave; row < n_rows;
+         row += (int64_t)(gridDim.x / chunks) * waves_per_block) {
+        const int64_t beg = indptr[row], end = indptr[row + 1];
+        if (ch == 0 && lane == 0) nonempty[row] = end > beg ? 1 : 0;
+        if (direct_permille >= 0 && csr_row_is_walked(end - beg, dim, direct_permille)) continue;  // the walk kernel's row
+        int64_t k = 0, t = 0;
+        if (end > beg) csr_row_by_entry(indices, logs, beg, end, params, s_pad, my, k, t);
+        if (my < sample_size) {
+            int64_t *o = out + (row * sample_size + my) * 2;
+            o[0] = k;
+            o[1] = t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void weighted_walk_csr_kernel(const int64_t *__restrict__ indptr_, const int32_t *__restrict__ indices_,
+                                                                const float *__restrict__ logs_, int64_t n_rows, int32_t dim,
+                                                                int32_t direct_permille, const WalkPlan *__restrict__ plan,
+                                                                const float4 *__restrict__ walk_a, const uint32_t *__restrict__ walk_c,
+                                                                const float4 *__restrict__ aos, const float *__restrict__ params,
+                                                                int32_t sample_size, int32_t s_pad, int32_t list_cap,
+                                                                int64_t *__restrict__ out) {
+    extern __shared__ float row[];                                             // dim logs of the row (-inf: not stored)
+    uint16_t *list = reinterpret_cast<uint16_t *>(row + ((dim + 3) & ~3));    // columns above the cut (list_cap of them)
+    __shared__ int s_nout, s_odd;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), n_waves = blockDim.x >> 6;
+    const int32_t chunks = s_pad / kWave;
+    const float lcut = plan->lcut;
+    const int32_t n_cc = chunks < kCachedChunks ? chunks : kCachedChunks;
+    float4 *s_cache_a = reinterpret_cast<float4 *>(row + ((dim + 3) & ~3) + ((list_cap + 7) & ~7) / 2);
+    uint32_t *s_cache_c = reinterpret_cast<uint32_t *>(s_cache_a + n_cc * kWalkCached * kWave);
+    for (int j = tid; j < n_cc * kWalkCached * kWave; j += blockDim.x) {
+        const int ch = j / (kWalkCached * kWave), k = j / kWave % kWalkCached;
+        if (ch < chunks && k < dim) {
+            s_cache_a[j] = walk_a[((int64_t)ch * dim + k) * kWave + (j & (kWave - 1))];
+            s_cache_c[j] = walk_c[((int64_t)ch * dim + k) * kWave + (j & (kWave - 1))];
+        }
+    }
+    const int64_t MHX_CONST_AS *indptr = (const int64_t MHX_CONST_AS *)indptr_;
+    for (int64_t d = blockIdx.x; d < n_rows; d += gridDim.x) {
+        const int64_t beg = indptr[d], end = indptr[d + 1];
+        if (!csr_row_is_walked(end - beg, dim, direct_permille)) continue;  // the direct kernel's row
+        if (tid == 0) s_nout = 0, s_odd = 0;
+        for (int c = tid; c < dim; c += blockDim.x) row[c] = -__builtin_inff();
+        __syncthreads();
+        // scatter; "odd": a NaN, a column stored twice, a column outside the matrix -- such a row is evaluated entry by entry
+        bool odd = false;
+        for (int64_t j = beg + tid; j < end; j += blockDim.x) {
+            const int32_t c = indices_[j];
+            const float l = logs_[j];
+            if (l != l || c < 0 || c >= dim) {
+                odd = true;
+                continue;
+            }
+            if (l == -__builtin_inff()) continue;  // a stored zero: +inf for ln_a, never the argmin of a row with anything else
+            const float was = __uint_as_float(atomicExch(reinterpret_cast<unsigned int *>(&row[c]), __float_as_uint(l)));
+            odd |= !(was == -__builtin_inff());
+            if (l > lcut) {
+                const int at = atomicAdd(&s_nout, 1);
+                if (at < list_cap) list[at] = (uint16_t)c;
+            }
+        }
+        if (__any(odd) && lane == 0) s_odd = 1;
+        __syncthreads();
+        const int n_out = s_nout;
+        // nothing but stored zeros would leave the walk without an answer: entry by entry as well (k = the first column)
+        const bool by_entry = s_odd != 0 || n_out > list_cap;
+        for (int32_t ch = wave; ch < chunks; ch += n_waves) {
+            const int32_t my = ch * kWave + lane;
+            int64_t k_out = 0, t_out = 0;
+            if (by_entry) {
+                csr_row_by_entry((const int32_t MHX_CONST_AS *)indices_, (const float MHX_CONST_AS *)logs_, beg, end, params, s_pad, my, k_out, t_out);
+            } else {
+                walk_row(row, list, n_out, false, dim, ch, my, sample_size, walk_a, walk_c, aos, s_pad,
+                         ch < n_cc ? s_cache_a + ch * kWalkCached * kWave : nullptr,
+                         ch < n_cc ? s_cache_c + ch * kWalkCached * kWave : nullptr, k_out, t_out);
+                if (my < sample_size && k_out == 0xFFFFFFFFll)  // the walk met nothing (stored zeros only)
+                    csr_row_by_entry((const int32_t MHX_CONST_AS *)indices_, (const float MHX_CONST_AS *)logs_, beg, end, params, s_pad, my, k_out, t_out);
+            }
+            if (my < sample_size) {
+                int64_t *o = out + (d * sample_size + my) * 2;
+                o[0] = k_out;
+                o[1] = t_out;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 int launch_wgen_transpose(mhx_wgen *gen, const float *d_rs, const float *d_lncs, const float *d_betas) {
@@ -901,9 +1052,57 @@ int launch_weighted_log(mhx_ctx *ctx, const float *d_x, int64_t n, float *d_out)
     return MHX_OK;
 }
 
+// CSR rows when the generator has walk tables: sparse rows entry by entry, the others through the walk
+static int launch_weighted_csr_walk(mhx_wgen *gen, const int64_t *d_indptr, const int32_t *d_indices, const float *d_values,
+                                    int values_are_logs, int64_t n_rows, int64_t nnz, int64_t *d_out, uint8_t *d_nonempty) {
+    mhx_ctx *ctx = gen->ctx;
+    const int32_t dim = gen->dim;
+    const float *d_logs = d_values;
+    if (!values_are_logs) {  // device-log mode: the logs once, into scratch slot 3
+        if (int rc = ctx->ensure_scratch(3, sizeof(float) * (size_t)std::max<int64_t>(nnz, 1) + 256)) return rc;
+        if (nnz > 0)
+            if (int rc = launch_weighted_log(ctx, d_values, nnz, (float *)ctx->scratch[3])) return rc;
+        d_logs = (const float *)ctx->scratch[3];
+    }
+    const int32_t direct_permille = ctx->opt_weighted_direct > 0 ? (int32_t)ctx->opt_weighted_direct : 60;
+    WalkPlan *plan = reinterpret_cast<WalkPlan *>(gen->d_walk_plan);
+    float4 *walk_a = reinterpret_cast<float4 *>(gen->d_walk_a);
+    const bool any_walk = nnz * 1000 > (int64_t)direct_permille * dim;  // some row may be long enough
+    if (any_walk) {
+        const int32_t seg = (int32_t)std::min<int64_t>(nnz, 1024);
+        hipLaunchKernelGGL(walk_plan_kernel<true>, dim3(1), dim3(1024), 0, ctx->stream, d_logs, nnz, seg, (int32_t)std::min<int64_t>(16, nnz / seg), plan);
+        MHX_HIP_CHECK(hipGetLastError());
+        int32_t p2 = 1;
+        while (p2 < dim) p2 <<= 1;
+        hipLaunchKernelGGL(walk_build_kernel, dim3((unsigned)gen->sample_size), dim3(256), sizeof(unsigned long long) * (size_t)p2, ctx->stream, plan,
+                           reinterpret_cast<const float4 *>(gen->d_aos), dim, p2, gen->s_pad, walk_a, gen->d_walk_c);
+        MHX_HIP_CHECK(hipGetLastError());
+    }
+    const int64_t chunks = gen->s_pad / kWave;
+    const int64_t want = (n_rows + 3) / 4;
+    const int64_t groups = std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * (ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu : 16) / chunks));
+    hipLaunchKernelGGL(weighted_csr_direct_kernel, dim3((unsigned)(groups * chunks)), dim3(256), 0,
+                       ctx->stream, d_indptr, d_indices, d_logs, n_rows, dim, any_walk ? direct_permille : -1,
+                       gen->d_params, gen->sample_size, gen->s_pad, d_out, d_nonempty);
+    MHX_HIP_CHECK(hipGetLastError());
+    if (any_walk) {
+        const int32_t list_cap = std::max(64, dim / 4);
+        const int32_t n_cc = std::min<int32_t>(gen->s_pad / kWave, kCachedChunks);
+        const size_t lds = sizeof(float) * (size_t)((dim + 3) & ~3) + sizeof(uint16_t) * (size_t)((list_cap + 7) & ~7) + 20 * (size_t)n_cc * kWalkCached * kWave;
+        const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)((160 << 10) / (lds + 64))));
+        const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_rows, per_cu * ctx->num_cus));
+        hipLaunchKernelGGL(weighted_walk_csr_kernel, dim3(blocks), dim3(256), lds, ctx->stream, d_indptr, d_indices, d_logs, n_rows, dim, direct_permille,
+                           plan, walk_a, gen->d_walk_c, reinterpret_cast<const float4 *>(gen->d_aos), gen->d_params, gen->sample_size, gen->s_pad, list_cap, d_out);
+        MHX_HIP_CHECK(hipGetLastError());
+    }
+    return MHX_OK;
+}
+
 int launch_weighted(mhx_wgen *gen, const int64_t *d_indptr, const int32_t *d_indices, const float *d_values,
                     int values_are_logs, int64_t n_rows, int64_t nnz, int64_t *d_out, uint8_t *d_nonempty) {
     mhx_ctx *ctx = gen->ctx;
+    if (gen->walk_ok && ctx->opt_weighted_path == 0)
+        return launch_weighted_csr_walk(gen, d_indptr, d_indices, d_values, values_are_logs, n_rows, nnz, d_out, d_nonempty);
     // scratch slot 3: row flags, then (device-log mode) the logs
     const size_t flag_bytes = ((size_t)n_rows + 255) & ~(size_t)255;
     const size_t log_bytes = values_are_logs ? 0 : sizeof(float) * (size_t)nnz;

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--density", type=float, default=1.0, help="fraction of stored entries (the rest are zeros)")
     ap.add_argument("--dist", default="uniform", help="uniform | lognormal | sorted (columns by increasing weight)")
     ap.add_argument("--variants", default="path=0;path=2")
+    ap.add_argument("--csr", action="store_true", help="hand the rows over as CSR (mhx_weighted_minhash_many_dev) instead of dense")
     args = ap.parse_args()
 
     from datasketch_amd import WeightedMinHashGenerator, _native
@@ -54,9 +55,19 @@ def main():
     lib = ctx.lib
     with np.errstate(invalid="ignore", divide="ignore"):
         logs = np.log(x)
-    d_x = ctx.to_device(logs)
     d_o = ctx.alloc(n * s * 16)
     d_ne = ctx.alloc(n)
+    if args.csr:
+        import scipy.sparse as sp
+
+        csr = sp.csr_matrix(x)
+        csr.sort_indices()
+        with np.errstate(invalid="ignore", divide="ignore"):
+            d_ptr, d_idx = ctx.to_device(csr.indptr.astype(np.int64)), ctx.to_device(csr.indices.astype(np.int32))
+            d_val = ctx.to_device(np.log(csr.data).astype(np.float32))
+        nnz = int(csr.nnz)
+    else:
+        d_x = ctx.to_device(logs)
     first = None
     for variant in args.variants.split(";"):
         opts = dict(kv.split("=") for kv in variant.split(",") if kv)
@@ -66,7 +77,10 @@ def main():
         ctx.set_option("weighted.debug", int(opts.get("debug", 0)))
 
         def call():
-            _native.check(lib.mhx_weighted_minhash_many_dense_dev(handle, d_x.ptr, 1, n, d_o.ptr, d_ne.ptr))
+            if args.csr:
+                _native.check(lib.mhx_weighted_minhash_many_dev(handle, d_ptr.ptr, d_idx.ptr, d_val.ptr, 1, n, nnz, d_o.ptr, d_ne.ptr))
+            else:
+                _native.check(lib.mhx_weighted_minhash_many_dense_dev(handle, d_x.ptr, 1, n, d_o.ptr, d_ne.ptr))
 
         call()
         ctx.synchronize()
