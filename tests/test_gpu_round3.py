@@ -1,0 +1,236 @@
+"""GPU parity tests added in round 3 (run on an MI355X: python -m pytest tests -m gpu -x -q).
+
+The weighted sketch's bound-ordered walk (dense rows and CSR rows): bit-identical (k, t) against the C oracle and
+against the evaluate-every-element kernels of round 2 on config 4's own input at full size, on heavy-tailed,
+sorted, sparse and degenerate inputs, across table rebuilds, and for every (dim, sample_size) shape class of the
+kernels.  Everything goes through the C ABI; the oracle is the checker.
+"""
+import os
+import zlib
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from datasketch_amd import WeightedMinHashGenerator, _native
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert _native.gpu_available(), "these tests need an MI355X"
+    return _native.context()
+
+
+def _oracle(g, x, rows=None):
+    xs = x if rows is None else x[rows]
+    csr = sp.csr_matrix(xs)
+    csr.sort_indices()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return O.c_weighted_minhash_many(csr.indptr, csr.indices, csr.data, g.rs, g.ln_cs, g.betas)
+
+
+def _same(got, want, wn):
+    """(k, t) of the rows that store something; rows that store nothing report empty."""
+    out, ne = got
+    return np.array_equal(ne.astype(bool), wn) and np.array_equal(out[wn], want[wn]) and not out[~wn].any()
+
+
+def _config4_input(n, dim=4096):
+    rs_ = np.random.RandomState(42)
+    x = np.empty((n, dim), dtype=np.float32)
+    for i in range(0, n, 10_000):
+        x[i : i + 10_000] = rs_.uniform(0, 100, (min(10_000, n - i), dim))
+    return x
+
+
+def test_walk_on_config4_input_at_full_size(ctx):
+    """BASELINE.json configs[3] on its own input: 2 500 rows spread over the matrix against the C oracle, and EVERY row
+    against the kernels that evaluate every element (weighted.path = 2, round 2's path) -- two implementations that
+    share nothing but the arithmetic of one evaluation."""
+    n, dim, s = 100_000, 4096, 128
+    x = _config4_input(n, dim)
+    g = WeightedMinHashGenerator(dim, s, seed=1, gpu_mode="always")
+    out, ne = g.minhash_many_arrays(x)
+    assert ne.all()
+    rows = np.unique(np.concatenate([np.arange(0, 32), np.linspace(0, n - 1, 2500).astype(np.int64), np.arange(n - 32, n)]))
+    want, wn = _oracle(g, x, rows)
+    assert wn.all() and np.array_equal(out[rows], want)
+    wctx, _ = g._device_handle()
+    wctx.set_option("weighted.path", 2)
+    try:
+        every, ne2 = g.minhash_many_arrays(x)
+    finally:
+        wctx.set_option("weighted.path", 0)
+    assert np.array_equal(every, out) and np.array_equal(ne2, ne)
+
+
+@pytest.mark.parametrize("kind", ["lognormal2", "sorted_up", "sorted_down", "constant", "spikes", "tiny_and_huge", "counts", "half_zeros", "few_percent", "one_entry"])
+def test_walk_on_inputs_that_stress_the_cut_and_the_stop_rule(ctx, kind):
+    """Heavy tails (entries above the cut, evaluated before the walk), sorted rows, rows of one value (every bound is
+    tight: ties everywhere), rare spikes, logs near the float32 range ends, small integers, and rows that store little."""
+    rng = np.random.RandomState(zlib.crc32(kind.encode()))
+    n, dim, s = 96, 1024, 128
+    if kind == "lognormal2":
+        x = rng.lognormal(0, 2.0, (n, dim))
+    elif kind in ("sorted_up", "sorted_down"):
+        x = np.sort(rng.uniform(0, 100, (n, dim)), axis=1)
+        x = x if kind == "sorted_up" else x[:, ::-1]
+    elif kind == "constant":
+        x = np.repeat(rng.uniform(0.5, 50, (n, 1)), dim, axis=1)
+    elif kind == "spikes":
+        x = rng.uniform(0, 1, (n, dim))
+        x[rng.random_sample(x.shape) < 0.002] = 1e6
+    elif kind == "tiny_and_huge":
+        x = np.exp(rng.uniform(-80, 80, (n, dim)))
+    elif kind == "counts":
+        x = rng.poisson(3.0, (n, dim)).astype(np.float64)
+    elif kind == "half_zeros":
+        x = rng.uniform(0, 100, (n, dim))
+        x[rng.random_sample(x.shape) < 0.5] = 0
+    elif kind == "few_percent":
+        x = rng.uniform(0, 100, (n, dim))
+        x[rng.random_sample(x.shape) < rng.uniform(0.85, 0.995, (n, 1))] = 0
+    else:
+        x = np.zeros((n, dim))
+        x[np.arange(n), rng.randint(0, dim, n)] = rng.uniform(0.1, 9, n)
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    x[5] = 0  # a row that stores nothing
+    g = WeightedMinHashGenerator(dim, s, seed=3, gpu_mode="always")
+    want, wn = _oracle(g, x)
+    assert not wn[5]
+    assert _same(g.minhash_many_arrays(x), want, wn)
+    # the same rows as CSR (mhx_weighted_minhash_many): short rows entry by entry, long rows walked
+    assert _same(g.minhash_many_arrays(sp.csr_matrix(x)), want, wn)
+
+
+@pytest.mark.parametrize("dim,s", [(1, 1), (2, 3), (5, 64), (7, 70), (63, 128), (300, 300), (513, 128), (4096, 129), (5000, 64), (16384, 65), (16385, 64)])
+def test_walk_shape_classes(ctx, dim, s):
+    """Dimensions that are not multiples of 4 (no 16-byte loads), above 4096 (rows not held in registers ahead), at and
+    above the walk's limit of 16384 (above it the round-2 kernels take over), sample sizes that are not multiples of 64
+    and above 256 (more chunks than a workgroup caches), in dense and CSR form, full and 20 % stored."""
+    rng = np.random.RandomState(dim * 7 + s)
+    n = 37 if dim < 5000 else 11
+    g = WeightedMinHashGenerator(dim, s, seed=2, gpu_mode="always")
+    for density in (1.0, 0.2):
+        x = rng.uniform(0, 30, (n, dim)).astype(np.float32)
+        if density < 1.0:
+            x[rng.random_sample(x.shape) >= density] = 0
+        want, wn = _oracle(g, x)
+        assert _same(g.minhash_many_arrays(x), want, wn)
+        assert _same(g.minhash_many_arrays(sp.csr_matrix(x)), want, wn)
+
+
+def test_walk_rows_with_nan_and_infinite_values(ctx):
+    """numpy's argmin on a row with a NaN log (a negative value): the first NaN wins; +inf values give ln_a = -inf;
+    rows of such values sit between ordinary rows of the same call."""
+    rng = np.random.RandomState(8)
+    n, dim, s = 64, 512, 100
+    x = rng.uniform(0, 10, (n, dim)).astype(np.float32)
+    x[3, 100] = -1.0            # log -> NaN
+    x[3, 7] = -2.0
+    x[9, 5] = np.inf            # log -> +inf: ln_a = -inf
+    x[9, 300] = np.inf          # a tie at -inf: the first column wins
+    x[12, :] = 0
+    x[12, 44] = np.nan
+    x[20, rng.random_sample(dim) < 0.97] = 0
+    x[20, 17] = -5.0            # a NaN in a short row
+    g = WeightedMinHashGenerator(dim, s, seed=4, gpu_mode="always")
+    with np.errstate(invalid="ignore", divide="ignore"):
+        want, wn = _oracle(g, x)
+    dense = g.minhash_many_arrays(x)
+    csr = g.minhash_many_arrays(sp.csr_matrix(x))
+    odd = np.array([3, 9, 12, 20])  # their t is floor(NaN) or floor(inf) cast to int64: the cast is platform-defined
+    rest = np.setdiff1d(np.arange(n), odd)
+    for out, ne in (dense, csr):
+        assert np.array_equal(ne.astype(bool), wn)
+        assert np.array_equal(out[rest], want[rest])
+        assert np.array_equal(out[odd][:, :, 0], want[odd][:, :, 0])  # the winning columns
+    assert np.array_equal(want[3][:, 0], np.full(s, 7)) and np.array_equal(want[9][:, 0], np.full(s, 5))
+    assert np.array_equal(dense[0], csr[0])
+
+
+def test_walk_tables_follow_the_scale_of_the_data(ctx):
+    """The cut is planned per call from a sample of the call's logs and the sorted tables are rebuilt when it moves:
+    calls at scales 1, 1e4, 1e-3 and 1 again on one generator, each against the oracle -- results never depend on
+    which tables happen to be in place."""
+    rng = np.random.RandomState(31)
+    n, dim, s = 64, 2048, 128
+    g = WeightedMinHashGenerator(dim, s, seed=9, gpu_mode="always")
+    base = rng.uniform(0, 1, (n, dim)).astype(np.float32)
+    for scale in (1.0, 1e4, 1e-3, 1.0, 3.0):
+        x = (base * np.float32(scale)).astype(np.float32)
+        want, wn = _oracle(g, x)
+        assert _same(g.minhash_many_arrays(x), want, wn)
+    # one call whose rows live on very different scales: most rows have all their entries above or far below the cut
+    x = (base * np.float32(10.0) ** rng.randint(-6, 7, (n, 1)).astype(np.float32)).astype(np.float32)
+    want, wn = _oracle(g, x)
+    assert _same(g.minhash_many_arrays(x), want, wn)
+
+
+def test_sparse_rows_at_scale_against_the_oracle(ctx):
+    """1 %-dense CSR rows, 100 000 of them (dim 4096, 128 samples): 2 500 rows against the C oracle, every row against
+    the IEEE-division-everywhere kernels (weighted.path = 1)."""
+    n, dim, s = 100_000, 4096, 128
+    rng = np.random.RandomState(77)
+    x = sp.random(n, dim, density=0.01, format="csr", dtype=np.float32, random_state=rng, data_rvs=lambda k: rng.uniform(0.01, 100, k).astype(np.float32))
+    x.sort_indices()
+    g = WeightedMinHashGenerator(dim, s, seed=1, gpu_mode="always")
+    out, ne = g.minhash_many_arrays(x)
+    rows = np.unique(np.linspace(0, n - 1, 2500).astype(np.int64))
+    sub = x[rows]
+    want, wn = O.c_weighted_minhash_many(sub.indptr, sub.indices, sub.data, g.rs, g.ln_cs, g.betas)
+    assert np.array_equal(ne[rows].astype(bool), wn) and np.array_equal(out[rows][wn], want[wn])
+    wctx, _ = g._device_handle()
+    wctx.set_option("weighted.path", 1)
+    try:
+        every, ne2 = g.minhash_many_arrays(x)
+    finally:
+        wctx.set_option("weighted.path", 0)
+    assert np.array_equal(every, out) and np.array_equal(ne2, ne)
+
+
+def test_csr_rows_with_stored_zeros_and_through_the_c_abi_in_log_form(ctx):
+    """Logs handed over as they are (values_are_logs): a stored zero is a log of -inf (ln_a = +inf: it wins only a row
+    that stores nothing else, and then its first column does); rows long enough to be walked and short ones."""
+    rng = np.random.RandomState(5)
+    dim, s = 256, 64
+    g = WeightedMinHashGenerator(dim, s, seed=6, gpu_mode="always")
+    wctx, handle = g._device_handle()
+    lens = [0, 1, 3, 40, 200, 256, 2, 100, 256, 30]
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    indices = np.concatenate([np.sort(rng.choice(dim, k, replace=False)) for k in lens]).astype(np.int32)
+    logs = rng.uniform(-3, 5, int(indptr[-1])).astype(np.float32)
+    logs[indptr[3] : indptr[4] : 3] = -np.inf     # stored zeros inside a short row
+    logs[indptr[4] : indptr[5] : 2] = -np.inf     # ... inside a walked row
+    logs[indptr[6] : indptr[7]] = -np.inf         # a short row of nothing but stored zeros
+    logs[indptr[8] : indptr[9]] = -np.inf         # a long row of nothing but stored zeros
+    want, wn = O.c_weighted_minhash_many(indptr, indices, None, g.rs, g.ln_cs, g.betas, logs=logs)
+    got, ne = wctx.weighted_minhash_many(handle, s, indptr, indices, logs, True)
+    zeros_only = np.array([6, 8])  # t = floor(-inf) cast to int64: platform-defined; the column is the row's first
+    rest = np.setdiff1d(np.arange(len(lens)), zeros_only)
+    assert np.array_equal(ne.astype(bool), wn) and np.array_equal(got[rest], want[rest])
+    assert np.array_equal(got[zeros_only][:, :, 0], want[zeros_only][:, :, 0])
+    assert (want[6][:, 0] == indices[indptr[6]]).all() and (want[8][:, 0] == indices[indptr[8]]).all()
+
+
+def test_device_log_mode_through_the_walk(ctx):
+    """device_log=True takes logf on the device inside the walk kernel's staging pass: its (k, t) may differ from parity
+    mode only under BASELINE.md section 3's rule (bench.weighted_gap_gate)."""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from bench import weighted_gap_gate
+
+    n, dim, s = 4096, 4096, 128
+    x = _config4_input(n, dim)
+    g = WeightedMinHashGenerator(dim, s, seed=1, gpu_mode="always")
+    gl = WeightedMinHashGenerator(dim, s, seed=1, gpu_mode="always", device_log=True)
+    hv, _ = g.minhash_many_arrays(x)
+    hv_l, _ = gl.minhash_many_arrays(x)
+    mism = np.argwhere(np.any(hv != hv_l, axis=2))
+    assert len(mism) < 1e-5 * n * s
+    assert weighted_gap_gate(x, g, hv, hv_l, mism)["unexplained"] == 0
