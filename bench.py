@@ -73,11 +73,14 @@ def parse_args(argv=None):
 def spawn_ranks(args) -> int:
     from datasketch_amd import rendezvous
 
+    import secrets
+
     port = rendezvous.free_port()
+    nonce = secrets.token_hex(16)  # only this job's ranks may join the group
     procs = []
     for rank in range(args.gpus):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus),
-                   LOCAL_WORLD_SIZE=str(args.gpus), MHX_RDZV_ADDR=f"127.0.0.1:{port}")
+                   LOCAL_WORLD_SIZE=str(args.gpus), MHX_RDZV_ADDR=f"127.0.0.1:{port}", MHX_RDZV_NONCE=nonce)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     deadline = time.time() + float(os.environ.get("MHX_BENCH_TIMEOUT", "1500"))
@@ -246,6 +249,7 @@ def main():
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
         "traffic": measured_traffic(n, t, k, args),
+        "traffic_source": "profiles/%s: rocprofv3 --pmc passes over this same command (tools/traffic.sh), replayed here -- not measured in this process" % os.path.basename(TRAFFIC_FILE),
         "kernel": "minhash_bulk_kernel<MODE_SIEVE> (+ the MODE_FULL launch over the flagged sets)",
         "kernel_ms": kernel_ms,
         "algorithmic_bytes_per_launch": alg_bytes,
@@ -696,18 +700,31 @@ def extra_c4(ctx, n=100_000, dim=4096, s=128):
     d_x = wctx.to_device(logs)
     d_o = wctx.alloc(n * s * 16)
     d_ne = wctx.alloc(n)
-    ms = _timed(wctx, lambda: _native.check(lib.mhx_weighted_minhash_many_dense_dev(handle, d_x.ptr, 1, n, d_o.ptr, d_ne.ptr)), reps=2)
+    ms = _timed(wctx, lambda: _native.check(lib.mhx_weighted_minhash_many_dense_dev(handle, d_x.ptr, 1, n, d_o.ptr, d_ne.ptr)), reps=5)
+    hv_dev = d_o.download((n, s, 2), np.int64)  # the timed entry point's own result
+    wctx.set_option("weighted.path", 2)  # A/B: every element evaluated (round 2's kernels), same call
+    try:
+        ms_every = _timed(wctx, lambda: _native.check(lib.mhx_weighted_minhash_many_dense_dev(handle, d_x.ptr, 1, n, d_o.ptr, d_ne.ptr)), reps=1)
+        hv_every = d_o.download((n, s, 2), np.int64)
+    finally:
+        wctx.set_option("weighted.path", 0)
     d_x.upload(x)
-    ms_log = _timed(wctx, lambda: _native.check(lib.mhx_weighted_minhash_many_dense_dev(handle, d_x.ptr, 0, n, d_o.ptr, d_ne.ptr)), reps=2)
+    ms_log = _timed(wctx, lambda: _native.check(lib.mhx_weighted_minhash_many_dense_dev(handle, d_x.ptr, 0, n, d_o.ptr, d_ne.ptr)), reps=5)
     for d in (d_x, d_o, d_ne):
         d.free()
-    # parity gate: sample rows against the C oracle (bit-exact (k, t) in parity mode)
-    rows = np.unique(np.linspace(0, n - 1, 48).astype(np.int64))
+    # parity gates: 2 048 rows spread over the matrix against the C oracle (bit-exact (k, t) in parity mode), and EVERY
+    # row of the walk against the kernels that evaluate every element
+    rows = np.unique(np.linspace(0, n - 1, 2048).astype(np.int64))
     csr = sp.csr_matrix(x[rows])
     csr.sort_indices()
+    t0 = time.perf_counter()
     wo, wn = O.c_weighted_minhash_many(csr.indptr, csr.indices, csr.data, g.rs, g.ln_cs, g.betas)
-    if not (np.array_equal(hv[rows], wo) and np.array_equal(ne[rows], wn)):
+    oracle_s = time.perf_counter() - t0
+    if not (np.array_equal(hv[rows], wo) and np.array_equal(ne[rows], wn) and np.array_equal(hv_dev[rows], wo)):
         raise SystemExit("PARITY FAILURE (extra.c4): weighted (k, t) differ from the oracle in parity mode")
+    if not np.array_equal(hv_dev, hv_every):
+        raise SystemExit("PARITY FAILURE (extra.c4): the walk and the evaluate-every-element kernels disagree")
+    cpu = weighted_cpu_baseline(x, g, wo[:64] if np.array_equal(rows[:64], np.arange(64)) else None, oracle_rows=len(rows), oracle_s=oracle_s)
     # fast-mode acceptance gate: every (k, t) mismatch must come from two smallest ln_a
     # within 1e-6 relative of each other
     mism = np.argwhere(np.any(hv != hv_l, axis=2))
@@ -717,7 +734,12 @@ def extra_c4(ctx, n=100_000, dim=4096, s=128):
     alg = n * (4 * dim + 16 * s)
     out.update({
         "kernel": dict(_roof(alg, ms), vectors_per_s=n / (ms * 1e-3), element_evaluations_per_s=n * dim * s / (ms * 1e-3),
-                       note="fp32-VALU bound (one quotient, floor and 6 add/mul/compare per element-sample); logs precomputed, resident"),
+                       kernels="walk_plan_kernel + walk_build_kernel (no-op once the tables stand) + weighted_walk_dense_kernel",
+                       note="bound-ordered walk: ~2 exact evaluations per (row, sample) instead of 4096 (the element rate counts the "
+                            "evaluations the reference makes); the matrix is read once, logs precomputed and resident; "
+                            "algorithmic bytes = 4*dim + 16*S per vector"),
+        "kernel_every_element": dict(_roof(alg, ms_every), vectors_per_s=n / (ms_every * 1e-3),
+                                     note="weighted.path=2: round 2's kernels (every element evaluated), same call, same box"),
         "kernel_device_log": dict(_roof(alg, ms_log), vectors_per_s=n / (ms_log * 1e-3)),
         "from_python_parity_mode": {"seconds": dt_par, "vectors_per_s": n / dt_par, "first_call_seconds": dt_par_first,
                                     "note": "numpy in -> numpy out; np.log on the host; first call = with the one-time allocation of the page-locked log buffers"},
@@ -725,9 +747,44 @@ def extra_c4(ctx, n=100_000, dim=4096, s=128):
         "device_log_mismatch_rate": float(len(mism)) / (n * s),
         "device_log_mismatches": int(len(mism)),
         "device_log_gate": gate,
-        "parity": f"{len(rows)} rows bit-exact (k, t) vs the C oracle in parity mode; all-rows nonempty = {bool(ne.all())}",
+        "cpu_baseline": cpu,
+        "parity": f"{len(rows)} rows bit-exact (k, t) vs the C oracle in parity mode; all {n} rows equal to the evaluate-every-element "
+                  f"kernels; all-rows nonempty = {bool(ne.all())}",
     })
     return out
+
+
+def weighted_cpu_baseline(x, g, want64, oracle_rows, oracle_s):
+    """The reference's CPU paths for config 4 on a bounded sample of its input, one core (numpy's float32 ufuncs are
+    single-threaded): `minhash_many` as the reference evaluates it (weighted_minhash.py:205-239: per row the (S, nnz)
+    arrays) through this package's gpu_mode='disable' path (the same numpy statements), the per-vector `minhash` loop
+    (weighted_minhash.py:123-159; SURVEY.md section 8d: the reference's faster CPU alternative), and the scalar C
+    oracle.  kind 'port': the reference itself is not on the GPU box."""
+    from datasketch_amd import WeightedMinHashGenerator
+    from oracle import oracle as O
+    import scipy.sparse as sp
+
+    gd = WeightedMinHashGenerator(g.dim, g.sample_size, seed=g.seed, gpu_mode="disable")
+    m = 64
+    t0 = time.perf_counter()
+    res = gd.minhash_many(x[:m])
+    dt_many = time.perf_counter() - t0
+    if want64 is None:
+        c = sp.csr_matrix(x[:m])
+        c.sort_indices()
+        want64 = O.c_weighted_minhash_many(c.indptr, c.indices, c.data, g.rs, g.ln_cs, g.betas)[0]
+    if not np.array_equal(np.stack([r.hashvalues for r in res]), want64):
+        raise SystemExit("PARITY FAILURE (extra.c4): the numpy path differs from the oracle on the cpu_baseline sample")
+    t0 = time.perf_counter()
+    for v in x[:m]:
+        gd.minhash(v)
+    dt_each = time.perf_counter() - t0
+    return {"value": m / dt_many, "unit": "vectors/s", "cores": 1, "kind": "port",
+            "sample": f"first {m} rows of config 4's input (dim {g.dim}, sample_size {g.sample_size}): minhash_many, numpy, {dt_many:.1f} s",
+            "per_vector_minhash_loop_value": m / dt_each,
+            "per_vector_minhash_loop_sample": f"the same {m} rows through minhash() one at a time, {dt_each:.1f} s",
+            "c_oracle_value": oracle_rows / oracle_s, "c_oracle_sample": f"{oracle_rows} rows, scalar C, {oracle_s:.1f} s",
+            "cpu_model": cpu_model()}
 
 
 def weighted_gap_gate(x, g, hv_par, hv_log, mism, tol=1e-6):

@@ -568,9 +568,14 @@ class Context:
         p = _vp()
         check(self.lib.mhx_host_alloc(self.handle, n, ctypes.byref(p)))
         buf = (ctypes.c_char * max(n, 1)).from_address(p.value)
-        ptr = p.value
-        # (not at interpreter exit, when the context may be gone already: the process's pages go back anyway)
-        weakref.finalize(buf, lambda: self.handle and self.lib.mhx_host_free(self.handle, ptr)).atexit = False
+        ptr, lib, ctx_ref = p.value, self.lib, weakref.ref(self)
+
+        def release():  # with the context if it is still open (it waits for transfers in flight), without it otherwise
+            ctx = ctx_ref()
+            lib.mhx_host_free(ctx.handle if ctx is not None and ctx.handle else None, ptr)
+
+        # (not at interpreter exit, when the library may be gone already: the process's pages go back anyway)
+        weakref.finalize(buf, release).atexit = False
         return np.frombuffer(buf, dtype=dtype, count=n // dtype.itemsize).reshape(shape)
 
     def weighted_dense_feed(self, h: int, sample_size: int, dim: int, values_are_logs: bool, piece_rows: int) -> "WeightedFeed":

@@ -85,9 +85,10 @@ __global__ __launch_bounds__(256) void band_keys_with_luggage_kernel(const SigT 
     }
 }
 
-__global__ __launch_bounds__(256) void unpack_luggage_kernel(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ vals,
+// keys and sorted_keys_only are the same buffer at the call site (read, then overwritten, element by element): no __restrict__
+__global__ __launch_bounds__(256) void unpack_luggage_kernel(const uint64_t *keys, const uint32_t *__restrict__ vals,
                                                              int64_t total, int band_bits, int sort_bits,
-                                                             uint64_t *__restrict__ sorted_keys_only, uint64_t *__restrict__ sorted_digests,
+                                                             uint64_t *sorted_keys_only, uint64_t *__restrict__ sorted_digests,
                                                              uint32_t *__restrict__ sorted_rows) {
     const int d_bits = sort_bits - band_bits, h_bits = 64 - sort_bits;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {

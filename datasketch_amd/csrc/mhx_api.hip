@@ -295,9 +295,12 @@ int mhx_host_alloc(mhx_ctx *ctx, size_t bytes, void **ptr) {
 }
 
 int mhx_host_free(mhx_ctx *ctx, void *ptr) {
-    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
-    MHX_GUARD(ctx);
     if (!ptr) return MHX_OK;
+    if (!ctx) {  // the context that allocated it is gone (and with it every transfer that could still use the block)
+        MHX_HIP_CHECK(hipHostFree(ptr));
+        return MHX_OK;
+    }
+    MHX_GUARD(ctx);
     if (int rc = ctx->activate()) return rc;
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (ctx->copy_in) MHX_HIP_CHECK(hipStreamSynchronize(ctx->copy_in));

@@ -19,6 +19,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import weakref
+
 import numpy as np
 
 from datasketch_amd import rendezvous
@@ -78,21 +80,25 @@ def allgather_signatures(local: np.ndarray, group=None, counts: Optional[Sequenc
     return np.concatenate(mats, axis=0).astype(np.uint64)
 
 
-_COMM_CACHE = {}
-
-
 def communicator(ctx, group):
     """The RCCL communicator of this rank's context for ``group`` (created once: rank 0 makes the
-    128-byte id, the group's broadcast hands it out)."""
+    128-byte id, the group's broadcast hands it out).  It lives on the group object itself -- a table keyed by
+    ``id()`` would hand a recycled address the communicator of a dead group -- and ``group.close()`` destroys it."""
     from datasketch_amd import _native
 
-    key = (id(ctx), id(group))
-    comm = _COMM_CACHE.get(key)
-    if comm is None:
+    comms = getattr(group, "_mhx_comms", None)
+    if comms is None:
+        comms = weakref.WeakKeyDictionary()  # context -> communicator: gone with either of the two
+        try:
+            group._mhx_comms = comms
+        except AttributeError:  # a foreign group object without a __dict__: no caching
+            pass
+    comm = comms.get(ctx)
+    if comm is None or comm.handle is None:
         uid = _native.Communicator.unique_id() if group.rank == 0 else b""
         uid = group.allgather(uid)[0]
         comm = _native.Communicator(ctx, uid, group.rank, group.world)
-        _COMM_CACHE[key] = comm
+        comms[ctx] = comm
     return comm
 
 

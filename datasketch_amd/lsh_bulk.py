@@ -315,6 +315,13 @@ class SortedBandsIndex:
             _native.check(self.ctx.lib.mhx_lsh_sort_bands_dev_typed(self.ctx.handle, self._d_sig.ptr, self._code, self.n, self.k,
                                                                     self.b, self.r, self._d_dig.ptr, self._d_rows.ptr))
 
+    def _as_index_dtype(self, sig: np.ndarray) -> np.ndarray:
+        """``sig`` in the index's signature type; a wider matrix must fit (a wrapped value would match band keys the
+        reference's byte-keyed dictionaries keep apart)."""
+        if self.dtype == np.uint32 and sig.dtype.itemsize > 4 and sig.size and int(sig.max()) > 0xFFFFFFFF:
+            raise ValueError("signature values >= 2**32 do not fit this uint32 index")
+        return np.ascontiguousarray(sig, dtype=self.dtype)
+
     def extend(self, signatures) -> range:
         """Add rows (what ``MinHashLSH.insert`` does key by key, ref: datasketch/lsh.py:326-347) and return their row
         numbers ``range(old N, new N)``.  The matrix grows on the device (the rows already there are not uploaded
@@ -322,7 +329,7 @@ class SortedBandsIndex:
         more = np.asarray(signatures)
         if more.ndim != 2 or more.shape[1] != self.k:
             raise ValueError("Expecting minhash with length %d, got %d" % (self.k, more.shape[-1]))
-        more = np.ascontiguousarray(more, dtype=self.dtype)
+        more = self._as_index_dtype(more)
         first, m = self.n, more.shape[0]
         if m == 0:
             return range(first, first)
@@ -343,9 +350,10 @@ class SortedBandsIndex:
         ``i`` are ``rows[offsets[i]:offsets[i+1]]``, ascending."""
         import ctypes
 
-        q = np.ascontiguousarray(np.asarray(signatures), dtype=self.dtype)
+        q = np.asarray(signatures)
         if q.ndim != 2 or q.shape[1] != self.k:
             raise ValueError("Expecting minhash with length %d, got %d" % (self.k, q.shape[-1]))
+        q = self._as_index_dtype(q)
         m = q.shape[0]
         offsets = np.zeros(m + 1, dtype=np.int64)
         if m == 0 or self.n == 0:

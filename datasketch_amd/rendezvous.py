@@ -13,14 +13,21 @@ Address of rank 0, in order of preference:
   * ``MHX_RDZV_ADDR=host:port`` (set by ``bench.py`` when it spawns its own ranks);
   * ``MASTER_ADDR`` / ``MASTER_PORT`` as exported by ``python -m torch.distributed.run``: that port
     itself belongs to the launcher's store, so rank 0 binds a free port and publishes it in
-    ``$TMPDIR/mhx_rdzv_<uid>_<MASTER_PORT>_<parent pid>`` (all ranks of one node share the launcher
-    as parent); with ranks on several nodes (``LOCAL_WORLD_SIZE`` < ``WORLD_SIZE``) rank 0 listens
-    on ``MASTER_PORT + 1`` instead.
+    ``$TMPDIR/mhx_rdzv_<uid>/<MASTER_PORT>_<parent pid>`` (a 0700 directory of this user; the file is
+    created with O_EXCL, mode 0600, and holds a random nonce every joining rank must present; all
+    ranks of one node share the launcher as parent) and listens on the loopback interface only; with
+    ranks on several nodes (``LOCAL_WORLD_SIZE`` < ``WORLD_SIZE``) rank 0 listens on
+    ``MASTER_PORT + 1`` of the address ``MASTER_ADDR`` resolves to (``MHX_RDZV_NONCE``, if the
+    launcher exports one to every rank, is the shared secret there).
+Connections that are not ranks of the group (wrong magic, wrong nonce, a rank twice, an oversized
+frame) are dropped; they do not abort the group.
 """
 from __future__ import annotations
 
+import hmac
 import json
 import os
+import secrets
 import socket
 import struct
 import tempfile
@@ -29,6 +36,8 @@ from typing import List, Optional, Sequence
 
 _MAGIC = b"MHXR"
 _HDR = struct.Struct("<4sIQ")  # magic, rank, payload length
+_HELLO_MAX = 256               # a hello frame carries the group's nonce and nothing else
+MAX_FRAME = 1 << 32            # no frame is larger (the CPU stand-in carries signature shards; a GPU job a few hundred bytes)
 
 
 def _recv_exact(sock: socket.socket, n: int) -> bytes:
@@ -47,10 +56,12 @@ def _send_frame(sock: socket.socket, rank: int, payload: bytes) -> None:
     sock.sendall(_HDR.pack(_MAGIC, rank, len(payload)) + payload)
 
 
-def _recv_frame(sock: socket.socket):
+def _recv_frame(sock: socket.socket, limit: int = MAX_FRAME):
     magic, rank, n = _HDR.unpack(_recv_exact(sock, _HDR.size))
     if magic != _MAGIC:
         raise ConnectionError("not a libmhx rendezvous peer")
+    if n > limit:  # the length comes from the peer: never allocate on its say-so alone
+        raise ConnectionError(f"rendezvous frame of {n} bytes exceeds the limit of {limit}")
     return rank, _recv_exact(sock, n)
 
 
@@ -60,12 +71,52 @@ def free_port(host: str = "127.0.0.1") -> int:
         return s.getsockname()[1]
 
 
+def _listen_address(host: str, port: int, single_node: bool):
+    """(family, sockaddr) rank 0 binds: the loopback interface when every rank is on this node; otherwise the address
+    MASTER_ADDR resolves to (IPv4 or IPv6) when that is an address of this host, else every interface of its family."""
+    if single_node:
+        return (socket.AF_INET6, ("::1", port, 0, 0)) if host == "::1" else (socket.AF_INET, ("127.0.0.1", port))
+    try:
+        infos = socket.getaddrinfo(host or None, port, type=socket.SOCK_STREAM, flags=socket.AI_PASSIVE if not host else 0)
+    except socket.gaierror:
+        infos = []
+    for family, _t, _p, _c, sockaddr in infos:
+        try:  # bindable = one of this host's own addresses
+            with socket.socket(family, socket.SOCK_STREAM) as probe:
+                probe.bind(sockaddr[:1] + (0,) + sockaddr[2:])
+            return family, sockaddr
+        except OSError:
+            continue
+    family = infos[0][0] if infos else socket.AF_INET
+    return family, (("::", port, 0, 0) if family == socket.AF_INET6 else ("", port))
+
+
+def _publish_dir() -> str:
+    """A directory only this user can write: $TMPDIR/mhx_rdzv_<uid> (0700, owned by us, not a symlink)."""
+    uid = os.getuid() if hasattr(os, "getuid") else 0
+    path = os.path.join(tempfile.gettempdir(), f"mhx_rdzv_{uid}")
+    try:
+        os.mkdir(path, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(path)
+    import stat
+
+    if not stat.S_ISDIR(st.st_mode) or (hasattr(os, "getuid") and st.st_uid != uid) or (st.st_mode & 0o077):
+        raise PermissionError(f"{path} is not a private directory of this user")
+    return path
+
+
 class Group:
     """``world`` processes, this one being ``rank``.  Collectives: :meth:`allgather`,
-    :meth:`broadcast`, :meth:`barrier`, :meth:`allreduce_max`."""
+    :meth:`broadcast`, :meth:`barrier`, :meth:`allreduce_max`.
+
+    ``nonce``: a secret every rank of the group knows (``MHX_RDZV_NONCE`` from the spawning parent, or the one
+    rank 0 writes next to its port in the published file); a connection whose hello does not carry it is dropped.
+    ``single_node``: rank 0 listens on the loopback interface only."""
 
     def __init__(self, rank: int, world: int, host: str = "127.0.0.1", port: int = 0, timeout: float = 120.0,
-                 publish: Optional[str] = None):
+                 publish: Optional[str] = None, nonce: Optional[str] = None, single_node: Optional[bool] = None):
         if not (0 <= rank < world):
             raise ValueError("rank out of range")
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
@@ -73,58 +124,91 @@ class Group:
         self._sock: Optional[socket.socket] = None                   # ranks > 0: connection to rank 0
         self._listener: Optional[socket.socket] = None
         self._publish = publish
+        self._published = False
         if world == 1:
             return
-        if rank == 0:
-            lst = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-            lst.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-            # a loopback / literal address is bound as given; a host NAME (MASTER_ADDR on a cluster) may not
-            # resolve to a local interface, so rank 0 then listens on all of them
-            lst.bind((host if host[:1].isdigit() else "", port))
-            lst.listen(world)
-            lst.settimeout(timeout)
-            self._listener = lst
-            self.port = lst.getsockname()[1]
-            if publish:
-                tmp = publish + ".%d.tmp" % os.getpid()
-                with open(tmp, "w") as f:
-                    json.dump({"host": host if host[:1].isdigit() else "127.0.0.1", "port": self.port, "pid": os.getpid(),
-                               "time": time.time()}, f)
-                os.replace(tmp, publish)
-            for _ in range(world - 1):
+        if single_node is None:
+            single_node = publish is not None or host in ("127.0.0.1", "localhost", "::1")
+        try:
+            if rank == 0:
+                self._serve(host, port, timeout, publish, nonce, single_node)
+            else:
+                self._join(host, port, timeout, publish, nonce)
+        except BaseException:
+            self.close()
+            raise
+
+    def _serve(self, host, port, timeout, publish, nonce, single_node):
+        family, sockaddr = _listen_address(host, port, single_node)
+        lst = socket.socket(family, socket.SOCK_STREAM)
+        self._listener = lst
+        lst.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        lst.bind(sockaddr)
+        lst.listen(self.world)
+        self.port = lst.getsockname()[1]
+        if publish:
+            if nonce is None:
+                nonce = secrets.token_hex(16)
+            info = {"host": "::1" if family == socket.AF_INET6 and single_node else ("127.0.0.1" if single_node else host),
+                    "port": self.port, "pid": os.getpid(), "time": time.time(), "nonce": nonce}
+            try:
+                os.unlink(publish)  # a stale file of an earlier job of this user (the directory is ours alone)
+            except FileNotFoundError:
+                pass
+            fd = os.open(publish, os.O_WRONLY | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+            with os.fdopen(fd, "w") as f:
+                json.dump(info, f)
+            self._published = True
+        want = (nonce or "").encode()
+        deadline = time.time() + timeout
+        missing = self.world - 1
+        while missing:
+            left = deadline - time.time()
+            if left <= 0:
+                raise TimeoutError(f"rank 0: {missing} of {self.world - 1} ranks did not join within {timeout:.0f} s")
+            lst.settimeout(left)
+            try:
                 conn, _addr = lst.accept()
+            except socket.timeout:
+                continue
+            try:  # anything that is not a rank of this group is dropped, not fatal: a port scanner, a stale job
+                conn.settimeout(min(5.0, max(0.1, left)))
+                peer, hello = _recv_frame(conn, _HELLO_MAX)
+                if not (0 < peer < self.world) or self._peers[peer] is not None or not hmac.compare_digest(hello, want):
+                    raise ConnectionError("unexpected rendezvous peer")
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 conn.settimeout(timeout)
-                peer, _ = _recv_frame(conn)
-                if not (0 < peer < world) or self._peers[peer] is not None:
-                    raise ConnectionError(f"unexpected rendezvous peer rank {peer}")
                 self._peers[peer] = conn
-        else:
-            deadline = time.time() + timeout
-            last: Optional[Exception] = None
-            while True:
-                target = (host, port)
-                if publish:  # the port is whatever rank 0 published (re-read: a stale file may still be there)
-                    try:
-                        with open(publish) as f:
-                            info = json.load(f)
-                        target = (info["host"], int(info["port"]))
-                    except (OSError, ValueError, KeyError) as e:
-                        last, target = e, None
-                if target is not None:
-                    try:
-                        s = socket.create_connection(target, timeout=5.0)
-                        s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                        s.settimeout(timeout)
-                        _send_frame(s, rank, b"")
-                        self._sock = s
-                        break
-                    except OSError as e:
-                        last = e
-                if time.time() > deadline:
-                    raise TimeoutError(f"rank {rank}: no rendezvous with rank 0 within {timeout:.0f} s ({last!r})")
-                time.sleep(0.05)
-            self.port = target[1]
+                missing -= 1
+            except (OSError, struct.error):
+                conn.close()
+
+    def _join(self, host, port, timeout, publish, nonce):
+        deadline = time.time() + timeout
+        last: Optional[Exception] = None
+        while True:
+            target, hello = (host, port), (nonce or "")
+            if publish:  # port and nonce are whatever rank 0 published (re-read: a stale file may still be there)
+                try:
+                    with open(publish) as f:
+                        info = json.load(f)
+                    target, hello = (info["host"], int(info["port"])), str(info.get("nonce", ""))
+                except (OSError, ValueError, KeyError) as e:
+                    last, target = e, None
+            if target is not None:
+                try:
+                    s = socket.create_connection(target, timeout=5.0)
+                    s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                    s.settimeout(timeout)
+                    _send_frame(s, self.rank, hello.encode())
+                    self._sock = s
+                    break
+                except OSError as e:
+                    last = e
+            if time.time() > deadline:
+                raise TimeoutError(f"rank {self.rank}: no rendezvous with rank 0 within {timeout:.0f} s ({last!r})")
+            time.sleep(0.05)
+        self.port = target[1]
 
     # -- collectives ------------------------------------------------------------------------
     def allgather(self, payload: bytes) -> List[bytes]:
@@ -164,6 +248,13 @@ class Group:
         return [list(struct.unpack(fmt, p)) for p in self.allgather(struct.pack(fmt, *[int(v) for v in values]))]
 
     def close(self) -> None:
+        for comm in list(getattr(self, "_mhx_comms", {}).values()):  # RCCL communicators made for this group (dist.communicator)
+            try:
+                comm.close()
+            except Exception:  # noqa: BLE001
+                pass
+        if hasattr(self, "_mhx_comms"):
+            self._mhx_comms.clear()
         for s in [self._sock, self._listener] + [p for p in self._peers if p is not None]:
             if s is not None:
                 try:
@@ -172,7 +263,8 @@ class Group:
                     pass
         self._sock = self._listener = None
         self._peers = [None] * self.world
-        if self.rank == 0 and self._publish:
+        if self.rank == 0 and self._publish and self._published:
+            self._published = False
             try:
                 os.unlink(self._publish)
             except OSError:
@@ -192,15 +284,15 @@ def from_env(timeout: float = 120.0) -> Group:
     rank = int(os.environ.get("RANK", "0"))
     if world == 1:
         return Group(0, 1)
+    nonce = os.environ.get("MHX_RDZV_NONCE")
     addr = os.environ.get("MHX_RDZV_ADDR")
     if addr:
         host, _, port = addr.rpartition(":")
-        return Group(rank, world, host or "127.0.0.1", int(port), timeout)
+        return Group(rank, world, host.strip("[]") or "127.0.0.1", int(port), timeout, nonce=nonce)
     host = os.environ.get("MASTER_ADDR", "127.0.0.1")
     mport = int(os.environ.get("MASTER_PORT", "29500"))
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
-    if local_world == world:  # one node: rank 0 publishes a free port under the launcher's pid
-        uid = os.getuid() if hasattr(os, "getuid") else 0
-        path = os.path.join(tempfile.gettempdir(), f"mhx_rdzv_{uid}_{mport}_{os.getppid()}")
-        return Group(rank, world, host, 0, timeout, publish=path)
-    return Group(rank, world, host, mport + 1, timeout)
+    if local_world == world:  # one node: rank 0 publishes a free port (and a nonce) under the launcher's pid
+        path = os.path.join(_publish_dir(), f"{mport}_{os.getppid()}")
+        return Group(rank, world, host, 0, timeout, publish=path, nonce=nonce, single_node=True)
+    return Group(rank, world, host, mport + 1, timeout, nonce=nonce, single_node=False)

@@ -195,7 +195,10 @@ class WeightedMinHashGenerator:
 
         ring = self.__dict__.pop("_log_ring", None)  # taken out while in use: a concurrent call makes its own
         if ring is None or ring[0].shape != (rows, dim):  # page-locked: a piece goes up by DMA straight from it
-            ring = [ctx.pinned_empty((rows, dim), np.float32) for _ in range(3)]
+            try:
+                ring = [ctx.pinned_empty((rows, dim), np.float32) for _ in range(3)]
+            except _native.MhxError:  # no page-locked memory to be had: ordinary buffers (the upload is staged then)
+                ring = [np.empty((rows, dim), dtype=np.float32) for _ in range(3)]
         threads = self._PIPE_LOG_THREADS
         starts = list(range(0, n, rows))
 

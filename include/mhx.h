@@ -93,6 +93,7 @@ MHX_API int mhx_dev_free(mhx_ctx *ctx, void *dptr);
 /* page-locked host memory: buffers a caller fills and hands to the host entry points again and again (the pieces of
  * mhx_weighted_dense_feed, staging for mhx_minhash_bulk) go up by DMA straight from it, about 1.3x the rate of pageable memory */
 MHX_API int mhx_host_alloc(mhx_ctx *ctx, size_t bytes, void **ptr);
+/* ctx may be NULL once the allocating context has been destroyed (mhx_ctx_destroy does not free these blocks) */
 MHX_API int mhx_host_free(mhx_ctx *ctx, void *ptr);
 MHX_API int mhx_memcpy_h2d(mhx_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 MHX_API int mhx_memcpy_d2h(mhx_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);

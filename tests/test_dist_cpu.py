@@ -168,3 +168,107 @@ def test_bench_self_launch_spawns_ranks_and_propagates_failure_without_a_gpu():
                        timeout=300, env=env)
     assert p.returncode != 0
     assert (p.stdout + p.stderr).count("no HIP device visible") == 2
+
+
+# ---- the rendezvous itself: strangers are dropped, frames are capped, the published port is private ----
+def _group_in_thread(rank, world, port, nonce, out, **kw):
+    from datasketch_amd import rendezvous
+
+    try:
+        out[rank] = rendezvous.Group(rank, world, "127.0.0.1", port, timeout=20.0, nonce=nonce, **kw)
+    except Exception as e:  # noqa: BLE001
+        out[rank] = e
+
+
+def test_rendezvous_drops_strangers_instead_of_aborting():
+    """A connection that is not a rank of the group -- wrong magic, an oversized hello, the wrong nonce, a rank number
+    twice -- is closed and the group still forms; rank 0 listens on the loopback interface only."""
+    import struct
+    import threading
+    import time
+
+    from datasketch_amd import rendezvous
+
+    port = _free_port()
+    res = {}
+    t0 = threading.Thread(target=_group_in_thread, args=(0, 2, port, "s3cret", res))
+    t0.start()
+    hdr = struct.Struct("<4sIQ")
+    deadline = time.time() + 10
+    while True:  # wait for the listener
+        try:
+            s = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+            break
+        except OSError:
+            assert time.time() < deadline
+            time.sleep(0.02)
+    s.sendall(b"GET / HTTP/1.0\r\n\r\n" + b"\0" * 16)  # not our protocol
+    s.close()
+    for frame in (hdr.pack(b"MHXR", 1, 1 << 40),                        # a hello that claims a terabyte
+                  hdr.pack(b"MHXR", 1, 5) + b"wrong",                   # the wrong nonce
+                  hdr.pack(b"MHXR", 7, 6) + b"s3cret"):                 # a rank outside the group
+        with socket.create_connection(("127.0.0.1", port), timeout=1.0) as c:
+            c.sendall(frame)
+            time.sleep(0.05)
+    t1 = threading.Thread(target=_group_in_thread, args=(1, 2, port, "s3cret", res))
+    t1.start()
+    t0.join(30)
+    t1.join(30)
+    g0, g1 = res[0], res[1]
+    assert isinstance(g0, rendezvous.Group) and isinstance(g1, rendezvous.Group), (g0, g1)
+    assert g0._listener.getsockname()[0] == "127.0.0.1"
+    got = {}
+    th = threading.Thread(target=lambda: got.update(a=g1.allgather(b"one")))
+    th.start()
+    assert g0.allgather(b"zero") == [b"zero", b"one"]
+    th.join(10)
+    assert got["a"] == [b"zero", b"one"]
+    g0.close()
+    g1.close()
+
+
+def test_rendezvous_frame_cap_and_cleanup_on_failure(tmp_path, monkeypatch):
+    """_recv_frame refuses a length above its limit before allocating; a rank 0 whose peers never come closes its
+    listener and removes the published file; the file is private (0600, O_EXCL) inside a 0700 directory."""
+    import stat
+    import struct
+
+    from datasketch_amd import rendezvous
+
+    a, b = socket.socketpair()
+    a.sendall(struct.pack("<4sIQ", b"MHXR", 0, 10_000))
+    with pytest.raises(ConnectionError):
+        rendezvous._recv_frame(b, limit=1000)
+    a.close()
+    b.close()
+    monkeypatch.setenv("TMPDIR", str(tmp_path))
+    import tempfile
+
+    monkeypatch.setattr(tempfile, "tempdir", None)
+    d = rendezvous._publish_dir()
+    assert stat.S_IMODE(os.stat(d).st_mode) == 0o700
+    path = os.path.join(d, "29500_1")
+    seen = {}
+
+    def peek():  # what a joining rank would read while rank 0 waits
+        import time
+
+        for _ in range(200):
+            if os.path.exists(path):
+                seen["mode"] = stat.S_IMODE(os.stat(path).st_mode)
+                seen["info"] = open(path).read()
+                return
+            time.sleep(0.01)
+
+    import threading
+
+    th = threading.Thread(target=peek)
+    th.start()
+    with pytest.raises(TimeoutError):
+        rendezvous.Group(0, 2, "127.0.0.1", 0, timeout=1.0, publish=path)
+    th.join()
+    assert seen["mode"] == 0o600 and '"nonce"' in seen["info"]
+    assert not os.path.exists(path)  # removed with the failed group
+    os.chmod(d, 0o755)
+    with pytest.raises(PermissionError):
+        rendezvous._publish_dir()
