@@ -55,7 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--allgather", action="store_true", help="RCCL all-gather of the uint32 shards inside every step")
     ap.add_argument("--no-allgather-probe", action="store_true", help="N > 1: skip the separate all-gather measurement")
-    ap.add_argument("--probe-timeout", type=float, default=120.0, help="seconds the all-gather probe may take before it is given up")
+    ap.add_argument("--probe-timeout", type=float, default=240.0, help="seconds the all-gather probe may take before it is given up (a first ncclCommInitRank over 8 GPUs can take tens of seconds)")
     ap.add_argument("--check-rows", type=int, default=4096, help="rows verified against the numpy path")
     ap.add_argument("--cpu-sample", type=int, default=160_000, help="sets timed on the CPU baseline (0 = skip)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive host->host measurement")
@@ -102,7 +102,7 @@ def main():
     from datasketch_amd import _native, rendezvous
     from datasketch_amd.minhash import MinHash
 
-    group = rendezvous.from_env()
+    group = rendezvous.from_env(timeout=float(os.environ.get("MHX_RDZV_TIMEOUT", "300")))  # eight ranks start eight HIP runtimes at once
     world, rank = group.world, group.rank
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world != args.gpus:
@@ -130,15 +130,31 @@ def main():
     proto = MinHash(num_perm=k, seed=args.seed, hashfunc=lambda x: x)
     perms = proto.permutations
 
-    # ---- synthetic corpus, resident in HBM before timing
+    # ---- synthetic corpus, resident in HBM before timing.  One rank keeps the whole numpy array (the CPU baseline, the
+    # host-to-host figures and the extra configs read it); with several ranks on a node each generates its shard in
+    # pieces of 50k sets (100 MB) that go up as they are made -- same RandomState stream, bounded host footprint --
+    # and keeps only the rows the parity check will look at.
     rng = np.random.RandomState(42 + rank)
-    tokens = rng.randint(0, 2**32, size=(n, t), dtype=np.uint64)
-    if args.u32:
-        d_tok = ctx.to_device(tokens.astype(np.uint32))
-        tok_dtype, out_dtype, out_np, tok_bytes, out_bytes = _native.MHX_U32, _native.MHX_U32, np.uint32, 4, 4
+    tok_dtype, out_dtype, out_np, tok_bytes, out_bytes = ((_native.MHX_U32, _native.MHX_U32, np.uint32, 4, 4) if args.u32
+                                                          else (_native.MHX_U64, _native.MHX_U64, np.uint64, 8, 8))
+    tok_np = np.uint32 if args.u32 else np.uint64
+    check = max(0, min(args.check_rows, n))
+    check_rows_idx = np.unique(np.linspace(0, n - 1, check).astype(np.int64)) if check else np.empty(0, dtype=np.int64)
+    if world == 1:
+        tokens = rng.randint(0, 2**32, size=(n, t), dtype=np.uint64)
+        d_tok = ctx.to_device(tokens.astype(tok_np) if args.u32 else tokens)
+        check_tokens = tokens[check_rows_idx]
     else:
-        d_tok = ctx.to_device(tokens)
-        tok_dtype, out_dtype, out_np, tok_bytes, out_bytes = _native.MHX_U64, _native.MHX_U64, np.uint64, 8, 8
+        tokens = None
+        d_tok = ctx.alloc(n * t * tok_bytes)
+        kept, piece = [], 50_000
+        for lo in range(0, n, piece):
+            part = rng.randint(0, 2**32, size=(min(piece, n - lo), t), dtype=np.uint64)
+            sel = check_rows_idx[(check_rows_idx >= lo) & (check_rows_idx < lo + len(part))] - lo
+            kept.append(part[sel])
+            d_tok.upload(part.astype(tok_np) if args.u32 else part, offset=lo * t * tok_bytes)
+        check_tokens = np.concatenate(kept) if kept else np.empty((0, t), dtype=np.uint64)
+        del part, kept
     d_out = ctx.alloc(n * k * out_bytes)
     ctx.perm_handle(perms)
 
@@ -190,14 +206,12 @@ def main():
     from datasketch_amd.hashfunc import prehashed
 
     a, b = perms
-    check = max(0, min(args.check_rows, n))
     sig_head = None
     if check or (args.cpu_sample > 0 and rank == 0 and world == 1):
         sig = d_out.download((n, k), out_np)
         if check:
-            rows = np.unique(np.linspace(0, n - 1, check).astype(np.int64))
-            want = MinHash.bulk_signatures(tokens[rows], num_perm=k, seed=args.seed, hashfunc=prehashed, gpu_mode="disable")
-            if not np.array_equal(sig[rows].astype(np.uint64), want):
+            want = MinHash.bulk_signatures(check_tokens, num_perm=k, seed=args.seed, hashfunc=prehashed, gpu_mode="disable")
+            if not np.array_equal(sig[check_rows_idx].astype(np.uint64), want):
                 raise SystemExit("PARITY FAILURE: GPU signatures differ from the numpy path")
         sig_head = sig[: min(n, 40_000)].astype(np.uint64)
         del sig
@@ -274,6 +288,7 @@ def main():
         dog.start()
         try:
             out["allgather"] = allgather_probe(ctx, group, gather, perms, d_tok, tok_dtype, n, t, k)
+            out["per_rank"]["rccl_ranks_seen"] = out["allgather"].get("rccl_ranks_seen")  # ncclCommCount as every rank reports it
         except (ConnectionError, TimeoutError, OSError) as e:  # a peer left (its own watchdog, or a crash inside RCCL)
             out["allgather"] = {"error": repr(e)}
             if rank == 0:

@@ -234,3 +234,67 @@ def test_device_log_mode_through_the_walk(ctx):
     mism = np.argwhere(np.any(hv != hv_l, axis=2))
     assert len(mism) < 1e-5 * n * s
     assert weighted_gap_gate(x, g, hv, hv_l, mism)["unexplained"] == 0
+
+
+# ------------------------------------------------------------------ bench.py at N = 8 (one GPU shared: plumbing only)
+def _bench(argv, env=None, timeout=900):
+    import subprocess
+    import sys
+
+    e = dict(os.environ)
+    for var in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MHX_RDZV_ADDR", "MHX_RDZV_NONCE", "TORCHELASTIC_RUN_ID"):
+        e.pop(var, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True, timeout=timeout, env=e, cwd=ROOT)
+
+
+def _keys(obj, prefix=""):
+    if isinstance(obj, dict):
+        out = set()
+        for k, v in obj.items():
+            out |= {prefix + k} | _keys(v, prefix + k + ".")
+        return out
+    return set()
+
+
+def test_bench_with_eight_ranks_on_one_gpu():
+    """The driver's SCALE run is the first launch with eight ranks anybody makes.  Here eight ranks share this box's one
+    GPU (--share-devices: the numbers mean nothing): eight HIP runtimes start at once, the star rendezvous forms at
+    world 8, every rank generates its shard in bounded pieces, the MAX over ranks is taken, rank 0 alone prints.  With
+    the all-gather probe on, RCCL refuses eight ranks on one device; that must come back as an error in the line, from
+    every rank, before the watchdog -- not as a hang."""
+    import json
+
+    p = _bench(["--gpus", "8", "--steps", "3", "--warmup", "1", "--sets", "20000", "--check-rows", "256", "--share-devices", "--no-allgather-probe"])
+    assert p.returncode == 0, p.stdout + p.stderr
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # only rank 0 prints
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["value"] > 0
+    assert len(line["per_rank"]["ms_per_step"]) == 8 and len(line["per_rank"]["kernel_ms"]) == 8 and len(line["per_rank"]["devices"]) == 8
+    assert "cpu_baseline" not in line and "extra" not in line
+    p = _bench(["--gpus", "8", "--steps", "2", "--warmup", "1", "--sets", "10000", "--check-rows", "64", "--share-devices", "--probe-timeout", "120"])
+    assert p.returncode == 0, p.stdout + p.stderr
+    line = json.loads([ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and "allgather" in line
+    ag = line["allgather"]
+    assert "error" in ag or ag.get("rccl_ranks_seen") == [8] * 8  # one device: refused by RCCL (or, if it ever works, complete)
+    if "error" in ag:
+        assert "did not finish" not in str(ag["error"])  # the refusal came back from RCCL, the watchdog never fired
+
+
+def test_bench_line_is_the_same_with_and_without_a_launcher_environment_at_one_gpu():
+    """N = 1 under `python bench.py` and under a launcher that exports RANK=0 / WORLD_SIZE=1: the same keys at every
+    level of the line, and the same number within the spread of two short runs."""
+    import json
+
+    args = ["--sets", "200000", "--steps", "10", "--warmup", "2", "--cpu-sample", "0", "--no-e2e", "--no-extra", "--check-rows", "512"]
+    plain = _bench(args)
+    assert plain.returncode == 0, plain.stdout + plain.stderr
+    launched = _bench(args, env={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "LOCAL_WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29511"})
+    assert launched.returncode == 0, launched.stdout + launched.stderr
+    a = json.loads(plain.stdout.strip().splitlines()[-1])
+    b = json.loads(launched.stdout.strip().splitlines()[-1])
+    assert _keys(a) == _keys(b)
+    assert abs(a["value"] - b["value"]) <= 0.05 * a["value"]
+    assert a["n_gpus"] == b["n_gpus"] == 1 and a["metric"] == b["metric"]
