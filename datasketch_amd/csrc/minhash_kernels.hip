@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
 // a lane group reads the same address, a broadcast), and the sieve runs per lane exactly as in kernel A -- row minima
 // of 16 keys, tagged top-two fold, rescan of the best row, one exact candidate; the partial last row takes part with
 // its stale cells masked.  A set whose proof fails in any of its lanes is flagged for the dedup / pairwise launches.
-template <int KP, typename TokT, typename OutT>
+template <int KP, int P, typename TokT, typename OutT>
 __global__ __launch_bounds__(256) void minhash_packed_kernel(const BulkArgs args) {
     constexpr int G = kWave / KP;
     constexpr int STRIDE = 36;
@@ -1149,16 +1149,20 @@ __global__ __launch_bounds__(256) void minhash_packed_kernel(const BulkArgs args
     __shared__ __attribute__((aligned(16))) uint32_t stage[4 * G * kStageWordsPerWave];
     uint32_t *tiles = stage + wave * (G * kStageWordsPerWave);
     uint32_t *my_tile = tiles + g * kStageWordsPerWave;
-    const bool active = k < args.num_perm;
-    Perms<1> pm;
-    SievePerms<1> sp;
-    {
-        const uint64_t a = active ? args.a[k] : 0, b = active ? args.b[k] : 0;
-        pm.a_lo[0] = sp.a_lo[0] = (uint32_t)a;
-        pm.a_hi[0] = (uint32_t)(a >> 32);
-        pm.b[0] = b;
-        sp.b8[0] = b + 8;
-        sp.active[0] = active;
+    // lane k of a group holds permutations k, k + KP, ... (P of them): a token read from the tile serves all P
+    Perms<P> pm;
+    SievePerms<P> sp;
+    bool any_active = false;
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        const bool active = k + q * KP < args.num_perm;
+        const uint64_t a = active ? args.a[k + q * KP] : 0, b = active ? args.b[k + q * KP] : 0;
+        pm.a_lo[q] = sp.a_lo[q] = (uint32_t)a;
+        pm.a_hi[q] = (uint32_t)(a >> 32);
+        pm.b[q] = b;
+        sp.b8[q] = b + 8;
+        sp.active[q] = active;
+        any_active |= active;
     }
     const TokT *hv_vec = static_cast<const TokT *>(args.hv);
     OutT *__restrict__ out = static_cast<OutT *>(args.out);
@@ -1172,7 +1176,9 @@ __global__ __launch_bounds__(256) void minhash_packed_kernel(const BulkArgs args
             beg = args.offsets ? args.offsets[set] : set * args.fixed_len;
             end = args.offsets ? args.offsets[set + 1] : beg + args.fixed_len;
         }
-        uint32_t res[1] = {kMaxHash};
+        uint32_t res[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q) res[q] = kMaxHash;
         bool fail = false;
         for (int64_t boff = 0; __any(beg + boff < end); boff += kBlockRows * kRowTokens) {
             const int64_t blk = beg + boff;
@@ -1211,7 +1217,7 @@ __global__ __launch_bounds__(256) void minhash_packed_kernel(const BulkArgs args
             }
             // (LDS operations of one wave complete in order: the tiles are written before they are read below)
             const int nrows = nb >> 4, rest = nb & 15;
-            Two rows[1];
+            Two rows[P];
             // rows of every group in lock step up to the longest set of the wave: no divergent control flow around
             // the LDS reads (a group that has run out of rows reads stale cells and its row is dropped by a select)
             int max_rows = 0;
@@ -1220,38 +1226,53 @@ __global__ __launch_bounds__(256) void minhash_packed_kernel(const BulkArgs args
 #pragma unroll 2
             for (int r = 0; r < max_rows; ++r) {
                 const uint32_t *rowp = my_tile + r * STRIDE;
-                uint32_t row = kMaxHash;
+                uint32_t row[P];
 #pragma unroll
                 for (int c = 0; c < kRowTokens; c += 2) {
-                    const uint32_t k0 = sieve_key(rowp[2 * c], sp.a_lo[0], sp.b8[0]);
-                    const uint32_t k1 = sieve_key(rowp[2 * c + 2], sp.a_lo[0], sp.b8[0]);
-                    row = c == 0 ? min(k0, k1) : umin3(row, k0, k1);
+                    const uint32_t h0 = rowp[2 * c], h1 = rowp[2 * c + 2];
+#pragma unroll
+                    for (int q = 0; q < P; ++q) {
+                        const uint32_t k0 = sieve_key(h0, sp.a_lo[q], sp.b8[q]);
+                        const uint32_t k1 = sieve_key(h1, sp.a_lo[q], sp.b8[q]);
+                        row[q] = c == 0 ? min(k0, k1) : umin3(row[q], k0, k1);
+                    }
                 }
-                rows[0].add(r < nrows ? tag16(row, (uint32_t)r) : kMaxHash);
+#pragma unroll
+                for (int q = 0; q < P; ++q) rows[q].add(r < nrows ? tag16(row[q], (uint32_t)r) : kMaxHash);
             }
             if (__any(rest > 0)) {  // partial last rows (row index nrows <= 15: a full tile has no rest)
-                uint32_t row = kMaxHash;
+                uint32_t row[P];
+#pragma unroll
+                for (int q = 0; q < P; ++q) row[q] = kMaxHash;
                 const uint32_t *rowp = my_tile + nrows * STRIDE;
                 for (int c = 0; c < kRowTokens - 1; ++c) {
                     if (!__any(c < rest)) break;
-                    if (c < rest) row = min(row, sieve_key(rowp[2 * c], sp.a_lo[0], sp.b8[0]));
+                    const uint32_t h = rowp[2 * c];
+#pragma unroll
+                    for (int q = 0; q < P; ++q)
+                        if (c < rest) row[q] = min(row[q], sieve_key(h, sp.a_lo[q], sp.b8[q]));
                 }
-                if (rest > 0) rows[0].add(tag16(row, (uint32_t)nrows));
+#pragma unroll
+                for (int q = 0; q < P; ++q)
+                    if (rest > 0) rows[q].add(tag16(row[q], (uint32_t)nrows));
             }
-            if (nb > 0) fail |= finish_block<1, STRIDE, 2, true>(rows, my_tile, pm, sp, res, (uint32_t)nrows, (uint32_t)rest);
+            if (nb > 0) fail |= finish_block<P, STRIDE, 2, true>(rows, my_tile, pm, sp, res, (uint32_t)nrows, (uint32_t)rest);
         }
-        const bool group_failed = (__ballot(fail && active) & group_lanes) != 0;
+        const bool group_failed = (__ballot(fail && any_active) & group_lanes) != 0;
         if (has && k == 0) args.redo[set] = group_failed ? 1 : 0;
-        if (has && active && !group_failed) {
-            uint64_t v;
-            if (args.init) {
-                const uint64_t iv = args.init[set * args.init_stride + k];
-                v = end > beg ? (uint64_t)min((iv >> 32) ? kMaxHash : (uint32_t)iv, res[0]) : iv;  // empty set: state untouched
-            } else {
-                v = end > beg ? res[0] : kMaxHash;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            if (has && sp.active[q] && !group_failed) {
+                uint64_t v;
+                if (args.init) {
+                    const uint64_t iv = args.init[set * args.init_stride + k + q * KP];
+                    v = end > beg ? (uint64_t)min((iv >> 32) ? kMaxHash : (uint32_t)iv, res[q]) : iv;  // empty set: state untouched
+                } else {
+                    v = end > beg ? res[q] : kMaxHash;
+                }
+                if (sizeof(OutT) == 4) v = v > kMaxHash ? kMaxHash : v;
+                out[set * args.num_perm + k + q * KP] = (OutT)v;
             }
-            if (sizeof(OutT) == 4) v = v > kMaxHash ? kMaxHash : v;
-            out[set * args.num_perm + k] = (OutT)v;
         }
     }
 }
@@ -1395,17 +1416,27 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_
             const BulkArgs &args_s = sieve_args;
             const bool plain = !args.init && !args.stats && args.alias_mask < 0;
             // short signatures: several sets per wave (kernel C) instead of a wave with most of its lanes idle
-            const bool packed = P == 1 && args.num_perm <= 32 && !args.stats && args.alias_mask < 0 && ctx->opt_minhash_packed != 1;
+            // Several sets per wave (kernel C) instead of a wave with idle lanes or half-used registers: num_perm <= 32 one
+            // permutation per lane on 8 / 16 / 32 lanes; 33 .. 64 three or four permutations on 16 lanes (four sets per
+            // wave; K = 48: 1.45 -> 1.13 ms per 1M x 256, K = 64: 1.46 -> 1.40); 65 .. 96 three on 32 lanes (2.14 -> 1.96).
+            // From 97 on one set per wave with its tokens on the scalar path is faster (K = 128: 2.19 against 2.42 ms, short
+            // ragged sets 1.02 against 1.21): minhash.packed = 2 takes those through kernel C all the same (profiling).
+            const int np = args.num_perm;
+            const bool packable = !args.stats && args.alias_mask < 0 && ctx->opt_minhash_packed != 1;
+            const bool packed = packable && P <= 2 && (np <= 96 || (ctx->opt_minhash_packed == 2 && np <= 128));
             if (packed) {
-                const int kp = args.num_perm <= 8 ? 8 : args.num_perm <= 16 ? 16 : 32;
+                const int kp = np <= 8 ? 8 : np <= 16 ? 16 : np <= 32 ? 32 : np <= 64 ? 16 : np <= 96 ? 32 : 64;
                 const int64_t items = (args.n_sets + 64 / kp - 1) / (64 / kp);
                 dim3 pgrid((unsigned)std::max<int64_t>(1, std::min<int64_t>((items + 3) / 4, max_blocks)), 1u);
-                if (kp == 8)
-                    hipLaunchKernelGGL((minhash_packed_kernel<8, TokT, OutT>), pgrid, dim3(256), 0, ctx->stream, args_s);
-                else if (kp == 16)
-                    hipLaunchKernelGGL((minhash_packed_kernel<16, TokT, OutT>), pgrid, dim3(256), 0, ctx->stream, args_s);
-                else
-                    hipLaunchKernelGGL((minhash_packed_kernel<32, TokT, OutT>), pgrid, dim3(256), 0, ctx->stream, args_s);
+#define MHX_PACKED(KP_, P_) hipLaunchKernelGGL((minhash_packed_kernel<KP_, P_, TokT, OutT>), pgrid, dim3(256), 0, ctx->stream, args_s)
+                if (np <= 8) MHX_PACKED(8, 1);
+                else if (np <= 16) MHX_PACKED(16, 1);
+                else if (np <= 32) MHX_PACKED(32, 1);
+                else if (np <= 48) MHX_PACKED(16, 3);
+                else if (np <= 64) MHX_PACKED(16, 4);
+                else if (np <= 96) MHX_PACKED(32, 3);
+                else MHX_PACKED(64, 2);
+#undef MHX_PACKED
             } else
             if (plain && !args.offsets && args.fixed_len % kRowTokens == 0)  // whole 16-token rows: no tail code in the kernel
                 hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN_FIXED_ROWS>), grid, dim3(256), 0, ctx->stream, args_s);

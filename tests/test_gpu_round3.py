@@ -298,3 +298,42 @@ def test_bench_line_is_the_same_with_and_without_a_launcher_environment_at_one_g
     assert _keys(a) == _keys(b)
     assert abs(a["value"] - b["value"]) <= 0.05 * a["value"]
     assert a["n_gpus"] == b["n_gpus"] == 1 and a["metric"] == b["metric"]
+
+
+# ------------------------------------------------------------------ MinHash: several permutations per lane in kernel C
+@pytest.mark.parametrize("k", [33, 40, 48, 49, 64, 65, 96, 97, 128])
+def test_packed_kernel_with_several_permutations_per_lane(ctx, k):
+    """Kernel C with P permutations per lane (a token read from the LDS tile serves all P): 33 .. 48 permutations run
+    there by default (16 lanes x 3, four sets per wave), 49 .. 128 when minhash.packed = 2 asks for it.  Against the C
+    oracle on ragged sets (empty, shorter than a row, several 256-token blocks, wide tokens, repeated tokens), with an
+    initial state, uint32 tokens and output -- under every setting of the option."""
+    rng = np.random.RandomState(300 + k)
+    n = 2051
+    lens = rng.randint(0, 600, size=n)
+    lens[:8] = [0, 1, 15, 16, 17, 255, 256, 257]
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    hv = rng.randint(0, 2**32, int(offsets[-1]), dtype=np.uint64)
+    wide = rng.random_sample(hv.size) < 0.01
+    hv[wide] = rng.randint(0, 2**64, int(wide.sum()), dtype=np.uint64)
+    hv[offsets[20] : offsets[20] + 5] = hv[offsets[20]]  # repeated tokens: proofs fail, the set goes to the dedup launch
+    a, b = O.np_init_permutations(k, 3)
+    init = rng.randint(0, 2**32, (n, k), dtype=np.uint64)
+    init[3, 0] = 2**40
+    want = O.c_minhash_bulk(hv, offsets, a, b)
+    want_init = O.c_minhash_bulk(hv, offsets, a, b, init)
+    narrow = hv & np.uint64(0xFFFFFFFF)
+    want32 = O.c_minhash_bulk(narrow, offsets, a, b)
+    dense = rng.randint(0, 2**32, (1001, 48), dtype=np.uint64)
+    want_dense = O.c_minhash_bulk_dense(dense, a, b)
+    for packed in (0, 1, 2):
+        ctx.set_option("minhash.packed", packed)
+        ctx.set_option("minhash.split", 1)
+        try:
+            assert np.array_equal(ctx.minhash_bulk((a, b), hv, offsets, 0, n), want), packed
+            assert np.array_equal(ctx.minhash_bulk((a, b), hv, offsets, 0, n, init), want_init), packed
+            got32 = ctx.minhash_bulk((a, b), narrow.astype(np.uint32), offsets, 0, n, out_dtype=np.uint32)
+            assert np.array_equal(got32.astype(np.uint64), want32), packed
+            assert np.array_equal(ctx.minhash_bulk((a, b), dense.reshape(-1), None, 48, 1001), want_dense), packed
+        finally:
+            ctx.set_option("minhash.packed", 0)
+            ctx.set_option("minhash.split", 0)
