@@ -55,6 +55,205 @@ __global__ __launch_bounds__(256) void gather_digests_kernel(const uint64_t *__r
         sorted_digests[p] = digests[(int64_t)rows[p] * bands + p / n];
 }
 
+// ---- the bands bucketed in two passes (round 3) ------------------------------------------------------------
+// FNV digests of band keys are uniform, so a most-significant-digit split lands the elements of a band in bins of
+// nearly equal size, and a bin small enough for LDS is finished there: two passes over 12-byte (digest, row) pairs
+// instead of the library sort's four over key + value (with the digests' lower bits riding along).
+//   pass 1 (lsh_bin_scatter_kernel): a team of 256 threads takes 2048 rows of ONE band, computes their digests (the band's
+//     r values are 32 or 64 contiguous bytes of a row; the teams of a workgroup take the bands that share those rows'
+//     cache lines), counts them per bin in LDS (the top bin_bits of the digest), reserves a range in
+//     every bin's slab with one global atomic per (workgroup, bin) and writes (digest, row) there.
+//   pass 2 (lsh_bin_sort_kernel): one workgroup per (band, bin) loads the slab (about 2400 elements) into LDS, spreads
+//     it over 2048 buckets by the next 11 digest bits (one or two elements per bucket), ranks every element inside its
+//     bucket by (digest, row) and writes it to its place in the output: band * n + the sizes of the band's bins before
+//     it + the bucket's start + the rank.  The order is (band, digest, row): exactly what the stable radix sort of rows in
+//     ascending order gives.
+// A bin can hold kBinCap elements; one that would overflow (a corpus of near-identical signatures) raises a flag that the
+// host reads after pass 1, and the call falls back to the radix sort.
+constexpr int kBinCap = 3072;
+constexpr int kScatterRows = 8;   // rows per thread of pass 1 (2048 per workgroup: 26 KB of LDS, six workgroups per CU)
+constexpr int kSubBits = 11;
+constexpr int kSortThreads = 512;
+constexpr int kMaxBinBits = 12;
+
+// inclusive prefix sum over the threads of a workgroup: shuffles inside a wave, the wave totals through LDS
+__device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t *tmp4, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)v, o);
+        if (lane >= o) v += up;
+    }
+    if (lane == 63) tmp4[wave] = v;
+    __syncthreads();
+    uint32_t add = 0;
+    for (int w = 0; w < wave; ++w) add += tmp4[w];
+    __syncthreads();
+    return v + add;
+}
+
+__device__ __forceinline__ uint32_t bin_of(uint64_t digest, int bin_bits) { return bin_bits ? (uint32_t)(digest >> (64 - bin_bits)) : 0u; }
+
+// A workgroup is `band_share` teams of 256 threads; team q takes band group * band_share + q of the same 2048 rows.  The
+// bands of a group are the ones whose r values of a row share a 128-byte line: the teams load in lock step, so the line
+// comes from HBM once (one workgroup per band left that to the L2 -- whose 4 MB turn over in microseconds under this
+// stream: 1.04 ms for the pass instead of 0.5).
+template <typename SigT>
+__global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__restrict__ sig, int32_t k, int32_t r, int64_t n, int32_t bands,
+                                                               int bin_bits, int band_share, uint32_t *__restrict__ cursor,
+                                                               uint64_t *__restrict__ slab_dig, uint32_t *__restrict__ slab_row,
+                                                               uint32_t *__restrict__ overflow) {
+    constexpr int kChunk = 256 * kScatterRows;
+    extern __shared__ uint64_t scatter_lds[];  // per team: st_dig[kChunk] | hist[nb] | base[nb] | lstart[nb] | st_row u16[kChunk] | scan_tmp[4]
+    const int nb = 1 << bin_bits, team = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const size_t team_words = kChunk + (3 * (size_t)nb * 4 + kChunk * 2 + 16 + 7) / 8;
+    uint64_t *st_dig = scatter_lds + team * team_words;  // the chunk's elements grouped by bin before they go out
+    uint32_t *hist = reinterpret_cast<uint32_t *>(st_dig + kChunk), *base = hist + nb, *lstart = base + nb;
+    uint16_t *st_row = reinterpret_cast<uint16_t *>(lstart + nb);  // row - row0
+    uint32_t *scan_tmp = reinterpret_cast<uint32_t *>(st_row + kChunk);
+    const int64_t chunks = (n + kChunk - 1) / kChunk;
+    const int groups = bands / band_share;
+    for (int64_t item = blockIdx.x; item < chunks * groups; item += gridDim.x) {
+        const int band = (int)(item % groups) * band_share + team;
+        const int64_t row0 = item / groups * kChunk;
+        for (int t = tid; t < nb; t += 256) hist[t] = 0;
+        __syncthreads();
+        uint64_t dg[kScatterRows];
+#pragma unroll
+        for (int j = 0; j < kScatterRows; ++j) {
+            const int64_t row = row0 + j * 256 + tid;
+            if (row < n) {
+                dg[j] = band_digest_of<SigT>(sig, row, band, k, r);
+                atomicAdd(&hist[bin_of(dg[j], bin_bits)], 1u);
+            }
+        }
+        __syncthreads();
+        // per bin: a range of its slab (one global atomic) and the start of its elements in the team's staging area
+        // (exclusive scan of the counts: thread t owns bins [t * per, t * per + per))
+        {
+            const int per = (nb + 255) / 256;
+            uint32_t sum = 0;
+            for (int j = 0; j < per; ++j) {
+                const int t = tid * per + j;
+                if (t < nb) sum += hist[t];
+            }
+            const uint32_t incl = block_inclusive_scan(sum, scan_tmp, tid);
+            uint32_t at = incl - sum;
+            for (int j = 0; j < per; ++j) {
+                const int t = tid * per + j;
+                if (t < nb) {
+                    const uint32_t c = hist[t];
+                    const uint32_t b = c ? atomicAdd(&cursor[(int64_t)band * nb + t], c) : 0u;
+                    if (b + c > (uint32_t)kBinCap) *overflow = 1u;
+                    base[t] = b;
+                    lstart[t] = at;
+                    hist[t] = 0;
+                    at += c;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kScatterRows; ++j) {
+            const int64_t row = row0 + j * 256 + tid;
+            if (row < n) {
+                const uint32_t bin = bin_of(dg[j], bin_bits);
+                const uint32_t lp = lstart[bin] + atomicAdd(&hist[bin], 1u);
+                st_dig[lp] = dg[j];
+                st_row[lp] = (uint16_t)(j * 256 + tid);
+            }
+        }
+        __syncthreads();
+        // out: consecutive threads carry consecutive elements of a bin -- every (team, bin) piece is one contiguous run
+        const uint32_t total = (uint32_t)min((int64_t)kChunk, n - row0);
+        for (uint32_t i = tid; i < total; i += 256) {
+            const uint64_t d = st_dig[i];
+            const uint32_t bin = bin_of(d, bin_bits);
+            const uint32_t pos = base[bin] + (i - lstart[bin]);
+            if (pos < (uint32_t)kBinCap) {
+                const int64_t at = ((int64_t)band * nb + bin) * kBinCap + pos;
+                slab_dig[at] = d;
+                slab_row[at] = (uint32_t)(row0 + st_row[i]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ bool pair_less(uint64_t da, uint32_t ra, uint64_t db, uint32_t rb) { return da < db || (da == db && ra < rb); }
+
+__global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32_t *__restrict__ cursor, const uint64_t *__restrict__ slab_dig,
+                                                           const uint32_t *__restrict__ slab_row, int64_t n, int32_t bands, int bin_bits,
+                                                           uint64_t *__restrict__ out_dig, uint32_t *__restrict__ out_row) {
+    __shared__ uint64_t dig[kBinCap];
+    __shared__ uint32_t row[kBinCap];
+    __shared__ uint32_t cnt[1 << kSubBits], start[1 << kSubBits];
+    __shared__ uint32_t part[kSortThreads];
+    __shared__ uint32_t scan_tmp[kSortThreads / 64];
+    const int nb = 1 << bin_bits, tid = threadIdx.x;
+    constexpr int kSub = 1 << kSubBits, kPer = kSub / kSortThreads;
+    for (int64_t item = blockIdx.x; item < (int64_t)bands * nb; item += gridDim.x) {
+        const int64_t band = item >> bin_bits;
+        const int bin = (int)(item & (nb - 1));
+        const uint32_t *cur = cursor + band * nb;
+        const uint32_t count = min(cur[bin], (uint32_t)kBinCap);
+        // where the bin goes: behind the band's bins before it
+        uint32_t before = 0;
+        for (int t = tid; t < bin; t += kSortThreads) before += min(cur[t], (uint32_t)kBinCap);
+        part[tid] = before;
+        for (int t = tid; t < kSub; t += kSortThreads) cnt[t] = 0;
+        __syncthreads();
+        for (int o = kSortThreads / 2; o > 0; o >>= 1) {
+            if (tid < o) part[tid] += part[tid + o];
+            __syncthreads();
+        }
+        const int64_t out_base = band * n + part[0];
+        const int64_t slab = item * kBinCap;
+        const auto sub_of = [&](uint64_t d) { return (uint32_t)((bin_bits ? d << bin_bits : d) >> (64 - kSubBits)); };
+        // the slab is read twice (the second time from the L2): bucket sizes first, then every element to its bucket's range
+        // in LDS -- one LDS copy of the bin, three workgroups per CU
+        for (uint32_t i = tid; i < count; i += kSortThreads) atomicAdd(&cnt[sub_of(slab_dig[slab + i])], 1u);
+        __syncthreads();
+        // exclusive scan of the 2048 bucket sizes: a thread's 8 buckets, then the threads' sums
+        uint32_t mine[kPer], sum = 0;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            mine[j] = cnt[tid * kPer + j];
+            sum += mine[j];
+        }
+        const uint32_t incl = block_inclusive_scan(sum, scan_tmp, tid);
+        uint32_t at = incl - sum;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            start[tid * kPer + j] = at;
+            cnt[tid * kPer + j] = 0;
+            at += mine[j];
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < count; i += kSortThreads) {
+            const uint64_t d = slab_dig[slab + i];
+            const uint32_t b = sub_of(d);
+            const uint32_t p = start[b] + atomicAdd(&cnt[b], 1u);
+            dig[p] = d;
+            row[p] = slab_row[slab + i];
+        }
+        __syncthreads();
+        // every element finds its place inside its bucket by counting the bucket's smaller (digest, row) pairs -- one or two
+        // comparisons for uniform digests, the bucket's size for a cluster of equal ones (spread over the whole workgroup:
+        // an element is a thread's, whatever its bucket) -- and goes straight to its position in the output
+        for (uint32_t i = tid; i < count; i += kSortThreads) {
+            const uint64_t d = dig[i];
+            const uint32_t rw = row[i];
+            const uint32_t b = sub_of(d), lo = start[b], hi = lo + cnt[b];
+            uint32_t rank = 0;
+            for (uint32_t j = lo; j < hi; ++j) rank += pair_less(dig[j], row[j], d, rw) ? 1u : 0u;
+            out_dig[out_base + lo + rank] = d;
+            out_row[out_base + lo + rank] = rw;
+        }
+        __syncthreads();
+    }
+}
+
 // ---- the whole digest rides through the sort (n <= 2^(32 - band_bits)) --------------------------------
 // The radix sort orders by the low sort_bits of a 64-bit key and moves the whole key and a 32-bit value every pass.
 // The key's upper 64 - sort_bits bits and the value's bits above the row number are free luggage: the digest bits
@@ -345,9 +544,58 @@ int launch_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *d_sorted_digests, c
     return MHX_OK;
 }
 
+// the two-pass bucketing; *done = false when a bin overflowed (the caller falls back to the radix sort)
+static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t bands, int32_t r,
+                                   uint64_t *d_sorted_digests, uint32_t *d_sorted_rows, bool *done) {
+    *done = false;
+    int bin_bits = 0;
+    while (bin_bits < kMaxBinBits && (n >> bin_bits) > 2500) ++bin_bits;  // about 1250 .. 2500 elements per bin (kBinCap: 3072)
+    if ((n >> bin_bits) > 2500) return MHX_OK;                            // more than 12 million rows: the radix sort
+    const int64_t nb = (int64_t)1 << bin_bits, bins = nb * bands;
+    const size_t cur_bytes = ((sizeof(uint32_t) * (size_t)(bins + 1)) + 255) & ~(size_t)255;
+    const size_t dig_bytes = sizeof(uint64_t) * (size_t)bins * kBinCap, row_bytes = sizeof(uint32_t) * (size_t)bins * kBinCap;
+    if (cur_bytes + dig_bytes + row_bytes > (size_t)ctx->hbm_bytes / 4) return MHX_OK;
+    if (int rc = ctx->ensure_scratch(3, cur_bytes + dig_bytes + row_bytes + 256)) return rc;
+    uint32_t *d_cursor = (uint32_t *)ctx->scratch[3];
+    uint32_t *d_overflow = d_cursor + bins;
+    uint64_t *d_slab_dig = (uint64_t *)((char *)ctx->scratch[3] + cur_bytes);
+    uint32_t *d_slab_row = (uint32_t *)((char *)ctx->scratch[3] + cur_bytes + dig_bytes);
+    MHX_HIP_CHECK(hipMemsetAsync(d_cursor, 0, sizeof(uint32_t) * (size_t)(bins + 1), ctx->stream));
+    // bands whose r values of a row share a 128-byte line go to one workgroup (at most four)
+    const int piece = r * (sig_dtype == MHX_U32 ? 4 : 8);
+    int band_share = piece < 128 && 128 % piece == 0 ? std::min(4, 128 / piece) : 1;
+    while (bands % band_share) band_share >>= 1;
+    const int64_t items = (n + 256 * kScatterRows - 1) / (256 * kScatterRows) * (bands / band_share);
+    const size_t team_bytes = 8 * (size_t)(256 * kScatterRows) + 8 * ((3 * (size_t)nb * 4 + 256 * kScatterRows * 2 + 16 + 7) / 8);
+    const size_t lds1 = team_bytes * band_share;
+    const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(32 / (4 * band_share), (int64_t)((160 << 10) / (lds1 + 64))));
+    const unsigned grid1 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, (int64_t)ctx->num_cus * per_cu * 2));
+    if (sig_dtype == MHX_U32)
+        hipLaunchKernelGGL(lsh_bin_scatter_kernel<uint32_t>, dim3(grid1), dim3(256 * band_share), lds1, ctx->stream, (const uint32_t *)d_sig, k, r, n, bands,
+                           bin_bits, band_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
+    else
+        hipLaunchKernelGGL(lsh_bin_scatter_kernel<uint64_t>, dim3(grid1), dim3(256 * band_share), lds1, ctx->stream, (const uint64_t *)d_sig, k, r, n, bands,
+                           bin_bits, band_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
+    MHX_HIP_CHECK(hipGetLastError());
+    uint32_t overflow = 0;
+    MHX_HIP_CHECK(hipMemcpyAsync(&overflow, d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (overflow) return MHX_OK;
+    hipLaunchKernelGGL(lsh_bin_sort_kernel, dim3((unsigned)std::min<int64_t>(bins, (int64_t)ctx->num_cus * 64)), dim3(kSortThreads), 0, ctx->stream, d_cursor,
+                       d_slab_dig, d_slab_row, n, bands, bin_bits, d_sorted_digests, d_sorted_rows);
+    MHX_HIP_CHECK(hipGetLastError());
+    *done = true;
+    return MHX_OK;
+}
+
 int launch_lsh_sort_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t bands, int32_t r,
                           uint64_t *d_sorted_digests, uint32_t *d_sorted_rows) {
     if (n >= ((int64_t)1 << 32)) return fail(MHX_ERR_UNSUPPORTED, "more than 2^32-1 signatures per call");
+    if (ctx->opt_lsh_sort != 1 && ctx->opt_lsh_sort_bits == 0 && ctx->opt_lsh_gather == 0 && n > 0) {  // the options of the radix path select it
+        bool done = false;
+        if (int rc = launch_lsh_bucket_bands(ctx, d_sig, sig_dtype, n, k, bands, r, d_sorted_digests, d_sorted_rows, &done)) return rc;
+        if (done) return MHX_OK;
+    }
     // scratch[3]: digests[n, bands] | keys u64[total] | sorted keys u64[total] | rows u32[total] | marks u8[total] |
     // rocPRIM temporary
     const int64_t total = n * (int64_t)bands;

@@ -228,6 +228,7 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "host.chunk_bytes")) ctx->opt_host_chunk_bytes = value;
     else if (!strcmp(key, "lsh.sort_bits")) ctx->opt_lsh_sort_bits = value;
     else if (!strcmp(key, "lsh.gather")) ctx->opt_lsh_gather = value;
+    else if (!strcmp(key, "lsh.sort")) ctx->opt_lsh_sort = value;
     else return fail(MHX_ERR_INVALID, "unknown option '%s'", key);
     return MHX_OK;
 }

@@ -67,6 +67,7 @@ struct mhx_ctx {
     int64_t opt_weighted_path = 0;  // 0 auto (dense rows: bound-ordered walk; CSR: reciprocal-multiply quotient + row blocks), 1 IEEE division for every element, 2 every element evaluated (dense rows compacted to CSR: the round-2 path)
     int64_t opt_weighted_debug = 0;  // profiling only (results are wrong): 1 = rows staged and scanned, not walked; 2 = staged without the scan
     int64_t opt_weighted_direct = 0; // walk kernel: rows storing at most this many per mille of the columns are evaluated entry by entry; 0 auto
+    int64_t opt_lsh_sort = 0;       // mhx_lsh_sort_bands: 0 auto (two-pass bucketing, radix sort when a bin would overflow), 1 radix sort
     int64_t opt_lsh_gather = 0;     // mhx_lsh_sort_bands: 1 = gather the full digests after the sort (the fallback path) even when they could ride along
     int64_t opt_lsh_sort_bits = 0;  // mhx_lsh_sort_bands: bits of (band, digest) the radix sort orders by; 0 = from n
     int64_t opt_host_chunk_bytes = 0;  // mhx_minhash_bulk: bytes per pipelined piece; 0 auto (96 MiB, inputs > 256 MiB), < 0 never pipeline

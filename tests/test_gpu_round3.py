@@ -337,3 +337,48 @@ def test_packed_kernel_with_several_permutations_per_lane(ctx, k):
         finally:
             ctx.set_option("minhash.packed", 0)
             ctx.set_option("minhash.split", 0)
+
+
+# ------------------------------------------------------------------ LSH: the bands bucketed in two passes
+@pytest.mark.parametrize("n,b,r,dtype", [(1, 4, 2, np.uint64), (100, 32, 8, np.uint32), (2999, 20, 5, np.uint64), (3001, 20, 5, np.uint32),
+                                         (50_000, 32, 8, np.uint32), (300_000, 16, 4, np.uint64), (70_000, 128, 2, np.uint32), (40_000, 1, 6, np.uint64)])
+def test_bands_bucketed_in_two_passes_match_the_host_sort(ctx, n, b, r, dtype):
+    """mhx_lsh_sort_bands' default path (a scatter into bins by the digest's top bits, every bin finished in LDS) against
+    the stable host sort of (digest, row) per band and against the radix-sort path (lsh.sort = 1), for sizes on both
+    sides of every bin-count step, one band and 128, uint32 and uint64 signatures, with buckets of equal keys."""
+    from datasketch_amd import lsh_bulk as LB
+
+    rng = np.random.RandomState(n % 1000 + b)
+    sig = rng.randint(0, 2**32, (n, b * r + 3), dtype=np.uint64).astype(dtype)
+    if n > 10:
+        sig[rng.randint(0, n, n // 5)] = sig[rng.randint(0, n, n // 5)]          # buckets of equal rows
+        sig[rng.randint(0, n, n // 8), :r] = sig[rng.randint(0, n, n // 8), :r]  # ... and of single bands
+    want_dig, want_rows = LB.sorted_bands(sig, b, r, gpu_mode="disable")
+    got_dig, got_rows = LB.sorted_bands(sig, b, r, gpu_mode="always")
+    assert np.array_equal(got_dig, want_dig) and np.array_equal(got_rows, want_rows)
+    ctx.set_option("lsh.sort", 1)
+    try:
+        radix_dig, radix_rows = LB.sorted_bands(sig, b, r, gpu_mode="always")
+    finally:
+        ctx.set_option("lsh.sort", 0)
+    assert np.array_equal(radix_dig, want_dig) and np.array_equal(radix_rows, want_rows)
+    assert np.array_equal(LB.candidate_pairs(sig, b, r, gpu_mode="always"), LB.candidate_pairs(sig, b, r, gpu_mode="disable"))
+
+
+def test_bands_bucketed_with_clustered_and_identical_signatures(ctx):
+    """Thousands of copies of a few rows (large buckets inside a bin: the bin is finished by the bitonic sort), then tens
+    of thousands of identical rows (a bin overflows: the call falls back to the radix sort) -- same answer as the host."""
+    from datasketch_amd import lsh_bulk as LB
+
+    rng = np.random.RandomState(77)
+    n, b, r = 60_000, 8, 4
+    sig = rng.randint(0, 2**32, (n, b * r), dtype=np.uint64)
+    for c in range(6):  # six clusters of 1500 copies: buckets of 1500 equal digests inside bins of ~3000
+        sig[rng.permutation(n)[:1500]] = sig[c]
+    want_dig, want_rows = LB.sorted_bands(sig, b, r, gpu_mode="disable")
+    got_dig, got_rows = LB.sorted_bands(sig, b, r, gpu_mode="always")
+    assert np.array_equal(got_dig, want_dig) and np.array_equal(got_rows, want_rows)
+    sig[rng.permutation(n)[:25_000]] = sig[0]  # one bucket of 25 000 per band: more than a bin holds
+    want_dig, want_rows = LB.sorted_bands(sig, b, r, gpu_mode="disable")
+    got_dig, got_rows = LB.sorted_bands(sig, b, r, gpu_mode="always")
+    assert np.array_equal(got_dig, want_dig) and np.array_equal(got_rows, want_rows)
