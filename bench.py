@@ -263,7 +263,8 @@ def main():
         "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS,
         "traffic": measured_traffic(n, t, k, args),
-        "traffic_source": "profiles/%s: rocprofv3 --pmc passes over this same command (tools/traffic.sh), replayed here -- not measured in this process" % os.path.basename(TRAFFIC_FILE),
+        "valu_issue_frac": measured_traffic(n, t, k, args, "valu_issue_frac"),
+        "traffic_source": "profiles/%s: rocprofv3 --pmc passes over this same command (tools/traffic.sh), replayed here (traffic, valu_issue_frac) -- not measured in this process" % os.path.basename(TRAFFIC_FILE),
         "kernel": "minhash_bulk_kernel<MODE_SIEVE> (+ the MODE_FULL launch over the flagged sets)",
         "kernel_ms": kernel_ms,
         "algorithmic_bytes_per_launch": alg_bytes,
@@ -336,13 +337,13 @@ def main():
         os._exit(0)
 
 
-def measured_traffic(n, t, k, args):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes of this same command
-    (profiles/r02_traffic_minhash_bulk.json); None for any other shape."""
+def measured_traffic(n, t, k, args, field="traffic_bytes_per_launch"):
+    """HBM bytes per launch (or the share of VALU issue cycles the launch needs) from the committed rocprofv3 PMC
+    passes of this same command (TRAFFIC_FILE; replayed, not measured in this process); None for any other shape."""
     if (n, t, k) != (1_000_000, 256, 128) or args.u32 or not os.path.exists(TRAFFIC_FILE):
         return None
     with open(TRAFFIC_FILE) as f:
-        return json.load(f).get("traffic_bytes_per_launch")
+        return json.load(f).get(field)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -602,7 +603,14 @@ def extra_configs(ctx, tokens, d_tok, seed, only):
         d_sd = ctx.alloc(n3 * bands * 8)
         d_sr = ctx.alloc(n3 * bands * 4)
         ms_dig = _timed(ctx, lambda: _native.check(lib.mhx_band_digests_dev_typed(ctx.handle, dsig.ptr, _native.MHX_U32, n3, k3, bands, r, d_dig.ptr)))
-        ms_sort = _timed(ctx, lambda: _native.check(lib.mhx_lsh_sort_bands_dev_typed(ctx.handle, dsig.ptr, _native.MHX_U32, n3, k3, bands, r, d_sd.ptr, d_sr.ptr)))
+        sort = lambda: _native.check(lib.mhx_lsh_sort_bands_dev_typed(ctx.handle, dsig.ptr, _native.MHX_U32, n3, k3, bands, r, d_sd.ptr, d_sr.ptr))
+        ctx.set_option("lsh.sort", 1)  # A/B: the library radix sort (round 2's path, now the fallback), same call
+        try:
+            ms_sort_radix = _timed(ctx, sort, reps=3)
+            sd_radix, sr_radix = d_sd.download((bands, n3), np.uint64), d_sr.download((bands, n3), np.uint32)
+        finally:
+            ctx.set_option("lsh.sort", 0)
+        ms_sort = _timed(ctx, sort)
         # parity: signature rows against the C oracle, digests against FNV-1a of the reference's key bytes, order of the sort
         rows, tok = sample_rows()
         a3, b3 = p3
@@ -621,16 +629,23 @@ def extra_configs(ctx, tokens, d_tok, seed, only):
         for j in (0, bands - 1):
             if np.any(sd[j, 1:] < sd[j, :-1]) or not np.array_equal(dig[sr[j].astype(np.int64), j], sd[j]):
                 raise SystemExit("PARITY FAILURE (extra.c3): sorted bands are not the digests in ascending order")
-        del sig, dig, sd, sr
+        if not (np.array_equal(sd, sd_radix) and np.array_equal(sr, sr_radix)):
+            raise SystemExit("PARITY FAILURE (extra.c3): the bucketing passes and the stable radix sort disagree")
+        del sig, dig, sd, sr, sd_radix, sr_radix
         res["c3"] = {
             "workload": f"config 3 per-GPU shard: {n3} sets x {t} tokens, num_perm={k3} (uint64 tokens in, uint32 signatures out = the all-gather's wire format), then LSH band digests ({bands} bands x {r}) and the bucketing sort",
             "signatures": dict(_roof(n3 * (8 * t + 4 * k3), ms_sig), signatures_per_s=n3 / (ms_sig * 1e-3),
                                note="algorithmic bytes 8*T + 4*K per signature (uint32 out); SURVEY 8d's 4096 B/sig assumes uint64 out"),
             "band_digests": _roof(n3 * (4 * k3 + 8 * bands), ms_dig),
             "lsh_sort_bands": dict(_roof(n3 * (4 * k3 + 12 * bands), ms_sort), keys_per_s=n3 * bands / (ms_sort * 1e-3),
-                                   note="digests + one radix sort of (band, digest prefix, row) + exact clean-up; bytes = signatures in, (digest, row) out"),
+                                   kernels="lsh_bin_scatter_kernel + lsh_bin_sort_kernel",
+                                   note="digests computed and scattered to bins by their top bits, every bin ordered in LDS: exact (band, digest, row) "
+                                        "order; bytes = signatures in, (digest, row) out"),
+            "lsh_sort_bands_radix": dict(_roof(n3 * (4 * k3 + 12 * bands), ms_sort_radix), keys_per_s=n3 * bands / (ms_sort_radix * 1e-3),
+                                         note="lsh.sort=1: digests + the library radix sort of (band, digest prefix, row) + exact clean-up (round 2's path, "
+                                              "now the fallback), same call, same box"),
             "pipeline_ms": ms_sig + ms_sort,
-            "parity": f"{len(rows)} signature rows vs the C oracle, 64 x {bands} digests vs FNV-1a-64 of the reference's key bytes, 2 bands' order",
+            "parity": f"{len(rows)} signature rows vs the C oracle, 64 x {bands} digests vs FNV-1a-64 of the reference's key bytes, 2 bands' order, all {bands} sorted bands equal to the stable radix sort's",
         }
         for d in (d_dig, d_sd, d_sr):
             d.free()

@@ -74,10 +74,15 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * ("minhash.alias", profiling only: >= 0 makes set i read the tokens of set i & mask),
  * ("weighted.path", 0 auto: dense rows through the bound-ordered walk, CSR rows through the row-block kernels,
  * 1 IEEE division for every element, 2 = every element evaluated: dense rows compacted to CSR first),
+ * ("weighted.direct", n: a dense row with at most n stored elements per 1000 columns is evaluated element by element
+ * instead of walked, default 60), ("weighted.debug", profiling only: 1 = stage and scan the rows without walking them,
+ * 2 = skip the scan; results are meaningless),
  * ("host.chunk_bytes", see
  * mhx_minhash_bulk), ("lsh.sort_bits", bits of (band, digest) mhx_lsh_sort_bands hands to the radix sort,
  * 0 = chosen from n; the order is exact for any value, fewer bits leave more to the clean-up pass),
- * ("lsh.gather", 1 = gather the full digests after the sort instead of letting them ride through it). */
+ * ("lsh.gather", 1 = gather the full digests after the sort instead of letting them ride through it),
+ * ("lsh.sort", 0 auto: mhx_lsh_sort_bands buckets the bands in two passes and falls back to the radix sort when a bin
+ * overflows or n > 12M, 1 = radix sort always). */
 MHX_API int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value);
 /* Kernel event counters since the last call (synchronises the stream, then resets them):
  *   out[0] sets the sieve launch left to the full launch (failed proof, or skipped by the back-off),

@@ -1,17 +1,28 @@
 #!/usr/bin/env bash
 # tools/round_refresh.sh <tag> -- everything the round's evidence is rebuilt from, in one gpurun call:
-# GPU parity suite, smoke, the headline bench line, rocprofv3 trace + counter passes of the same command,
+# GPU parity suite, smoke, the headline bench line, a rocprofv3 kernel trace of the same command, counter passes
+# (own runs, no tracing) over bench.py with its extra configs and over the weighted walk, the HBM traffic passes,
 # the secondary benches and the host path.  Outputs under gpurun_out/refresh_<tag>/.
 set -uo pipefail
 TAG="${1:-run}"
 OUT="gpurun_out/refresh_${TAG}"
 mkdir -p "${OUT}"
-timeout 900 python -m pytest tests -q -m gpu > "${OUT}/pytest_gpu.log" 2>&1; echo "pytest rc=$?"; grep -E "passed|failed" "${OUT}/pytest_gpu.log" | tail -1
+timeout 1200 python -m pytest tests -q -m gpu -p no:cacheprovider > "${OUT}/pytest_gpu.log" 2>&1; echo "pytest rc=$?"; grep -aE "passed|failed" "${OUT}/pytest_gpu.log" | tail -1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "${OUT}/smoke.log" 2>&1; echo "smoke rc=$?"
 timeout 600 python bench.py > "${OUT}/bench.log" 2>&1; echo "bench rc=$?"; tail -1 "${OUT}/bench.log" > "${OUT}/bench.json"; cut -c1-260 "${OUT}/bench.json"
-timeout 900 bash tools/profile.sh "${TAG}" > "${OUT}/profile.log" 2>&1; echo "profile rc=$?"
-timeout 600 bash tools/traffic.sh "${TAG}" > "${OUT}/traffic.log" 2>&1; echo "traffic rc=$?"
-python tools/traffic_summary.py "gpurun_out/traffic_${TAG}" > "${OUT}/traffic.json" 2>&1 || true
+PROFILE_ONLY=trace timeout 600 bash tools/profile.sh "${TAG}" > "${OUT}/profile.log" 2>&1; echo "profile rc=$?"
+python tools/rocpd_summary.py "gpurun_out/prof_${TAG}" > "${OUT}/rocprof_summary.txt" 2>&1 || true
+timeout 900 bash tools/traffic.sh "${TAG}" > "${OUT}/traffic.log" 2>&1; echo "traffic rc=$?"
+python tools/traffic_summary.py "gpurun_out/traffic_${TAG}" > "${OUT}/traffic.json" 2> "${OUT}/traffic.err" || true
+timeout 1500 bash tools/pmc_extra.sh "${TAG}" > "${OUT}/pmc_extra.log" 2>&1; echo "pmc_extra rc=$?"
+timeout 900 bash tools/pmc_weighted.sh "${TAG}" --variants "path=0" > "${OUT}/pmc_weighted.log" 2>&1; echo "pmc_weighted rc=$?"
 timeout 1200 python tools/bench_extra.py > "${OUT}/bench_extra.jsonl" 2> "${OUT}/bench_extra.err"; echo "bench_extra rc=$?"
 timeout 300 python tools/host_path.py > "${OUT}/host_path.txt" 2>&1; echo "host_path rc=$?"
-python tools/rocpd_summary.py "gpurun_out/prof_${TAG}" > "${OUT}/rocprof_summary.txt" 2>&1 || true
+timeout 300 python tools/bench_shapes.py > "${OUT}/bench_shapes.jsonl" 2> "${OUT}/bench_shapes.err"; echo "shapes rc=$?"
+timeout 200 python tools/bench_sort.py > "${OUT}/bench_sort.txt" 2>&1; echo "sort rc=$?"
+{ for d in 1.0 0.3 0.05 0.01; do timeout 200 python tools/bench_weighted.py --rows 20000 --density $d --variants "path=0;path=2" --reps 3;
+    timeout 200 python tools/bench_weighted.py --csr --density $d --rows 20000 --variants "path=0;path=2" --reps 3; done;
+  timeout 200 python tools/bench_weighted.py --rows 20000 --dist lognormal --variants "path=0;path=2";
+  timeout 200 python tools/bench_weighted.py --rows 20000 --dist sorted --variants "path=0;path=2"; } > "${OUT}/bench_weighted.txt" 2>&1; echo "weighted rc=$?"
+: > "${OUT}/ubench_filter.txt"
+for seq in 0 8 9 10 1 2 3 11 4 5 12 13 6 7; do timeout 40 tools/ubench_filter ${seq} >> "${OUT}/ubench_filter.txt" 2>&1 || echo "sequence ${seq}: stopped (rc=$?)" >> "${OUT}/ubench_filter.txt"; done; echo "ubench done"

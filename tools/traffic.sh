@@ -14,5 +14,6 @@ pass wr  TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_DRAM_sum
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass hit TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+pass sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES
 python tools/rocpd_summary.py "${OUT}" > "${OUT}/summary.txt" 2>&1
 grep -v rocclr "${OUT}/summary.txt" | cut -c1-150

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/traffic_summary.py <gpurun_out/traffic_<tag>> -> JSON on stdout (profiles/r02_traffic_minhash_bulk.json).
+"""tools/traffic_summary.py <gpurun_out/traffic_<tag>> -> JSON on stdout (profiles/r0N_traffic_minhash_bulk.json).
 
 Bytes that crossed the L2 <-> fabric interface per launch, from TCC_EA0 request counters taken in their own
 rocprofv3 --pmc passes (tools/traffic.sh): a read request is 32, 64 or 128 bytes -- RDREQ_32B and RDREQ_64B count the
@@ -52,6 +52,18 @@ def main():
     r, w = read_bytes(pick(rd, is_sieve, 4)), write_bytes(pick(wr, is_sieve, 4))
     ra = read_bytes(pick(rd, is_alias, 3))
     alg_r, alg_w = 1_000_000 * 256 * 8, 1_000_000 * 128 * 8
+    issue = {}
+    sq_db = glob.glob(os.path.join(root, "sq", "*.db"))
+    if sq_db:
+        # VALU issue: a wave64 instruction holds its SIMD16 for at least 4 cycles; 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is
+        # summed over the 8 XCDs' instances
+        c = pick(counters(sq_db[0]), is_sieve, 4)
+        cycles = c["GRBM_GUI_ACTIVE"] / 8
+        issue = {"valu_wave_instructions_per_launch": c["SQ_INSTS_VALU"], "salu_wave_instructions_per_launch": c["SQ_INSTS_SALU"],
+                 "active_cycles_per_launch": cycles,
+                 "valu_issue_frac": 4 * c["SQ_INSTS_VALU"] / (1024 * cycles),
+                 "valu_issue_frac_formula": "4 cycles x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCD instances): the share of "
+                                            "SIMD issue cycles the launch's VALU instructions need at their minimum of 4 cycles each"}
     print(json.dumps({
         "kernel": "minhash_bulk_kernel<2, uint64, uint64, MODE_SIEVE, SHAPE_PLAIN_FIXED_ROWS> (1M sets x 256 tokens, K=128)",
         "source": "rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum / TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum, own passes (tools/traffic.sh), mean of 4 dispatches",
@@ -63,6 +75,7 @@ def main():
         "traffic_bytes_per_launch": r + w,
         "algorithmic_bytes_per_launch": alg_r + alg_w,
         "ratio_to_algorithmic": (r + w) / (alg_r + alg_w),
+        **issue,
         "reads_with_token_working_set_of_8MB": ra,
         "note": "reads exceed the 2.048 GB of tokens by the lines that the one-set-ahead warm-up load brought into the XCD's 4 MB L2 "
                 "and that were evicted again before the scalar / tile loads used them; the second fetch is served over the fabric "
