@@ -41,7 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic_minhash_bulk.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic_minhash_bulk.json")
 
 
 def parse_args(argv=None):
