@@ -225,6 +225,7 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "weighted.path")) ctx->opt_weighted_path = value;
     else if (!strcmp(key, "weighted.direct")) ctx->opt_weighted_direct = value;
     else if (!strcmp(key, "weighted.split")) ctx->opt_weighted_split = value;
+    else if (!strcmp(key, "weighted.tail")) ctx->opt_weighted_tail = value;
     else if (!strcmp(key, "weighted.debug")) ctx->opt_weighted_debug = value;
     else if (!strcmp(key, "host.chunk_bytes")) ctx->opt_host_chunk_bytes = value;
     else if (!strcmp(key, "lsh.sort_bits")) ctx->opt_lsh_sort_bits = value;

@@ -67,6 +67,7 @@ struct mhx_ctx {
     int64_t opt_weighted_path = 0;  // 0 auto (dense rows: bound-ordered walk; CSR: reciprocal-multiply quotient + row blocks), 1 IEEE division for every element, 2 every element evaluated (dense rows compacted to CSR: the round-2 path)
     int64_t opt_weighted_debug = 0;  // profiling only (results are wrong): 1 = rows staged and scanned, not walked; 2 = staged without the scan
     int64_t opt_weighted_split = 0;  // dense walk kernel, rows evaluated entry by entry: 0 = the waves of a workgroup that share a chunk of samples split the list, 1 = one wave per chunk
+    int64_t opt_weighted_tail = 0;   // walk plan: 0 = the cut with the smallest estimated cost, 1 .. 5 = that entry of kCutTail (profiling)
     int64_t opt_weighted_direct = 0; // walk kernel: rows storing at most this many per mille of the columns are evaluated entry by entry; 0 auto
     int64_t opt_lsh_sort = 0;       // mhx_lsh_sort_bands: 0 auto (two-pass bucketing, radix sort when a bin would overflow), 1 radix sort
     int64_t opt_lsh_gather = 0;     // mhx_lsh_sort_bands: 1 = gather the full digests after the sort (the fallback path) even when they could ride along

@@ -397,9 +397,21 @@ struct WalkPlan {  // device-resident, owned by the generator
 };
 
 constexpr int kHistBits = 14;  // sign, exponent and 5 mantissa bits of the order-preserving integer image of a float
-constexpr float kCutTail = 0.005f;   // Lcut = the (1 - kCutTail) quantile of the sampled logs ...
-constexpr float kCutSlack = 0.7f;    // ... or their maximum when that is less than this above the quantile
+constexpr int kWalkCached = 8;  // list positions per 64-sample chunk a workgroup keeps in LDS (1.25 KB each)
+constexpr int kCuts = 5;
+constexpr float kCutTail[kCuts] = {0.005f, 0.01f, 0.02f, 0.04f, 0.08f};  // Lcut = a (1 - tail) quantile of the sampled logs ...
+constexpr float kCutSlack = 0.7f;    // ... or their maximum when that is less than this above the first quantile
 constexpr float kCutKeep = 0.35f;    // tables built for a cut in [wanted, wanted + kCutKeep] are kept
+// Which tail: the one with the smallest estimated cost per row and wave.  An entry above the cut costs one evaluation
+// from the list (kCostListed cycles); the walk visits positions until one of them holds a log close under the cut, about
+// kWalkPerNear / (entries of a row within kNearCut under the cut) of them (measured on uniform, lognormal and sorted
+// inputs: 900 .. 1300), the first kWalkCached from LDS for next to nothing, the others at kCostPosition cycles.  Both
+// costs are latencies of this kernel at its occupancy, fitted to config 4's shape with lognormal (sigma = 2) weights and
+// the tail forced (option weighted.tail; 20k rows, ms): 0.5 % 0.78, 1 % 0.65, 2 % 0.63, 4 % 0.81, 8 % 1.30.
+// Uniform weights have a quarter of their logs that close under any high quantile: the walk is short whatever the cut
+// and the smallest tail wins; the lognormal weights have 10 entries of 4096 within 0.3 under the 99.5 % quantile (the
+// slowest lane of a wave walks ~90 positions) and 35 under the 98 % one (~30 positions, 80 listed entries).
+constexpr float kNearCut = 0.3f, kWalkPerNear = 1000.0f, kCostListed = 345.0f, kCostPosition = 435.0f;
 
 __device__ __forceinline__ uint32_t ordered_bits(float f) {  // unsigned order == float order (no NaN here)
     const uint32_t b = __float_as_uint(f);
@@ -421,13 +433,14 @@ __device__ __forceinline__ Entry entry_of(const float4 e) {
 // One workgroup: histogram of n_seg runs of seg_len values spread over v[0 .. total), then the cut.
 template <bool LOGS>
 __global__ __launch_bounds__(1024) void walk_plan_kernel(const float *__restrict__ v, int64_t total, int32_t seg_len, int32_t n_seg,
-                                                         WalkPlan *__restrict__ plan) {
+                                                         float per_row, int32_t forced, WalkPlan *__restrict__ plan) {
     __shared__ uint32_t hist[1 << kHistBits];
     __shared__ uint32_t part[1024];
-    __shared__ uint32_t s_top, s_cut, s_total;
+    __shared__ uint32_t s_top, s_cut[kCuts], s_above[kCuts];
     const int tid = threadIdx.x;
     for (int b = tid; b < (1 << kHistBits); b += 1024) hist[b] = 0;
-    if (tid == 0) s_top = 0, s_cut = 0, s_total = 0;
+    if (tid == 0) s_top = 0;
+    if (tid < kCuts) s_cut[tid] = 0, s_above[tid] = 0;
     __syncthreads();
     const int64_t span = total - seg_len;
     for (int sgm = 0; sgm < n_seg; ++sgm) {
@@ -453,21 +466,45 @@ __global__ __launch_bounds__(1024) void walk_plan_kernel(const float *__restrict
     }
     const uint32_t all = part[0];
     uint32_t above = tid + 1 < 1024 ? part[tid + 1] : 0;  // values in bins above this thread's
-    const uint32_t tail = (uint32_t)((float)all * kCutTail);
     for (int b = kPer - 1; b >= 0; --b) {
         const uint32_t h = hist[tid * kPer + b];
         if (h) atomicMax(&s_top, (uint32_t)(tid * kPer + b));
-        if (above <= tail && above + h > tail) s_cut = (uint32_t)(tid * kPer + b);  // the bin holding the quantile: one thread
+#pragma unroll
+        for (int i = 0; i < kCuts; ++i) {
+            const uint32_t tail = (uint32_t)((float)all * kCutTail[i]);
+            if (above <= tail && above + h > tail) s_cut[i] = (uint32_t)(tid * kPer + b), s_above[i] = above;  // the bin holding the quantile: one thread
+        }
         above += h;
     }
     __syncthreads();
     if (tid == 0) {
         // the largest float of a bin: every sampled value of the bin is <= it
         const auto upper = [](uint32_t bin) { return from_ordered_bits(((bin + 1u) << (32 - kHistBits)) - 1u); };
-        float top = all ? upper(s_top) : 0.0f, q = all ? upper(s_cut) : 0.0f;
+        const auto above_bin = [&](uint32_t bin) {  // sampled values in bins above `bin`
+            const uint32_t t = bin / kPer;
+            uint32_t n = t + 1 < 1024 ? part[t + 1] : 0;
+            for (uint32_t b = bin + 1; b < (t + 1) * kPer; ++b) n += hist[b];
+            return n;
+        };
+        float top = all ? upper(s_top) : 0.0f;
         if (!(top < __builtin_inff())) top = __FLT_MAX__;
-        if (!(q < __builtin_inff())) q = __FLT_MAX__;
-        const float want = top - q < kCutSlack ? top : q;
+        float want = top, q = top, best_cost = __builtin_inff();
+        for (int i = 0; i < kCuts && all; ++i) {
+            float cut = upper(s_cut[i]);
+            if (!(cut < __builtin_inff())) cut = __FLT_MAX__;
+            uint32_t listed = s_above[i];
+            if (i == 0) {
+                q = cut;
+                if (top - cut < kCutSlack) cut = top, listed = 0;
+            }
+            const float near_lo = cut - kNearCut;
+            const uint32_t lo_bin = near_lo > -__FLT_MAX__ ? ordered_bits(near_lo) >> (32 - kHistBits) : 0u;
+            const uint32_t near = above_bin(lo_bin) - listed;  // sampled logs in (cut - kNearCut, cut], by whole bins
+            const float scale = per_row / (float)all;
+            const float positions = kWalkPerNear / fmaxf((float)near * scale, 1e-3f);
+            const float cost = (float)listed * scale * kCostListed + fmaxf(positions - (float)kWalkCached, 0.0f) * kCostPosition;
+            if (forced > 0 ? i == forced - 1 : cost < best_cost) best_cost = cost, want = cut;  // forced: option weighted.tail (profiling)
+        }
         const float have = plan->lcut;
         const bool keep = have >= want && have - want <= kCutKeep;  // false for the initial NaN
         plan->rebuild = keep ? 0 : 1;
@@ -534,14 +571,15 @@ struct Held {
     }
 };
 
-constexpr int kWalkCached = 8;  // list positions per 64-sample chunk a workgroup keeps in LDS (1.25 KB each)
 constexpr int kCachedChunks = 4;
 
 // The second half of a row, one wave per 64 samples: the row's logs are in LDS (row[c]; -inf: not stored), `list` holds
 // n_list columns -- every stored one (all_listed: the row is evaluated entry by entry) or the ones above the cut, which
 // are evaluated before the walk.
 // `part` of `parts` (all_listed only): the waves of a workgroup that share a chunk of samples take a run of the list each;
-// the smallest of their results, taken by Held's own rule, is the row's.
+// the smallest of their results, taken by Held's own rule, is the row's.  (Sharing out the list of a WALKED row with
+// many entries above the cut the same way, the walk starting from what the waves found, was measured: lognormal weights
+// 0.675 -> 0.652 ms per 20k rows, config 4 0.50 -> 0.535 ms -- the extra code costs the common case registers.  Not kept.)
 __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list, int n_list, bool all_listed, int32_t dim, int32_t ch,
                                          int32_t my, int32_t sample_size, const float4 *__restrict__ walk_a,
                                          const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos, int32_t s_pad,
@@ -601,19 +639,42 @@ __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list,
             }
         }
         if (k == n_cached && k < dim && __any(!done)) {
-            float4 e = wa[(int64_t)k * kWave];
-            uint32_t c = wc[(int64_t)k * kWave];
-            for (; k < dim; ++k) {
-                const int32_t kn = k + 1 < dim ? k + 1 : k;  // the next position's entry is on its way
-                const float4 e_next = wa[(int64_t)kn * kWave];
-                const uint32_t c_next = wc[(int64_t)kn * kWave];
-                done = done || e.x > held.ln_a;
+            // beyond the cached positions (heavy-tailed rows: dozens of them for the slowest lane of a wave): rounds of kG
+            // positions (two: the registers that hold the rows fetched ahead leave no room for four) from registers, the next round's entries on their way from the L2 meanwhile (one position per
+            // round with one in flight cost an L2 round trip per position)
+            constexpr int kG = 2;
+            float4 e[kG];
+            uint32_t c[kG];
+#pragma unroll
+            for (int u = 0; u < kG; ++u) {
+                const int32_t at = k + u < dim ? k + u : dim - 1;
+                e[u] = wa[(int64_t)at * kWave], c[u] = wc[(int64_t)at * kWave];
+            }
+            for (; k < dim; k += kG) {
+                float4 e_next[kG];
+                uint32_t c_next[kG];
+#pragma unroll
+                for (int u = 0; u < kG; ++u) {
+                    const int32_t at = k + kG + u < dim ? k + kG + u : dim - 1;
+                    e_next[u] = wa[(int64_t)at * kWave], c_next[u] = wc[(int64_t)at * kWave];
+                }
+                done = done || e[0].x > held.ln_a;
                 if (!__any(!done)) break;
                 if (!done) {
-                    const float l = row[c];
-                    if (!(l == -__builtin_inff())) held.offer(l, make_float4(e.y, e.z, e.w, 0.0f), c);
+                    float l[kG], t[kG], a[kG];
+#pragma unroll
+                    for (int u = 0; u < kG; ++u) {
+                        l[u] = row[c[u]];
+                        evaluate<false>(l[u], entry_of(make_float4(e[u].y, e[u].z, e[u].w, 0.0f)), t[u], a[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < kG; ++u) {
+                        done = done || e[u].x > held.ln_a;  // (a position past the end repeats the last one: taken twice, the same)
+                        if (!done && !(l[u] == -__builtin_inff())) held.take(a[u], t[u], c[u]);
+                    }
                 }
-                e = e_next, c = c_next;
+#pragma unroll
+                for (int u = 0; u < kG; ++u) e[u] = e_next[u], c[u] = c_next[u];
             }
         }
     }
@@ -1064,9 +1125,9 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
     const int64_t total = n_rows * (int64_t)dim;
     const int32_t n_seg = (int32_t)std::min<int64_t>(n_rows, std::max<int64_t>(1, (16 << 10) / dim));  // about 16k sampled logs
     if (values_are_logs)
-        hipLaunchKernelGGL(walk_plan_kernel<true>, dim3(1), dim3(1024), 0, ctx->stream, d_x, total, dim, n_seg, plan);
+        hipLaunchKernelGGL(walk_plan_kernel<true>, dim3(1), dim3(1024), 0, ctx->stream, d_x, total, dim, n_seg, (float)dim, (int32_t)ctx->opt_weighted_tail, plan);
     else
-        hipLaunchKernelGGL(walk_plan_kernel<false>, dim3(1), dim3(1024), 0, ctx->stream, d_x, total, dim, n_seg, plan);
+        hipLaunchKernelGGL(walk_plan_kernel<false>, dim3(1), dim3(1024), 0, ctx->stream, d_x, total, dim, n_seg, (float)dim, (int32_t)ctx->opt_weighted_tail, plan);
     MHX_HIP_CHECK(hipGetLastError());
     int32_t p2 = 1;
     while (p2 < dim) p2 <<= 1;
@@ -1165,7 +1226,8 @@ static int launch_weighted_csr_walk(mhx_wgen *gen, const int64_t *d_indptr, cons
     const bool any_walk = nnz * 1000 > (int64_t)direct_permille * dim;  // some row may be long enough
     if (any_walk) {
         const int32_t seg = (int32_t)std::min<int64_t>(nnz, 1024);
-        hipLaunchKernelGGL(walk_plan_kernel<true>, dim3(1), dim3(1024), 0, ctx->stream, d_logs, nnz, seg, (int32_t)std::min<int64_t>(16, nnz / seg), plan);
+        hipLaunchKernelGGL(walk_plan_kernel<true>, dim3(1), dim3(1024), 0, ctx->stream, d_logs, nnz, seg, (int32_t)std::min<int64_t>(16, nnz / seg),
+                           (float)std::min<double>((double)dim, (double)nnz / (double)std::max<int64_t>(n_rows, 1)), (int32_t)ctx->opt_weighted_tail, plan);
         MHX_HIP_CHECK(hipGetLastError());
         int32_t p2 = 1;
         while (p2 < dim) p2 <<= 1;

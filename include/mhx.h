@@ -76,7 +76,8 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * 1 IEEE division for every element, 2 = every element evaluated: dense rows compacted to CSR first),
  * ("weighted.direct", n: a dense row with at most n stored elements per 1000 columns is evaluated element by element
  * instead of walked, default 100), ("weighted.split", 0 auto: the waves of a workgroup that share 64 samples split the list of a
- * dense row that is evaluated entry by entry, 1 = one wave per 64 samples), ("weighted.debug", profiling only: 1 = stage and scan the rows without walking them,
+ * dense row that is evaluated entry by entry, 1 = one wave per 64 samples), ("weighted.tail", profiling: 1 .. 5 force the share of a call's logs that
+ * counts as "above the cut" to 0.5, 1, 2, 4, 8 %; 0 = the cheapest by the plan's estimate), ("weighted.debug", profiling only: 1 = stage and scan the rows without walking them,
  * 2 = skip the scan; results are meaningless),
  * ("host.chunk_bytes", see
  * mhx_minhash_bulk), ("lsh.sort_bits", bits of (band, digest) mhx_lsh_sort_bands hands to the radix sort,

@@ -279,6 +279,34 @@ def test_entry_by_entry_rows_without_the_division_at_floor_boundaries(ctx, dim, 
     assert np.array_equal(got_d[rows][:, :, 1][finite[rows]], want[rows][:, :, 1][finite[rows]])
 
 
+@pytest.mark.parametrize("dist", ["lognormal", "uniform", "pareto"])
+def test_every_cut_the_plan_can_choose_gives_the_same_sketch(ctx, dist):
+    """The walk's cut is chosen per call from an estimate of the cost (the share of the logs above it: 0.5 .. 8 %);
+    heavy-tailed weights move it.  Whatever the cut -- each one forced in turn (option weighted.tail), tables rebuilt --
+    the (k, t) pairs are the oracle's; walks that run past the positions cached in LDS (lognormal, pareto) included."""
+    n, dim, s = 1500, 4096, 128
+    rng = np.random.RandomState(31)
+    if dist == "lognormal":
+        x = rng.lognormal(0.0, 2.0, (n, dim)).astype(np.float32)
+    elif dist == "pareto":
+        x = (rng.pareto(1.1, (n, dim)) + 1e-3).astype(np.float32)
+    else:
+        x = rng.uniform(0, 100, (n, dim)).astype(np.float32)
+    g = WeightedMinHashGenerator(dim, s, seed=3, gpu_mode="always")
+    wctx, _ = g._device_handle()
+    want, wn = _oracle(g, x, np.arange(0, n, 5))
+    try:
+        for tail in (0, 1, 2, 3, 4, 5, 0):
+            wctx.set_option("weighted.tail", tail)
+            out, ne = g.minhash_many_arrays(x)
+            assert ne.all() and np.array_equal(out[::5], want), (dist, tail)
+            if tail == 0:
+                first = out
+            assert np.array_equal(out, first), (dist, tail)
+    finally:
+        wctx.set_option("weighted.tail", 0)
+
+
 def test_device_log_mode_through_the_walk(ctx):
     """device_log=True takes logf on the device inside the walk kernel's staging pass: its (k, t) may differ from parity
     mode only under BASELINE.md section 3's rule (bench.weighted_gap_gate)."""

@@ -76,6 +76,7 @@ def main():
         ctx.set_option("weighted.direct", int(opts.get("direct", 0)))
         ctx.set_option("weighted.debug", int(opts.get("debug", 0)))
         ctx.set_option("weighted.split", int(opts.get("split", 0)))
+        ctx.set_option("weighted.tail", int(opts.get("tail", 0)))
 
         def call():
             if args.csr:
