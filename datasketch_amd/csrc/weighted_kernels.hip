@@ -159,6 +159,7 @@ __device__ __forceinline__ void evaluate(float logx, const Entry &e, float &t, f
 // way round they are.  x -> floor(RN(x + beta)) is monotone: if it gives the same t at b1 and b2 it gives that t at q,
 // and ln_y, ln_a follow from t exactly as in evaluate().  Otherwise (q + beta within ~2^-20 relative of an integer: a few
 // in 10^6; NaN) the result is "open" and the caller repeats the element with the true division.
+// (With the hardware's reciprocal for y -- 1 ulp instead of half an ulp -- the distance grows to 2^-22: still inside.)
 // Needs: |L| <= 2^80 or infinite (the table has 2^-40 <= r <= 2^40, so q' overflows only where q does); with `any` set
 // the test is written so that infinite b1, b2 (inf - inf: NaN) count as open and L needs no such bound.
 typedef float vec2f __attribute__((ext_vector_type(2)));
@@ -625,11 +626,20 @@ __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list,
             done = done || e[0].x > held.ln_a;  // an equal bound may still hide a tie at a smaller column
             if (!__any(!done)) break;
             if (!done) {
+                // e = {LB, r, ln_c, beta}; t without the division (evaluate_guarded with the hardware's reciprocal, 1 ulp:
+                // still inside the proof's margin), which is the longest dependent chain of a round; a column the row does
+                // not store (-inf: dropped below) is evaluated at 0 so that it does not count as open
                 float l[kU], t[kU], a[kU];
+                bool open = false;
 #pragma unroll
                 for (int u = 0; u < kU; ++u) {
                     l[u] = row[c[u]];
-                    evaluate<false>(l[u], entry_of(make_float4(e[u].y, e[u].z, e[u].w, 0.0f)), t[u], a[u]);  // e = {LB, r, ln_c, beta}
+                    open |= evaluate_guarded<true>(l[u] == -__builtin_inff() ? 0.0f : l[u],
+                                                   make_float4(e[u].y, e[u].z, e[u].w, __builtin_amdgcn_rcpf(e[u].y)), t[u], a[u]);
+                }
+                if (__builtin_expect(__any(open), 0)) {
+#pragma unroll
+                    for (int u = 0; u < kU; ++u) evaluate<false>(l[u], entry_of(make_float4(e[u].y, e[u].z, e[u].w, 0.0f)), t[u], a[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < kU; ++u) {
@@ -662,10 +672,16 @@ __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list,
                 if (!__any(!done)) break;
                 if (!done) {
                     float l[kG], t[kG], a[kG];
+                    bool open = false;
 #pragma unroll
                     for (int u = 0; u < kG; ++u) {
                         l[u] = row[c[u]];
-                        evaluate<false>(l[u], entry_of(make_float4(e[u].y, e[u].z, e[u].w, 0.0f)), t[u], a[u]);
+                        open |= evaluate_guarded<true>(l[u] == -__builtin_inff() ? 0.0f : l[u],
+                                                       make_float4(e[u].y, e[u].z, e[u].w, __builtin_amdgcn_rcpf(e[u].y)), t[u], a[u]);
+                    }
+                    if (__builtin_expect(__any(open), 0)) {
+#pragma unroll
+                        for (int u = 0; u < kG; ++u) evaluate<false>(l[u], entry_of(make_float4(e[u].y, e[u].z, e[u].w, 0.0f)), t[u], a[u]);
                     }
 #pragma unroll
                     for (int u = 0; u < kG; ++u) {
