@@ -9,7 +9,7 @@ mkdir -p "${OUT}"
 export TMPDIR=/tmp
 CMD=(python bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-e2e --check-rows 0)
 pass() { local name="$1"; shift
-  timeout 600 rocprofv3 --pmc "$@" -d "${OUT}/${name}" -o pmc -- "${CMD[@]}" > "${OUT}/${name}.log" 2>&1
+  timeout 120 rocprofv3 --pmc "$@" -d "${OUT}/${name}" -o pmc -- "${CMD[@]}" > "${OUT}/${name}.log" 2>&1
   echo "${name} rc=$?"; }
 pass sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU
 pass sq2 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE SQ_INSTS_BRANCH SQ_ACTIVE_INST_LDS

@@ -7,7 +7,7 @@ OUT="gpurun_out/traffic_${TAG}"
 mkdir -p "${OUT}"
 export TMPDIR=/tmp
 pass() { local name="$1"; shift
-  timeout 300 rocprofv3 --pmc "$@" -d "${OUT}/${name}" -o pmc -- python tools/traffic_probe.py > "${OUT}/${name}.log" 2>&1
+  timeout 90 rocprofv3 --pmc "$@" -d "${OUT}/${name}" -o pmc -- python tools/traffic_probe.py > "${OUT}/${name}.log" 2>&1
   echo "${name} rc=$?"; }
 pass rd  TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_DRAM_sum
 pass wr  TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_DRAM_sum
