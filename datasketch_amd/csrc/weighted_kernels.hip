@@ -827,7 +827,7 @@ __global__ __launch_bounds__(256, 4) void weighted_walk_dense_kernel(const float
             __syncthreads();
             n_list = n_stored;
         }
-        if (parts > 1 && listable && debug != 1) {
+        if (parts > 1 && listable && debug != 1 && dim >= (parts - 1) * chunks * 3 * kWave) {  // (the row's LDS must hold the waves' results)
             // (workgroup-uniform) a row evaluated entry by entry from its list: the waves that share a chunk of samples
             // take a run of the list each (with one wave per chunk half the workgroup would idle at 128 samples); their
             // results meet in the row's own LDS once every wave has finished reading it.  (The walk is not shared out this
