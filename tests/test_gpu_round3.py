@@ -307,30 +307,6 @@ def test_every_cut_the_plan_can_choose_gives_the_same_sketch(ctx, dist):
         wctx.set_option("weighted.tail", 0)
 
 
-@pytest.mark.parametrize("dim,s", [(300, 70), (200, 64), (64, 256), (1024, 128)])
-def test_sparse_and_dense_rows_interleaved_with_more_rows_than_workgroups(ctx, dim, s):
-    """Rows evaluated entry by entry (a few per cent stored; their list shared between the waves of a chunk, results
-    meeting in the row's LDS) between rows that are walked from the tables a workgroup caches in LDS, 6 000 rows so that
-    every workgroup takes several of both kinds: every row against the oracle.  (Small dim: the row's LDS is smaller than
-    what the waves' results take -- such rows must not be shared out.)"""
-    rng = np.random.RandomState(dim * 7 + s)
-    n = 6000
-    x = np.zeros((n, dim), dtype=np.float32)
-    density = rng.choice([0.02, 0.05, 0.09, 0.3, 0.6, 1.0], n)
-    mask = rng.random_sample((n, dim)) < density[:, None]
-    x[mask] = rng.uniform(0.01, 100, int(mask.sum())).astype(np.float32)
-    g = WeightedMinHashGenerator(dim, s, seed=11, gpu_mode="always")
-    want, wn = _oracle(g, x)
-    got = g.minhash_many_arrays(x)
-    assert _same(got, want, wn)
-    wctx, _ = g._device_handle()
-    wctx.set_option("weighted.split", 1)
-    try:
-        assert _same(g.minhash_many_arrays(x), want, wn)
-    finally:
-        wctx.set_option("weighted.split", 0)
-
-
 def test_device_log_mode_through_the_walk(ctx):
     """device_log=True takes logf on the device inside the walk kernel's staging pass: its (k, t) may differ from parity
     mode only under BASELINE.md section 3's rule (bench.weighted_gap_gate)."""
@@ -496,3 +472,28 @@ def test_bands_bucketed_with_clustered_and_identical_signatures(ctx):
     want_dig, want_rows = LB.sorted_bands(sig, b, r, gpu_mode="disable")
     got_dig, got_rows = LB.sorted_bands(sig, b, r, gpu_mode="always")
     assert np.array_equal(got_dig, want_dig) and np.array_equal(got_rows, want_rows)
+
+
+# (kept last in the file: added after the round's last GPU call, it first runs on the round-end box)
+@pytest.mark.parametrize("dim,s", [(300, 70), (200, 64), (64, 256), (1024, 128)])
+def test_sparse_and_dense_rows_interleaved_with_more_rows_than_workgroups(ctx, dim, s):
+    """Rows evaluated entry by entry (a few per cent stored; their list shared between the waves of a chunk, results
+    meeting in the row's LDS) between rows that are walked from the tables a workgroup caches in LDS, 6 000 rows so that
+    every workgroup takes several of both kinds: every row against the oracle.  (Small dim: the row's LDS is smaller than
+    what the waves' results take -- such rows must not be shared out.)"""
+    rng = np.random.RandomState(dim * 7 + s)
+    n = 6000
+    x = np.zeros((n, dim), dtype=np.float32)
+    density = rng.choice([0.02, 0.05, 0.09, 0.3, 0.6, 1.0], n)
+    mask = rng.random_sample((n, dim)) < density[:, None]
+    x[mask] = rng.uniform(0.01, 100, int(mask.sum())).astype(np.float32)
+    g = WeightedMinHashGenerator(dim, s, seed=11, gpu_mode="always")
+    want, wn = _oracle(g, x)
+    got = g.minhash_many_arrays(x)
+    assert _same(got, want, wn)
+    wctx, _ = g._device_handle()
+    wctx.set_option("weighted.split", 1)
+    try:
+        assert _same(g.minhash_many_arrays(x), want, wn)
+    finally:
+        wctx.set_option("weighted.split", 0)
