@@ -153,6 +153,50 @@ def test_group_collectives_in_threads():
         assert ints == [[0, 100], [1, 101], [2, 102]]
 
 
+def test_group_with_eight_ranks_late_joiners_and_large_frames():
+    """The shape of the first 8-GPU run: eight ranks, some arriving seconds after rank 0 listens, a 128-byte id broadcast
+    (the RCCL unique id), per-rank timings reduced with max, and frames of a few MB (host-side gathers of signature
+    shards) repeated over many rounds without the ranks drifting apart."""
+    import threading
+    import time
+
+    from datasketch_amd import rendezvous
+
+    port = _free_port()
+    world, res, errors = 8, {}, []
+
+    def run(rank):
+        try:
+            time.sleep(0.15 * (rank % 4))  # ranks 1..7 trickle in; rank 0 must wait for all of them
+            with rendezvous.Group(rank, world, "127.0.0.1", port, timeout=60) as g:
+                uid = g.broadcast(bytes(range(128)) if rank == 0 else None)
+                shard = bytes([rank]) * (2_000_000 + rank)
+                sizes = []
+                for rnd in range(5):
+                    got = g.allgather(shard if rnd == 0 else bytes([rank, rnd]))
+                    sizes.append([len(b) for b in got])
+                    assert all(b[0] == r for r, b in enumerate(got))
+                    g.barrier()
+                slow = g.allreduce_max(1.0 + rank / 10.0)
+                seen = g.allgather_ints([rank])
+                res[rank] = (uid, sizes, slow, seen)
+        except Exception as e:  # noqa: BLE001 - reported by the main thread
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+    assert not errors, errors
+    assert sorted(res) == list(range(world))
+    for r in range(world):
+        uid, sizes, slow, seen = res[r]
+        assert uid == bytes(range(128))
+        assert sizes[0] == [2_000_000 + q for q in range(world)] and all(sz == [2] * world for sz in sizes[1:])
+        assert slow == 1.7 and seen == [[q] for q in range(world)]
+
+
 def test_bench_self_launch_spawns_ranks_and_propagates_failure_without_a_gpu():
     """`python bench.py --gpus 2` with no launcher environment spawns two ranks itself; on this device-less box
     both meet at the rendezvous, find no HIP device and exit non-zero -- and so does the parent."""
