@@ -224,6 +224,9 @@ MHX_API int mhx_wgen_destroy(mhx_wgen *gen);
  *     no FMA contraction, so (k, t) are bit-exact);  == 0: the device takes logf(x) itself.
  *   out int64[n_rows, sample_size, 2] = (k, t) pairs (ref :233-239); rows without stored values
  *   get nonempty[row] = 0 (the reference returns None for them, ref :242-247) and zeros in out.
+ *   The host entry checks indptr (monotone) and every column index (0 <= index < dim; the reference raises
+ *   IndexError there) before anything is uploaded; the _dev entry takes resident arrays as they are: column
+ *   indices outside [0, dim) are the caller's error and are not looked for on the device.
  */
 MHX_API int mhx_weighted_minhash_many(mhx_wgen *gen, const int64_t *indptr, const int32_t *indices,
                                       const float *values, int values_are_logs, int64_t n_rows,
