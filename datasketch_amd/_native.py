@@ -39,6 +39,7 @@ _PROTOTYPES = {
     "mhx_ctx_counters": [_vp, _int, ctypes.POINTER(ctypes.c_uint64)],
     "mhx_dev_alloc": [_vp, _sz, ctypes.POINTER(_vp)],
     "mhx_dev_free": [_vp, _vp],
+    "mhx_debug_guard_alloc": [_int, ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
     "mhx_host_alloc": [_vp, _sz, ctypes.POINTER(_vp)],
     "mhx_host_free": [_vp, _vp],
     "mhx_memcpy_h2d": [_vp, _vp, _vp, _sz],
@@ -250,6 +251,15 @@ class WeightedFeed:
                 self.ctx.lib.mhx_weighted_dense_end(h)
         except Exception:
             pass
+
+
+def guard_alloc(align: int):
+    """Debugging (mhx_debug_guard_alloc): from now on every device allocation of the library in this process abuts an
+    unmapped page -- behind its last byte for align > 0 (size rounded up to ``align`` bytes), in front of its first for
+    align < 0; 0 switches back to hipMalloc.  Returns (mapping granule in bytes, guarded blocks alive)."""
+    g, live = _i64(0), _i64(0)
+    check(load().mhx_debug_guard_alloc(int(align), ctypes.byref(g), ctypes.byref(live)))
+    return int(g.value), int(live.value)
 
 
 class DeviceBuffer:

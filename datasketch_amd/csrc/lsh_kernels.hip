@@ -555,18 +555,23 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     const size_t cur_bytes = ((sizeof(uint32_t) * (size_t)(bins + 1)) + 255) & ~(size_t)255;
     const size_t dig_bytes = sizeof(uint64_t) * (size_t)bins * kBinCap, row_bytes = sizeof(uint32_t) * (size_t)bins * kBinCap;
     if (cur_bytes + dig_bytes + row_bytes > (size_t)ctx->hbm_bytes / 4) return MHX_OK;
-    if (int rc = ctx->ensure_scratch(3, cur_bytes + dig_bytes + row_bytes + 256)) return rc;
+    // bands whose r values of a row share a 128-byte line go to one workgroup (at most four) -- as far as the teams'
+    // staging areas fit the LDS of a workgroup (4096 bins x 4 teams would be 272 KB: ADVICE r3); not even one team
+    // fitting, a slab that cannot be had, a launch that is refused: the radix sort below handles every size
+    const int piece = r * (sig_dtype == MHX_U32 ? 4 : 8);
+    int band_share = piece < 128 && 128 % piece == 0 ? std::min(4, 128 / piece) : 1;
+    while (bands % band_share) band_share >>= 1;
+    const size_t team_bytes = 8 * (size_t)(256 * kScatterRows) + 8 * ((3 * (size_t)nb * 4 + 256 * kScatterRows * 2 + 16 + 7) / 8);
+    const size_t lds_limit = (size_t)ctx->lds_per_block;
+    while (band_share > 1 && team_bytes * band_share > lds_limit) band_share >>= 1;
+    if (team_bytes * band_share > lds_limit) return MHX_OK;
+    if (ctx->ensure_scratch(3, cur_bytes + dig_bytes + row_bytes + 256) != MHX_OK) return MHX_OK;
     uint32_t *d_cursor = (uint32_t *)ctx->scratch[3];
     uint32_t *d_overflow = d_cursor + bins;
     uint64_t *d_slab_dig = (uint64_t *)((char *)ctx->scratch[3] + cur_bytes);
     uint32_t *d_slab_row = (uint32_t *)((char *)ctx->scratch[3] + cur_bytes + dig_bytes);
     MHX_HIP_CHECK(hipMemsetAsync(d_cursor, 0, sizeof(uint32_t) * (size_t)(bins + 1), ctx->stream));
-    // bands whose r values of a row share a 128-byte line go to one workgroup (at most four)
-    const int piece = r * (sig_dtype == MHX_U32 ? 4 : 8);
-    int band_share = piece < 128 && 128 % piece == 0 ? std::min(4, 128 / piece) : 1;
-    while (bands % band_share) band_share >>= 1;
     const int64_t items = (n + 256 * kScatterRows - 1) / (256 * kScatterRows) * (bands / band_share);
-    const size_t team_bytes = 8 * (size_t)(256 * kScatterRows) + 8 * ((3 * (size_t)nb * 4 + 256 * kScatterRows * 2 + 16 + 7) / 8);
     const size_t lds1 = team_bytes * band_share;
     const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(32 / (4 * band_share), (int64_t)((160 << 10) / (lds1 + 64))));
     const unsigned grid1 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, (int64_t)ctx->num_cus * per_cu * 2));
@@ -576,7 +581,7 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     else
         hipLaunchKernelGGL(lsh_bin_scatter_kernel<uint64_t>, dim3(grid1), dim3(256 * band_share), lds1, ctx->stream, (const uint64_t *)d_sig, k, r, n, bands,
                            bin_bits, band_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
-    MHX_HIP_CHECK(hipGetLastError());
+    if (hipGetLastError() != hipSuccess) return MHX_OK;  // (a launch the device refuses: nothing has run, the radix sort takes over)
     uint32_t overflow = 0;
     MHX_HIP_CHECK(hipMemcpyAsync(&overflow, d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));

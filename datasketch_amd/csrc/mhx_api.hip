@@ -45,6 +45,106 @@ int bbit_slot_size(int b) {  // ref: datasketch/b_bit_minhash.py:147-160
     return 32;
 }
 
+// ---- device allocations of the library, all through here -------------------------------------------------------
+// Normally hipMalloc / hipFree.  In guard mode (environment MHX_GUARD_ALLOC=<align>, or mhx_debug_guard_alloc) every
+// allocation is mapped with the HIP virtual-memory API between two reserved, UNMAPPED granules and placed so that its
+// last byte (align > 0; rounded up to `align` bytes) or its first byte (align < 0) abuts an unmapped page: a kernel that
+// reads or writes past what it was given faults ("Memory access fault by GPU node ...") instead of silently touching a
+// neighbour.  tests/test_guard_pages.py runs the GPU parity suite this way.
+namespace {
+struct GuardRec {
+    void *va = nullptr;      // reserved range: [granule unmapped][mapped][granule unmapped]
+    size_t reserved = 0, mapped = 0, granule = 0;
+    hipMemGenericAllocationHandle_t handle{};
+};
+std::mutex g_guard_mu;
+std::unordered_map<void *, GuardRec> g_guard;
+int g_guard_align = -0x7fffffff;  // not read yet
+unsigned long long g_guard_count = 0;
+
+int guard_align() {
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    if (g_guard_align == -0x7fffffff) {
+        const char *e = getenv("MHX_GUARD_ALLOC");
+        g_guard_align = e ? atoi(e) : 0;
+    }
+    return g_guard_align;
+}
+
+hipError_t guard_malloc(void **p, size_t bytes, int align) {
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    hipMemAllocationProp prop = {};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = device;
+    size_t gran = 0;
+    e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess) return e;
+    if (gran == 0) return hipErrorNotSupported;
+    const size_t a = (size_t)(align < 0 ? -align : align);
+    const size_t want = (std::max<size_t>(bytes, 1) + a - 1) / a * a;
+    GuardRec r;
+    r.granule = gran;
+    r.mapped = (want + gran - 1) / gran * gran;
+    r.reserved = r.mapped + 2 * gran;
+    e = hipMemAddressReserve(&r.va, r.reserved, gran, nullptr, 0);
+    if (e != hipSuccess) return e;
+    e = hipMemCreate(&r.handle, r.mapped, &prop, 0);
+    if (e != hipSuccess) {
+        (void)hipMemAddressFree(r.va, r.reserved);
+        return e;
+    }
+    char *lo = static_cast<char *>(r.va) + gran;
+    e = hipMemMap(lo, r.mapped, 0, r.handle, 0);
+    if (e == hipSuccess) {
+        hipMemAccessDesc acc = {};
+        acc.location = prop.location;
+        acc.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(lo, r.mapped, &acc, 1);
+        if (e != hipSuccess) (void)hipMemUnmap(lo, r.mapped);
+    }
+    if (e != hipSuccess) {
+        (void)hipMemRelease(r.handle);
+        (void)hipMemAddressFree(r.va, r.reserved);
+        return e;
+    }
+    *p = align < 0 ? lo : lo + (r.mapped - want);
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guard[*p] = r;
+    ++g_guard_count;
+    return hipSuccess;
+}
+}  // namespace
+
+hipError_t dev_malloc(void **p, size_t bytes) {
+    const int align = guard_align();
+    if (align == 0) return hipMalloc(p, bytes);
+    return guard_malloc(p, bytes, align);
+}
+
+hipError_t dev_free(void *p) {
+    if (!p) return hipSuccess;
+    GuardRec r;
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        const auto it = g_guard.find(p);
+        if (it == g_guard.end()) return hipFree(p);
+        r = it->second;
+        g_guard.erase(it);
+    }
+    hipError_t e = hipDeviceSynchronize();
+    char *lo = static_cast<char *>(r.va) + r.granule;
+    const hipError_t e1 = hipMemUnmap(lo, r.mapped), e2 = hipMemRelease(r.handle), e3 = hipMemAddressFree(r.va, r.reserved);
+    if (e == hipSuccess) e = e1;
+    if (e == hipSuccess) e = e2;
+    if (e == hipSuccess) e = e3;
+    return e;
+}
+
+bool guard_mode() { return guard_align() != 0; }
+
 }  // namespace mhx
 
 using mhx::fail;
@@ -55,21 +155,23 @@ int mhx_ctx::activate() const {
 }
 
 int mhx_ctx::ensure_scratch(int slot, size_t bytes) {
-    if (bytes <= scratch_bytes[slot]) return MHX_OK;
-    const size_t old = scratch_bytes[slot];
+    // (guard mode: exactly what was asked for, every time, so that the end of the slot is the end of the mapping)
+    const bool guard = mhx::guard_mode();
+    if (guard ? (bytes == scratch_bytes[slot] && scratch[slot]) : bytes <= scratch_bytes[slot]) return MHX_OK;
+    const size_t old = guard ? 0 : scratch_bytes[slot];
     if (scratch[slot]) {
         MHX_HIP_CHECK(hipStreamSynchronize(stream));
-        MHX_HIP_CHECK(hipFree(scratch[slot]));
+        MHX_HIP_CHECK(mhx::dev_free(scratch[slot]));
         scratch[slot] = nullptr;
         scratch_bytes[slot] = 0;
     }
     // grow geometrically so repeated slightly larger calls do not reallocate every time
     size_t want = std::max(bytes, old + old / 2);
-    want = (want + 255) & ~(size_t)255;
-    hipError_t e = hipMalloc(&scratch[slot], want);
+    if (!guard) want = (want + 255) & ~(size_t)255;
+    hipError_t e = mhx::dev_malloc(&scratch[slot], want);
     if (e != hipSuccess && want != bytes) {
         want = (bytes + 255) & ~(size_t)255;
-        e = hipMalloc(&scratch[slot], want);
+        e = mhx::dev_malloc(&scratch[slot], want);
     }
     if (e != hipSuccess) {
         scratch[slot] = nullptr;
@@ -90,12 +192,12 @@ int mhx_ctx::ensure_redo(int64_t n_sets) {
     if (n_sets <= redo_capacity && d_redo) return MHX_OK;
     if (d_redo) {
         (void)hipStreamSynchronize(stream);
-        (void)hipFree(d_redo);
+        (void)mhx::dev_free(d_redo);
         d_redo = nullptr;
         redo_capacity = 0;
     }
     const int64_t cap = std::max<int64_t>(n_sets + n_sets / 4, 1024);
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_redo), (size_t)cap + 64);
+    hipError_t e = mhx::dev_malloc(reinterpret_cast<void **>(&d_redo), (size_t)cap + 64);
     if (e != hipSuccess) {
         d_redo = nullptr;
         return fail(MHX_ERR_OOM, "redo flag allocation of %lld bytes failed: %s", (long long)cap, hipGetErrorString(e));
@@ -106,7 +208,7 @@ int mhx_ctx::ensure_redo(int64_t n_sets) {
 
 int mhx_ctx::ensure_work() {
     if (d_work) return MHX_OK;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_work), mhx::kWorkBytes);
+    hipError_t e = mhx::dev_malloc(reinterpret_cast<void **>(&d_work), mhx::kWorkBytes);
     if (e != hipSuccess) {
         d_work = nullptr;
         return fail(MHX_ERR_OOM, "work counter allocation failed: %s", hipGetErrorString(e));
@@ -148,6 +250,7 @@ int mhx_ctx_create(int device, mhx_ctx **out) {
     mhx_ctx *ctx = new mhx_ctx();
     ctx->device = device;
     ctx->num_cus = prop.multiProcessorCount;
+    ctx->lds_per_block = (int64_t)prop.sharedMemPerBlock;
     ctx->hbm_bytes = (int64_t)prop.totalGlobalMem;
     snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name, prop.gcnArchName);
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
@@ -164,10 +267,10 @@ int mhx_ctx_destroy(mhx_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < 5; ++i)
-        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
-    if (ctx->d_stats) (void)hipFree(ctx->d_stats);
-    if (ctx->d_redo) (void)hipFree(ctx->d_redo);
-    if (ctx->d_work) (void)hipFree(ctx->d_work);
+        if (ctx->scratch[i]) (void)mhx::dev_free(ctx->scratch[i]);
+    if (ctx->d_stats) (void)mhx::dev_free(ctx->d_stats);
+    if (ctx->d_redo) (void)mhx::dev_free(ctx->d_redo);
+    if (ctx->d_work) (void)mhx::dev_free(ctx->d_work);
     if (ctx->copy_in) (void)hipStreamDestroy(ctx->copy_in);
     if (ctx->copy_out) (void)hipStreamDestroy(ctx->copy_out);
     (void)hipStreamDestroy(ctx->stream);
@@ -188,12 +291,12 @@ int mhx_ctx_release_scratch(mhx_ctx *ctx) {
     if (int rc = ctx->activate()) return rc;
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 5; ++i) {
-        if (ctx->scratch[i]) MHX_HIP_CHECK(hipFree(ctx->scratch[i]));
+        if (ctx->scratch[i]) MHX_HIP_CHECK(mhx::dev_free(ctx->scratch[i]));
         ctx->scratch[i] = nullptr;
         ctx->scratch_bytes[i] = 0;
     }
     if (ctx->d_redo) {
-        MHX_HIP_CHECK(hipFree(ctx->d_redo));
+        MHX_HIP_CHECK(mhx::dev_free(ctx->d_redo));
         ctx->d_redo = nullptr;
         ctx->redo_capacity = 0;
     }
@@ -246,14 +349,14 @@ int mhx_ctx_counters(mhx_ctx *ctx, int enable, uint64_t out[MHX_NUM_COUNTERS]) {
             MHX_HIP_CHECK(hipMemcpy(out, ctx->d_stats, sizeof(uint64_t) * MHX_NUM_COUNTERS, hipMemcpyDeviceToHost));
     }
     if (enable && !ctx->d_stats) {
-        hipError_t e = hipMalloc(reinterpret_cast<void **>(&ctx->d_stats), sizeof(uint64_t) * MHX_NUM_COUNTERS);
+        hipError_t e = mhx::dev_malloc(reinterpret_cast<void **>(&ctx->d_stats), sizeof(uint64_t) * MHX_NUM_COUNTERS);
         if (e != hipSuccess) {
             ctx->d_stats = nullptr;
             return fail(MHX_ERR_OOM, "counter allocation failed: %s", hipGetErrorString(e));
         }
     }
     if (!enable && ctx->d_stats) {
-        MHX_HIP_CHECK(hipFree(ctx->d_stats));
+        MHX_HIP_CHECK(mhx::dev_free(ctx->d_stats));
         ctx->d_stats = nullptr;
     }
     if (ctx->d_stats) MHX_HIP_CHECK(hipMemset(ctx->d_stats, 0, sizeof(uint64_t) * MHX_NUM_COUNTERS));
@@ -261,15 +364,48 @@ int mhx_ctx_counters(mhx_ctx *ctx, int enable, uint64_t out[MHX_NUM_COUNTERS]) {
 }
 
 // ---- device memory -------------------------------------------------------------------------
+int mhx_debug_guard_alloc(int align, int64_t *granule, int64_t *live) {
+    if (align != 0 && (align < -4096 || align > 4096 || ((align < 0 ? -align : align) & ((align < 0 ? -align : align) - 1))))
+        return fail(MHX_ERR_INVALID, "guard alignment must be 0 (off) or +-(a power of two <= 4096), got %d", align);
+    (void)mhx::guard_mode();  // read the environment first: this call overrides it
+    {
+        std::lock_guard<std::mutex> lk(mhx::g_guard_mu);
+        mhx::g_guard_align = align;
+        if (live) *live = (int64_t)mhx::g_guard.size();
+    }
+    if (granule) {
+        *granule = 0;
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            return align ? fail(MHX_ERR_NO_DEVICE, "no HIP device is available") : MHX_OK;
+        }
+        int device = 0;
+        MHX_HIP_CHECK(hipGetDevice(&device));
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = device;
+        size_t g = 0;
+        hipError_t e = hipMemGetAllocationGranularity(&g, &prop, hipMemAllocationGranularityMinimum);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(MHX_ERR_UNSUPPORTED, "hipMemGetAllocationGranularity failed: %s", hipGetErrorString(e));
+        }
+        *granule = (int64_t)g;
+    }
+    return MHX_OK;
+}
+
 int mhx_dev_alloc(mhx_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return fail(MHX_ERR_INVALID, "ctx/dptr is NULL");
     MHX_GUARD(ctx);
     *dptr = nullptr;
     if (int rc = ctx->activate()) return rc;
-    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    hipError_t e = mhx::dev_malloc(dptr, bytes ? bytes : 1);
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        return fail(MHX_ERR_OOM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return fail(MHX_ERR_OOM, "device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
     }
     return MHX_OK;
 }
@@ -280,7 +416,7 @@ int mhx_dev_free(mhx_ctx *ctx, void *dptr) {
     if (!dptr) return MHX_OK;
     if (int rc = ctx->activate()) return rc;
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    MHX_HIP_CHECK(hipFree(dptr));
+    MHX_HIP_CHECK(mhx::dev_free(dptr));
     return MHX_OK;
 }
 
@@ -402,7 +538,7 @@ int mhx_perm_create(mhx_ctx *ctx, const uint64_t *a, const uint64_t *b, int32_t 
     p->ctx = ctx;
     p->num_perm = num_perm;
     const size_t bytes = sizeof(uint64_t) * (size_t)num_perm;
-    hipError_t e = hipMalloc((void **)&p->d_a, 2 * bytes);
+    hipError_t e = mhx::dev_malloc((void **)&p->d_a, 2 * bytes);
     if (e != hipSuccess) {
         delete p;
         return fail(MHX_ERR_OOM, "hipMalloc for permutations failed: %s", hipGetErrorString(e));
@@ -412,7 +548,7 @@ int mhx_perm_create(mhx_ctx *ctx, const uint64_t *a, const uint64_t *b, int32_t 
     if (e == hipSuccess) e = hipMemcpyAsync(p->d_b, b, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
-        (void)hipFree(p->d_a);
+        (void)mhx::dev_free(p->d_a);
         delete p;
         return fail(MHX_ERR_HIP, "uploading permutations failed: %s", hipGetErrorString(e));
     }
@@ -425,7 +561,7 @@ int mhx_perm_destroy(mhx_perm *perm) {
     MHX_GUARD(perm->ctx);
     (void)hipSetDevice(perm->ctx->device);
     (void)hipStreamSynchronize(perm->ctx->stream);
-    (void)hipFree(perm->d_a);
+    (void)mhx::dev_free(perm->d_a);
     delete perm;
     return MHX_OK;
 }
@@ -1175,20 +1311,20 @@ int mhx_wgen_create(mhx_ctx *ctx, const float *rs, const float *ln_cs, const flo
         g->walk_ok = rs[j] > 0.0f && fabsf(ln_cs[j]) < __builtin_inff() && fabsf(betas[j]) < __builtin_inff();
     const size_t a_bytes = sizeof(float) * 4 * (size_t)g->s_pad * (size_t)dim;
     const float plan0[4] = {__builtin_nanf(""), 0.0f, 0.0f, 0.0f};  // WalkPlan: no tables yet
-    hipError_t e = hipMalloc((void **)&g->d_params, t_bytes);
-    if (e == hipSuccess) e = hipMalloc((void **)&g->d_aos, a_bytes);
-    if (e == hipSuccess && g->walk_ok) e = hipMalloc((void **)&g->d_walk_a, a_bytes);
-    if (e == hipSuccess && g->walk_ok) e = hipMalloc((void **)&g->d_walk_c, a_bytes / 4);
-    if (e == hipSuccess && g->walk_ok) e = hipMalloc(&g->d_walk_plan, sizeof(plan0));
+    hipError_t e = mhx::dev_malloc((void **)&g->d_params, t_bytes);
+    if (e == hipSuccess) e = mhx::dev_malloc((void **)&g->d_aos, a_bytes);
+    if (e == hipSuccess && g->walk_ok) e = mhx::dev_malloc((void **)&g->d_walk_a, a_bytes);
+    if (e == hipSuccess && g->walk_ok) e = mhx::dev_malloc((void **)&g->d_walk_c, a_bytes / 4);
+    if (e == hipSuccess && g->walk_ok) e = mhx::dev_malloc(&g->d_walk_plan, sizeof(plan0));
     if (e == hipSuccess && g->walk_ok) e = hipMemcpyAsync(g->d_walk_plan, plan0, sizeof(plan0), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && g->walk_ok) e = hipMemsetAsync(g->d_walk_a, 0, a_bytes, ctx->stream);  // lanes behind sample_size load from here too
     if (e == hipSuccess && g->walk_ok) e = hipMemsetAsync(g->d_walk_c, 0, a_bytes / 4, ctx->stream);
     if (e != hipSuccess) {
-        (void)hipFree(g->d_params);
-        (void)hipFree(g->d_aos);
-        (void)hipFree(g->d_walk_a);
-        (void)hipFree(g->d_walk_c);
-        (void)hipFree(g->d_walk_plan);
+        (void)mhx::dev_free(g->d_params);
+        (void)mhx::dev_free(g->d_aos);
+        (void)mhx::dev_free(g->d_walk_a);
+        (void)mhx::dev_free(g->d_walk_c);
+        (void)mhx::dev_free(g->d_walk_plan);
         delete g;
         return fail(MHX_ERR_OOM, "hipMalloc for weighted parameters failed: %s", hipGetErrorString(e));
     }
@@ -1204,11 +1340,11 @@ int mhx_wgen_create(mhx_ctx *ctx, const float *rs, const float *ln_cs, const flo
             rc = fail(MHX_ERR_HIP, "weighted parameter transpose failed");
     }
     if (rc != MHX_OK) {
-        (void)hipFree(g->d_params);
-        (void)hipFree(g->d_aos);
-        (void)hipFree(g->d_walk_a);
-        (void)hipFree(g->d_walk_c);
-        (void)hipFree(g->d_walk_plan);
+        (void)mhx::dev_free(g->d_params);
+        (void)mhx::dev_free(g->d_aos);
+        (void)mhx::dev_free(g->d_walk_a);
+        (void)mhx::dev_free(g->d_walk_c);
+        (void)mhx::dev_free(g->d_walk_plan);
         delete g;
         return rc;
     }
@@ -1221,11 +1357,11 @@ int mhx_wgen_destroy(mhx_wgen *gen) {
     MHX_GUARD(gen->ctx);
     (void)hipSetDevice(gen->ctx->device);
     (void)hipStreamSynchronize(gen->ctx->stream);
-    (void)hipFree(gen->d_params);
-    (void)hipFree(gen->d_aos);
-    (void)hipFree(gen->d_walk_a);
-    (void)hipFree(gen->d_walk_c);
-    (void)hipFree(gen->d_walk_plan);
+    (void)mhx::dev_free(gen->d_params);
+    (void)mhx::dev_free(gen->d_aos);
+    (void)mhx::dev_free(gen->d_walk_a);
+    (void)mhx::dev_free(gen->d_walk_c);
+    (void)mhx::dev_free(gen->d_walk_plan);
     delete gen;
     return MHX_OK;
 }
@@ -1382,8 +1518,8 @@ int mhx_weighted_dense_begin(mhx_wgen *gen, int values_are_logs, int64_t piece_r
     f->ne_off = (out_bytes + 255) & ~(size_t)255;
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-        e = hipMalloc(reinterpret_cast<void **>(&f->d_x[i]), x_bytes);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&f->d_res[i]), f->ne_off + (size_t)piece_rows);
+        e = mhx::dev_malloc(reinterpret_cast<void **>(&f->d_x[i]), x_bytes);
+        if (e == hipSuccess) e = mhx::dev_malloc(reinterpret_cast<void **>(&f->d_res[i]), f->ne_off + (size_t)piece_rows);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&f->uploaded[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&f->computed[i], hipEventDisableTiming);
     }
@@ -1434,8 +1570,8 @@ int mhx_weighted_dense_end(mhx_wfeed *f) {
     if (ctx->copy_in) (void)hipStreamSynchronize(ctx->copy_in);
     (void)hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < 2; ++i) {
-        if (f->d_x[i]) (void)hipFree(f->d_x[i]);
-        if (f->d_res[i]) (void)hipFree(f->d_res[i]);
+        if (f->d_x[i]) (void)mhx::dev_free(f->d_x[i]);
+        if (f->d_res[i]) (void)mhx::dev_free(f->d_res[i]);
         if (f->uploaded[i]) (void)hipEventDestroy(f->uploaded[i]);
         if (f->computed[i]) (void)hipEventDestroy(f->computed[i]);
     }

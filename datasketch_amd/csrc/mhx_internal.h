@@ -41,6 +41,11 @@ constexpr size_t kWorkBytes = 64 + sizeof(unsigned int) * kPairListCap;
         if (!(cond)) return ::mhx::fail(MHX_ERR_INVALID, __VA_ARGS__); \
     } while (0)
 
+// every device allocation of the library (mhx_api.hip): hipMalloc / hipFree, or guard-paged mappings in guard mode
+hipError_t dev_malloc(void **p, size_t bytes);
+hipError_t dev_free(void *p);
+bool guard_mode();
+
 }  // namespace mhx
 
 // Opaque handle layouts (C linkage names are declared in mhx.h).
@@ -51,6 +56,7 @@ struct mhx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     int num_cus = 0;
+    int64_t lds_per_block = 64 << 10;  // what a workgroup may ask for (160 KB on gfx950)
     int64_t hbm_bytes = 0;
     char name[128] = {0};
     // grow-only scratch used by the host entry points (device staging of inputs/outputs)

@@ -318,6 +318,10 @@ class SortedBandsIndex:
     def _as_index_dtype(self, sig: np.ndarray) -> np.ndarray:
         """``sig`` in the index's signature type; a wider matrix must fit (a wrapped value would match band keys the
         reference's byte-keyed dictionaries keep apart)."""
+        if sig.dtype.kind not in "ui":
+            raise ValueError("signatures are unsigned integers (hashvalues), not %s" % sig.dtype)
+        if sig.size and sig.dtype.kind == "i" and int(sig.min()) < 0:
+            raise ValueError("negative signature values")
         if self.dtype == np.uint32 and sig.dtype.itemsize > 4 and sig.size and int(sig.max()) > 0xFFFFFFFF:
             raise ValueError("signature values >= 2**32 do not fit this uint32 index")
         return np.ascontiguousarray(sig, dtype=self.dtype)

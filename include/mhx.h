@@ -17,6 +17,11 @@
  *     comm handles created from it) are serialised by a mutex inside the context, so concurrent
  *     callers are safe but do not overlap; distinct contexts are independent (one context per
  *     GPU / per process is the multi-GPU model).
+ *   - device buffers handed to "_dev" entry points need NO slack: a kernel reads and writes only the bytes
+ *     the argument list describes ([n_sigs, num_perm] elements, offsets[n_sets] tokens ...), and pointers need
+ *     only the natural alignment of their element type (wider loads are used where the pointer allows them).
+ *     tests/test_guard_pages.py holds the kernels to this with mhx_debug_guard_alloc (an unmapped page right
+ *     behind -- or in front of -- every buffer).
  *   - citations "ref:" are paths in the reference repository (ekzhu/datasketch v1.10.0).
  */
 #ifndef MHX_H_
@@ -97,6 +102,14 @@ MHX_API int mhx_ctx_counters(mhx_ctx *ctx, int enable, uint64_t out[MHX_NUM_COUN
 /* ---- device memory + events (so callers can keep corpora resident and time kernels) ------- */
 MHX_API int mhx_dev_alloc(mhx_ctx *ctx, size_t bytes, void **dptr);
 MHX_API int mhx_dev_free(mhx_ctx *ctx, void *dptr);
+/* Debugging: guard pages.  From this call on every device allocation of the library in this process (mhx_dev_alloc, the
+ * contexts' staging buffers, permutations, generator tables) is mapped with the HIP virtual-memory API between two
+ * unmapped granules, its LAST byte (align > 0; the size is rounded up to `align` bytes: 16, 8, 4, 1 ...) or its FIRST
+ * byte (align < 0) abutting the unmapped range, so that an over- or under-read by a kernel raises a GPU memory access
+ * fault instead of touching a neighbour.  align = 0 switches back to hipMalloc (live guarded blocks stay valid).  The
+ * environment variable MHX_GUARD_ALLOC=<align> does the same from the first allocation.  granule (may be NULL)
+ * receives the mapping granularity in bytes, live (may be NULL) the number of guarded blocks currently allocated. */
+MHX_API int mhx_debug_guard_alloc(int align, int64_t *granule, int64_t *live);
 /* page-locked host memory: buffers a caller fills and hands to the host entry points again and again (the pieces of
  * mhx_weighted_dense_feed, staging for mhx_minhash_bulk) go up by DMA straight from it, about 1.3x the rate of pageable memory */
 MHX_API int mhx_host_alloc(mhx_ctx *ctx, size_t bytes, void **ptr);
@@ -290,7 +303,9 @@ MHX_API int mhx_band_digests(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs, 
 /* LSH bucketing by sort (what the per-band dictionaries of ref: datasketch/lsh.py:326-347,370-400 do by
  * hashing): for every band j, sorted_digests[j*n .. (j+1)*n) are the band-j digests of all n signatures in
  * ascending order and sorted_rows[...] the row numbers in the same order -- every LSH bucket of band j is
- * a run of equal digests.  Rows are uint32 (n < 2^32). */
+ * a run of equal digests.  Rows are uint32 (n < 2^32).  The default two-pass bucketing reads one flag back between its
+ * passes (the call synchronises the stream once; with option "lsh.sort" = 1, the radix sort, it only enqueues) and keeps
+ * its bin slabs -- about 30 bytes per (row, band) -- in the context's scratch until mhx_ctx_release_scratch. */
 MHX_API int mhx_lsh_sort_bands_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n_sigs, int32_t num_perm,
                                    int32_t bands, int32_t r, uint64_t *d_sorted_digests,
                                    uint32_t *d_sorted_rows);

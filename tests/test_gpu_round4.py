@@ -1,0 +1,167 @@
+"""GPU parity tests added in round 4 (run on an MI355X: python -m pytest tests -m gpu -x -q).
+
+The weighted kernels with MORE ROWS THAN WORKGROUPS for every instantiation: a workgroup of the dense walk kernel keeps
+its cached walk tables, its prefetched rows and the row's LDS (which doubles as scratch for shared-out lists) across
+rows, so a bug in what survives from one row to the next only shows when a workgroup takes several rows
+(reference: datasketch/weighted_minhash.py:191-247).  Everything goes through the C ABI; the C
+oracle and the evaluate-every-element kernels (weighted.path = 2) are the checkers.
+"""
+import os
+import zlib
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from datasketch_amd import WeightedMinHashGenerator, _native
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    assert _native.gpu_available(), "these tests need an MI355X"
+    return _native.context()
+
+
+_THREADS = max(1, min(16, len(os.sched_getaffinity(0))))
+
+
+def _oracle_rows(g, csr, rows):
+    """The C oracle on the given rows, the rows shared out among host threads (ctypes releases the GIL)."""
+    sub = csr[rows]
+    sub.sort_indices()
+    indptr, indices = sub.indptr.astype(np.int64), sub.indices.astype(np.int32)
+
+    def piece(lo, hi):
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return O.c_weighted_minhash_many(indptr[lo : hi + 1] - indptr[lo], indices[indptr[lo] : indptr[hi]], sub.data[indptr[lo] : indptr[hi]],
+                                             g.rs, g.ln_cs, g.betas)
+
+    n = len(rows)
+    cuts = np.linspace(0, n, min(_THREADS, n) + 1).astype(np.int64)
+    with ThreadPoolExecutor(_THREADS) as pool:
+        parts = list(pool.map(lambda i: piece(cuts[i], cuts[i + 1]), range(len(cuts) - 1)))
+    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+
+
+def _walk_dense_blocks(dim, s, cus=256):
+    """The grid launch_weighted_dense_walk chooses (weighted_kernels.hip): workgroups = min(rows, per_cu * CUs)."""
+    s_pad = (s + 63) // 64 * 64
+    list_cap = max(64, dim // 4)
+    n_cc = min(s_pad // 64, 4)
+    lds = 4 * ((dim + 3) & ~3) + 2 * ((list_cap + 7) & ~7) + 20 * n_cc * 8 * 64
+    return max(1, min(4, (160 << 10) // (lds + 64))) * cus, max(1, min(8, (160 << 10) // (lds + 64))) * cus
+
+
+def _fuzz_matrix(rng, n, dim, heavy):
+    """Rows of mixed density (0.02 .. 1.0 per row: entry-by-entry rows, shared-out lists and walked rows interleaved
+    inside every workgroup), uniform or heavy-tailed values, plus a row that stores nothing and rows with NaN / inf."""
+    x = (rng.lognormal(0, 2.0, (n, dim)) if heavy else rng.uniform(0, 100, (n, dim))).astype(np.float32)
+    dens = rng.choice([0.02, 0.05, 0.09, 0.12, 0.3, 0.6, 1.0], size=(n, 1), p=[0.1, 0.1, 0.1, 0.1, 0.15, 0.15, 0.3])
+    if dim >= 16:
+        x[rng.random_sample(x.shape) >= dens] = 0
+    x[7] = 0
+    if dim >= 8:
+        x[5, rng.randint(0, dim)] = np.nan
+        x[6, rng.randint(0, dim)] = np.inf
+        x[n - 3, rng.randint(0, dim)] = np.nan  # ... and in a workgroup's last round
+    x[n - 2] = 0
+    return x
+
+
+_DIMS = [63, 301, 513, 4095, 4097, 5000, 10000, 16384]   # dim % 4 != 0 or dim > 4096: weighted_walk_dense_kernel<*, AHEAD = false>
+_SAMPLES = [1, 65, 129, 300, 513]
+
+
+def _case_id(dim, s):
+    ahead = dim % 4 == 0 and 4 <= dim <= 4096
+    return f"walk_dense_AHEAD_{str(ahead).lower()}-dim{dim}-S{s}-chunks{(s + 63) // 64}"
+
+
+_CASES = [(d, s) for d in _DIMS for s in _SAMPLES] + [(1024, 300), (1024, 513), (4096, 300), (4096, 513), (4096, 128)]
+
+
+@pytest.mark.parametrize("dim,s", _CASES, ids=[_case_id(d, s) for d, s in _CASES])
+def test_weighted_kernels_with_several_rows_per_workgroup(ctx, dim, s):
+    """Every (dim, sample_size) class with n_rows >= 3 x the number of workgroups, dense and CSR, logs (parity mode) and
+    values (device log), weighted.split 0 / 1: a sample of rows against the C oracle (all rows of small shapes), EVERY
+    row against the evaluate-every-element kernels (weighted.path = 2)."""
+    rng = np.random.RandomState(zlib.crc32(f"{dim}/{s}".encode()))
+    dense_blocks, csr_blocks = _walk_dense_blocks(dim, s)
+    heavy = (dim + s) % 2 == 1
+    g = WeightedMinHashGenerator(dim, s, seed=11, gpu_mode="always")
+    gv = WeightedMinHashGenerator(dim, s, seed=11, gpu_mode="always", device_log=True)
+    wctx, _ = g._device_handle()
+
+    def every_element(gen, x):
+        wctx.set_option("weighted.path", 2)
+        try:
+            return gen.minhash_many_arrays(x)
+        finally:
+            wctx.set_option("weighted.path", 0)
+
+    def check(x, is_csr):
+        n = x.shape[0]
+        csr = sp.csr_matrix(x)
+        arg = csr if is_csr else x
+        out, ne = g.minhash_many_arrays(arg)
+        # the oracle on as many rows as ~0.6 s of the host's threads buy (all of them for small shapes), spread over the matrix so
+        # that first, middle and last rows of the workgroups' strides are among them
+        budget = int(1.5e8 * _THREADS // max(1, dim * s // 2))
+        rows = np.arange(n) if budget >= n else np.unique(np.concatenate([np.arange(min(n, 8)), np.linspace(0, n - 1, max(budget, 64)).astype(np.int64), np.arange(n - 8, n)]))
+        want, wn = _oracle_rows(g, csr, rows)
+        assert np.array_equal(ne[rows].astype(bool), wn)
+        got = out[rows]
+        odd = np.isin(rows, [5, 6, n - 3]) & (dim >= 8)  # the NaN / inf rows: floor(NaN), floor(inf) cast to int64 platform by platform
+        assert np.array_equal(got[wn & ~odd], want[wn & ~odd]) and not got[~wn].any()
+        assert np.array_equal(got[wn & odd][:, :, 0], want[wn & odd][:, :, 0])  # the winning columns
+        every, ne2 = every_element(g, arg)
+        assert np.array_equal(ne2, ne) and np.array_equal(every[ne.astype(bool)], out[ne.astype(bool)])
+        # values in, log on the device: the same logf in both implementations, so the sketches must agree exactly
+        out_v, ne_v = gv.minhash_many_arrays(arg)
+        every_v, ne_v2 = every_element(gv, arg)
+        assert np.array_equal(ne_v, ne_v2) and np.array_equal(out_v[ne_v.astype(bool)], every_v[ne_v.astype(bool)])
+        return out, ne
+
+    n_dense = 3 * dense_blocks + 37
+    x = _fuzz_matrix(rng, n_dense, dim, heavy)
+    out0, ne0 = check(x, False)
+    if (s + 63) // 64 * 2 <= 4:  # the waves of a workgroup can share a chunk's list: both settings of weighted.split
+        wctx.set_option("weighted.split", 1)
+        try:
+            out1, ne1 = g.minhash_many_arrays(x)
+        finally:
+            wctx.set_option("weighted.split", 0)
+        assert np.array_equal(out1, out0) and np.array_equal(ne1, ne0)
+    # CSR: walked rows (more than 10 % stored) and entry-by-entry rows in one call, three rows per workgroup of the walk kernel
+    n_csr = 3 * csr_blocks + 37
+    check(x if n_csr == n_dense else _fuzz_matrix(rng, n_csr, dim, heavy), True)
+
+
+@pytest.mark.parametrize("n", [2_600_000, 5_200_000])
+def test_bands_bucketed_beyond_two_and_a_half_million_rows(ctx, n):
+    """with 2048 / 4096 bins per band four teams per workgroup need 176 / 272 KB of LDS -- more than a
+    workgroup can have -- and the two-pass bucketing used to fail the call instead of sharing fewer bands per workgroup
+    (or leaving it to the radix sort).  uint32 signatures, r = 8 (32-byte band pieces: four bands share a 128-byte line),
+    against the radix path on the device."""
+    rng = np.random.RandomState(n % 1000)
+    bands, r = 4, 8
+    sig = rng.randint(0, 2**32, size=(n, bands * r), dtype=np.uint64).astype(np.uint32)
+    sig[n // 2 : n // 2 + 1000] = sig[:1000]  # some shared buckets
+    d_sig = ctx.to_device(sig)
+    d_dig, d_rows = ctx.alloc(8 * bands * n), ctx.alloc(4 * bands * n)
+    got = {}
+    for opt in (0, 1):
+        ctx.set_option("lsh.sort", opt)
+        try:
+            _native.check(ctx.lib.mhx_lsh_sort_bands_dev_typed(ctx.handle, d_sig.ptr, _native.MHX_U32, n, bands * r, bands, r, d_dig.ptr, d_rows.ptr))
+            got[opt] = (d_dig.download((bands, n), np.uint64), d_rows.download((bands, n), np.uint32))
+        finally:
+            ctx.set_option("lsh.sort", 0)
+    assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1])
+    dig = got[0][0]
+    assert (dig[:, 1:] >= dig[:, :-1]).all()
+    ctx.release_scratch()
