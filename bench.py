@@ -706,8 +706,10 @@ def extra_c4(ctx, n=100_000, dim=4096, s=128):
     x = np.empty((n, dim), dtype=np.float32)
     for i in range(0, n, 10_000):  # the same stream as one call; bounds the float64 temporary
         x[i:i + 10_000] = rs.uniform(0, 100, (min(10_000, n - i), dim))
-    g = WeightedMinHashGenerator(dim, s, seed=1, gpu_mode="always")
+    g = WeightedMinHashGenerator(dim, s, seed=1, gpu_mode="always", device_log=False)  # np.log on the host, whatever the device could do
     gl = WeightedMinHashGenerator(dim, s, seed=1, gpu_mode="always", device_log=True)
+    ga = WeightedMinHashGenerator(dim, s, seed=1, gpu_mode="always")  # the default: the log on the device where it is numpy's bit for bit
+    log_matches = bool(ctx.device_log_matches_numpy()) if hasattr(ctx, "device_log_matches_numpy") else False
     out = {"workload": f"config 4: {n} dense vectors x dim {dim}, sample_size {s}, float32 (the reference's arithmetic type)"}
     # from Python, parity mode and device-log mode
     g.minhash_many_arrays(x[:2048])
@@ -721,6 +723,12 @@ def extra_c4(ctx, n=100_000, dim=4096, s=128):
     t0 = time.perf_counter()
     hv_l, ne_l = gl.minhash_many_arrays(x)
     dt_log = time.perf_counter() - t0
+    ga.minhash_many_arrays(x[:2048])
+    t0 = time.perf_counter()
+    hv_a, ne_a = ga.minhash_many_arrays(x)
+    dt_auto = time.perf_counter() - t0
+    if not (np.array_equal(hv_a, hv) and np.array_equal(ne_a, ne)):
+        raise SystemExit("PARITY FAILURE (extra.c4): the default mode (log on the device after the start-up check) differs from the host-log results")
     # kernel only: logs resident on the device (the generator lives on the process-wide context: its stream is the
     # one the events must be recorded on)
     wctx, handle = g._device_handle()
@@ -771,8 +779,13 @@ def extra_c4(ctx, n=100_000, dim=4096, s=128):
         "kernel_every_element": dict(_roof(alg, ms_every), vectors_per_s=n / (ms_every * 1e-3),
                                      note="weighted.path=2: round 2's kernels (every element evaluated), same call, same box"),
         "kernel_device_log": dict(_roof(alg, ms_log), vectors_per_s=n / (ms_log * 1e-3)),
-        "from_python_parity_mode": {"seconds": dt_par, "vectors_per_s": n / dt_par, "first_call_seconds": dt_par_first,
-                                    "note": "numpy in -> numpy out; np.log on the host; first call = with the one-time allocation of the page-locked log buffers"},
+        "from_python_parity_mode": {"seconds": dt_auto, "vectors_per_s": n / dt_auto, "log_taken_on": "device" if log_matches else "host",
+                                    "note": "numpy in -> numpy out, the default mode: (k, t) bit-identical to the reference; the log is taken on the device when "
+                                            "its float32 log reproduces this host's np.log on the start-up sentinels (device_log_matches_numpy), else on the host; "
+                                            "equal to the host-log results on all rows (checked above)"},
+        "from_python_host_log": {"seconds": dt_par, "vectors_per_s": n / dt_par, "first_call_seconds": dt_par_first,
+                                 "note": "device_log=False: np.log on the host; first call = with the one-time allocation of the page-locked log buffers"},
+        "device_log_matches_numpy": log_matches,
         "from_python_device_log": {"seconds": dt_log, "vectors_per_s": n / dt_log},
         "device_log_mismatch_rate": float(len(mism)) / (n * s),
         "device_log_mismatches": int(len(mism)),

@@ -592,6 +592,31 @@ class Context:
         """Dense rows in pieces (mhx_weighted_dense_begin/feed/end); use as a context manager."""
         return WeightedFeed(self, h, sample_size, dim, values_are_logs, piece_rows)
 
+    def device_log_matches_numpy(self) -> bool:
+        """True when the device's float32 log (np_logf, weighted_kernels.hip: numpy's AVX2 / AVX512F loop restated)
+        reproduces THIS host's ``np.log`` bit for bit on ~14 000 sentinel values -- random patterns over the whole
+        range, denormals, both sides of the 1/sqrt(2) split in every binade, powers of two, zeros, infinities, NaNs,
+        negatives.  numpy's float32 log is not correctly rounded and depends on the CPU dispatch (a host without AVX2
+        runs libm's); the weighted sketch's parity mode takes the log on the device only where this holds
+        (ref: datasketch/weighted_minhash.py:212).  Checked once per context."""
+        ok = getattr(self, "_log_matches", None)
+        if ok is None:
+            rng = np.random.RandomState(20240)
+            near = np.arange(-2, 3, dtype=np.int64)
+            split = int(np.float32(0.70710678).view(np.uint32)) & 0x007FFFFF
+            pats = [rng.randint(1 << 23, 0x7F800000, size=8192), rng.randint(1, 1 << 23, size=1024),
+                    np.array([0, 1, 2, (1 << 23) - 1, 1 << 23, 0x7F7FFFFF, 0x7F800000, 0x7FC00000, 0x7F800001, 0x80000000, 0x80000001,
+                              0xBF800000, 0xFF800000, 0xFFC00000, 0x3F800000, 0x3F800001, 0x3F7FFFFF])]
+            for e in range(1, 255):
+                pats += [(e << 23) + near, (e << 23) + split + near]
+            bits = np.clip(np.concatenate(pats), 0, 0xFFFFFFFF).astype(np.uint32)
+            x = bits.view(np.float32)
+            with np.errstate(all="ignore"):
+                want = np.log(x)
+            ok = bool(np.array_equal(self.weighted_logf(x).view(np.uint32), want.view(np.uint32)))
+            self._log_matches = ok
+        return ok
+
     def weighted_logf(self, x: np.ndarray) -> np.ndarray:
         """The float32 log the device-log mode of the weighted path takes (mhx_weighted_logf)."""
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -42,7 +42,7 @@ constexpr size_t kWorkBytes = 64 + sizeof(unsigned int) * kPairListCap;
     } while (0)
 
 // every device allocation of the library (mhx_api.hip): hipMalloc / hipFree, or guard-paged mappings in guard mode
-hipError_t dev_malloc(void **p, size_t bytes);
+hipError_t dev_malloc(void **p, size_t bytes, bool caller = false);
 hipError_t dev_free(void *p);
 bool guard_mode();
 

@@ -82,6 +82,48 @@ __global__ void wgen_transpose_kernel(const float *__restrict__ rs, const float 
     }
 }
 
+// ---- numpy's float32 logarithm, bit for bit ---------------------------------------------------------------
+// WeightedMinHashGenerator.minhash_many takes np.log of the float32 data (ref: datasketch/weighted_minhash.py:212) and
+// everything after it is a deterministic function of that log: to reproduce the reference WITHOUT a host pass over the
+// matrix the device has to reproduce numpy's log, which is neither correctly rounded (3.83 ulp) nor libm's.  On x86-64
+// hosts with AVX2+FMA3 or AVX512F np.log on float32 runs one SIMD loop (numpy/_core/src/umath/
+// loops_exponent_log.dispatch.c.src, simd_log_FLOAT; unchanged since numpy 1.17), restated here operation by operation:
+//   x = m * 2^e, 0.5 <= m < 1;  m <= 1/sqrt(2): m += m, e -= 1;  m -= 1;  P(m) / Q(m) (degree 5, Horner, FMA; IEEE
+//   division);  fma(e, ln 2, P/Q);  x < 0 -> -NaN, +-0 -> -inf, +inf -> +inf, NaN -> the quiet NaN.
+// Equal to np.log for ALL 2^32 float32 bit patterns (oracle/np_logf.c, the CPU model of the same algorithm, against the
+// installed numpy: tests/test_np_logf_model.py, oracle/check_np_logf.py; this function against numpy on the GPU box's host:
+// test_device_log_equals_numpy_log_for_every_float32).  Whether THIS host's numpy runs that loop is checked once per process
+// on sentinel values before parity mode relies on it (weighted_minhash.py: device_log_matches_numpy).
+__device__ __forceinline__ float np_logf(float x) {
+    const uint32_t b = __float_as_uint(x);
+    const bool denormal = (b >> 23) == 0;                       // (b == 0 as well: overridden below)
+    const int s = denormal ? (int)__clz((int)b) - 8 : 0;        // normalise the mantissa: what getexp / getmant amount to
+    const uint32_t mb = b << (s & 31);
+    const int e = denormal ? -125 - s : (int)(b >> 23) - 126;
+    float m = __uint_as_float((mb & 0x007fffffu) | 0x3f000000u);
+    float ef = (float)e;
+    const bool low = m <= 0.707106781186547524400844362104849039f;
+    m = low ? m + m : m;
+    ef = low ? ef - 1.0f : ef;
+    m = m - 1.0f;
+    float num = __builtin_fmaf(2.589979117907922693523e-02f, m, 3.808837741388407920751e-01f);
+    num = __builtin_fmaf(num, m, 1.480000633576506585156e+00f);
+    num = __builtin_fmaf(num, m, 2.112677543073053063722e+00f);
+    num = __builtin_fmaf(num, m, 9.999999999999998702752e-01f);
+    num = __builtin_fmaf(num, m, 0.0f);
+    float den = __builtin_fmaf(5.875095403124574342950e-03f, m, 1.546476374983906719538e-01f);
+    den = __builtin_fmaf(den, m, 9.864942958519418960339e-01f);
+    den = __builtin_fmaf(den, m, 2.453006071784736363091e+00f);
+    den = __builtin_fmaf(den, m, 2.612677543073109236779e+00f);
+    den = __builtin_fmaf(den, m, 1.0f);
+    float r = __builtin_fmaf(ef, 0.693147180559945309417232121458176568f, num / den);
+    r = (b >> 31) ? __uint_as_float(0xffc00000u) : r;           // x < 0, -inf
+    r = (b << 1) == 0u ? -__builtin_inff() : r;                 // +-0
+    r = b == 0x7f800000u ? __builtin_inff() : r;
+    r = x != x ? __uint_as_float(0x7fc00000u) : r;
+    return r;
+}
+
 // ---- pre-pass: one wave per row -------------------------------------------------------------
 // logs[j] = ln(x) (device-log mode only), flags[row] = kFlagSamePattern (same column list as the
 // first row of its block of 8) | kFlagSane (every log value is 0, +-inf or 2^-40 <= |L| <= 2^40).
@@ -106,7 +148,7 @@ __global__ __launch_bounds__(256) void weighted_prepare_kernel(const int64_t *__
     for (int64_t j = beg + lane; j < end; j += kWave) {
         float l = values[j];
         if (!LOGS) {
-            l = logf(l);
+            l = np_logf(l);
             logs[j] = l;
         }
         sane &= sane_log(l);
@@ -448,7 +490,7 @@ __global__ __launch_bounds__(1024) void walk_plan_kernel(const float *__restrict
         const int64_t start = n_seg > 1 ? span * sgm / (n_seg - 1) : 0;
         for (int j = tid; j < seg_len; j += 1024) {
             float l = v[start + j];
-            if (!LOGS) l = logf(l);
+            if (!LOGS) l = np_logf(l);
             if (fabsf(l) < __builtin_inff()) atomicAdd(&hist[ordered_bits(l) >> (32 - kHistBits)], 1u);  // finite, not NaN
         }
     }
@@ -775,7 +817,7 @@ __global__ __launch_bounds__(256, 4) void weighted_walk_dense_kernel(const float
         int nnz = 0;
         bool nan = false;
         const auto take = [&](int c, float v) -> float {
-            const float l = LOGS ? v : logf(v);
+            const float l = LOGS ? v : np_logf(v);
             const bool stored = LOGS ? !(l == -__builtin_inff()) : (v != 0.0f);  // scipy's nonzero(): NaN stays
             nnz += stored;
             nan |= l != l;
@@ -1213,7 +1255,7 @@ int launch_weighted_dense(mhx_wgen *gen, const float *d_x, int values_are_logs, 
 // the log of the device-log mode on its own (tests and the bench's tolerance gate look at it)
 __global__ __launch_bounds__(256) void weighted_log_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = logf(x[i]);
+        out[i] = np_logf(x[i]);
 }
 
 int launch_weighted_log(mhx_ctx *ctx, const float *d_x, int64_t n, float *d_out) {

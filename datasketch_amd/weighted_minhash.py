@@ -58,11 +58,15 @@ class WeightedMinHashGenerator:
         seed: random seed.
         gpu_mode: 'disable' (numpy, as the reference), 'detect' or 'always' (HIP); not in the
             reference, which has no device path for the weighted sketch.
-        device_log: when True the device computes ``logf`` itself (fast mode, may differ from
-            numpy's float32 log in the last ulp); default False = parity mode.
+        device_log: where ``np.log`` of the data (ref: weighted_minhash.py:212) is taken.  None (default): on the
+            device when its float32 log reproduces this host's numpy bit for bit (the device function restates numpy's
+            AVX2 / AVX512F loop and equals it for all 2^32 float32 patterns; a start-up check on sentinel values says
+            whether this host's numpy runs that loop), else on the host -- the ``(k, t)`` pairs are the reference's
+            either way.  True: always on the device (no host pass; identical wherever the check holds).  False: always
+            on the host.
     """
 
-    def __init__(self, dim: int, sample_size: int = 128, seed: int = 1, gpu_mode: str = "disable", device_log: bool = False) -> None:
+    def __init__(self, dim: int, sample_size: int = 128, seed: int = 1, gpu_mode: str = "disable", device_log: Optional[bool] = None) -> None:
         self.dim = dim
         self.sample_size = sample_size
         self.seed = seed
@@ -88,6 +92,9 @@ class WeightedMinHashGenerator:
         if self._gpu_mode == "detect":
             return _native.gpu_available()
         return False
+
+    def _log_on_device(self, ctx) -> bool:
+        return ctx.device_log_matches_numpy() if self._device_log is None else bool(self._device_log)
 
     def _device_handle(self):
         ctx = _native.context()
@@ -152,7 +159,7 @@ class WeightedMinHashGenerator:
             # reference: seconds for 10^5 x 4096) is built there.  ln(0) = -inf marks the absent entries.
             ctx, handle = self._device_handle()
             x32 = np.ascontiguousarray(X, dtype=np.float32)
-            if self._device_log:
+            if self._log_on_device(ctx):
                 return ctx.weighted_minhash_many_dense(handle, self.sample_size, x32, False)
             return self._dense_parity_pipelined(ctx, handle, x32)
         X = sparse.csr_matrix(X, dtype=np.float32, copy=True)
@@ -162,7 +169,7 @@ class WeightedMinHashGenerator:
         indices = X.indices.astype(np.int32)
         if self._use_gpu():
             ctx, handle = self._device_handle()
-            if self._device_log:
+            if self._log_on_device(ctx):
                 return ctx.weighted_minhash_many(handle, self.sample_size, indptr, indices, X.data, False)
             with np.errstate(invalid="ignore", divide="ignore"):
                 log_data = np.log(X.data)

@@ -34,8 +34,38 @@ def _done(name):
         print("ok", name, flush=True)
 
 
+_KEEP = []  # GUARD_KEEP=1: nothing is freed before the process ends (no virtual address is ever mapped twice)
+
+
 def _dev(ctx, arr):
-    return ctx.to_device(np.ascontiguousarray(arr))
+    buf = ctx.to_device(np.ascontiguousarray(arr))
+    if os.environ.get("GUARD_KEEP"):
+        _KEEP.append(buf)
+    return buf
+
+
+def _alloc(ctx, nbytes, fill=0xA5):
+    """An output buffer, pre-filled with a pattern: an element the kernel does not write shows."""
+    buf = ctx.alloc(nbytes)
+    check(ctx.lib.mhx_memset_dev(ctx.handle, ctypes.c_void_p(buf.ptr), fill, nbytes))
+    if os.environ.get("GUARD_KEEP"):
+        _KEEP.append(buf)
+    return buf
+
+
+def _expect(got, want, what):
+    if np.array_equal(got, want):
+        return
+    bad = np.argwhere(np.asarray(got) != np.asarray(want))
+    print("MISMATCH", what, "elements", len(bad), "of", np.asarray(want).size, "first", bad[:6].tolist(),
+          "got", [hex(int(np.asarray(got)[tuple(i)])) for i in bad[:4]], "want", [hex(int(np.asarray(want)[tuple(i)])) for i in bad[:4]], flush=True)
+    global FAILED
+    FAILED += 1
+    if not os.environ.get("GUARD_CONTINUE"):
+        raise AssertionError(what)
+
+
+FAILED = 0
 
 
 def _p(buf):
@@ -56,11 +86,11 @@ def minhash_cases(ctx):
             perms = O.np_init_permutations(k, 3)
             hv = rng.randint(0, 2**32, size=(n, fixed), dtype=np.uint64)
             want = O.c_minhash_bulk_dense(hv, perms[0], perms[1])
-            d_hv, d_out = _dev(ctx, hv.astype(tok_dtype)), ctx.alloc(n * k * np.dtype(out_dtype).itemsize)
+            d_hv, d_out = _dev(ctx, hv.astype(tok_dtype)), _alloc(ctx, n * k * np.dtype(out_dtype).itemsize)
             ctx.minhash_bulk_dev(perms, d_hv.ptr, MHX_U32 if tok_dtype == np.uint32 else MHX_U64, None, fixed, n, n * fixed, None, 0,
                                  d_out.ptr, MHX_U32 if out_dtype == np.uint32 else MHX_U64)
             got = d_out.download((n, k), out_dtype)
-            assert np.array_equal(got.astype(np.uint64), want), ("dense", n, fixed, k, tok_dtype, out_dtype)
+            _expect(got.astype(np.uint64), want, ("dense", n, fixed, k, np.dtype(tok_dtype).name, np.dtype(out_dtype).name))
             _done(f"minhash dense {n}x{fixed} K={k} {np.dtype(tok_dtype).name}->{np.dtype(out_dtype).name}")
     # CSR, ragged: tails of 1..7 tokens behind the last whole chunk, the LAST set ending at the end of the token array
     for k in (8, 32, 64, 128, 192, 256):
@@ -75,10 +105,10 @@ def minhash_cases(ctx):
                 perms = O.np_init_permutations(k, 9)
                 init = rng.randint(0, 2**32, size=(n, k), dtype=np.uint64)
                 want = O.c_minhash_bulk(hv, offsets, perms[0], perms[1], init=init)
-                d_hv, d_off, d_init, d_out = _dev(ctx, hv.astype(tok_dtype)), _dev(ctx, offsets), _dev(ctx, init), ctx.alloc(n * k * 8)
+                d_hv, d_off, d_init, d_out = _dev(ctx, hv.astype(tok_dtype)), _dev(ctx, offsets), _dev(ctx, init), _alloc(ctx, n * k * 8)
                 ctx.minhash_bulk_dev(perms, d_hv.ptr, MHX_U32 if tok_dtype == np.uint32 else MHX_U64, d_off.ptr, 0, n, hv.size, d_init.ptr, k,
                                      d_out.ptr, MHX_U64)
-                assert np.array_equal(d_out.download((n, k), np.uint64), want), ("csr", k, lo, hi, n, tok_dtype)
+                _expect(d_out.download((n, k), np.uint64), want, ("csr", k, lo, hi, n, np.dtype(tok_dtype).name))
                 _done(f"minhash csr K={k} lens {lo}..{hi} n={n} {np.dtype(tok_dtype).name}")
     # repeated tokens: the dedup and pairwise launches
     for k in (64, 128, 256):
@@ -89,9 +119,9 @@ def minhash_cases(ctx):
         hv[::3, 9] = hv[::3, 8]
         hv[::5] = hv[::5, :1]  # constant sets
         perms = O.np_init_permutations(k, 2)
-        d_hv, d_out = _dev(ctx, hv), ctx.alloc(n * k * 8)
+        d_hv, d_out = _dev(ctx, hv), _alloc(ctx, n * k * 8)
         ctx.minhash_bulk_dev(perms, d_hv.ptr, MHX_U64, None, t, n, n * t, None, 0, d_out.ptr, MHX_U64)
-        assert np.array_equal(d_out.download((n, k), np.uint64), O.c_minhash_bulk_dense(hv, perms[0], perms[1]))
+        _expect(d_out.download((n, k), np.uint64), O.c_minhash_bulk_dense(hv, perms[0], perms[1]), ("repeats", k))
         _done(f"minhash repeats K={k}")
     # merge: odd counts
     for count in (1, 2, 3, 127, 128 * 33 + 1):
@@ -264,6 +294,9 @@ def main():
     pack_and_lsh_cases(ctx)
     ctx.synchronize()
     _, live = _native.guard_alloc(align)
+    if FAILED:
+        print(f"GUARD FAILED: {FAILED} mismatching cases of {CASES}", flush=True)
+        sys.exit(1)
     print(f"GUARD OK {CASES} cases (align {align}, granule {granule} bytes, {live} guarded blocks alive)", flush=True)
 
 

@@ -165,3 +165,22 @@ def test_bands_bucketed_beyond_two_and_a_half_million_rows(ctx, n):
     dig = got[0][0]
     assert (dig[:, 1:] >= dig[:, :-1]).all()
     ctx.release_scratch()
+
+
+def test_device_log_equals_numpy_log_for_every_float32(ctx):
+    """np_logf (weighted_kernels.hip) against np.log of THIS host's numpy for all 2^32 float32 bit patterns, in pieces
+    (ref: datasketch/weighted_minhash.py:212 takes np.log of float32 data).  Where the host's numpy does not run the
+    AVX2 / AVX512F loop the device function restates (the C model disagrees with np.log too), there is nothing to be equal
+    to: the product's start-up check then keeps the log on the host (test_parity_mode_takes_the_log_where_it_is_numpys)."""
+    probe = np.random.RandomState(1).randint(0, 0x7F800000, size=1 << 16).astype(np.uint32).view(np.float32)
+    if not np.array_equal(O.c_np_logf(probe).view(np.uint32), np.log(probe).view(np.uint32)):
+        pytest.skip("this host's numpy does not use the SIMD float32 log the device function restates")
+    piece = 1 << 26
+    bad = 0
+    with np.errstate(all="ignore"):
+        for start in range(0, 1 << 32, piece):
+            x = np.arange(start, start + piece, dtype=np.uint32).view(np.float32)
+            got = ctx.weighted_logf(x).view(np.uint32)
+            want = np.log(x).view(np.uint32)
+            bad += int(np.count_nonzero(got != want))
+    assert bad == 0

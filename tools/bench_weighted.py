@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--density", type=float, default=1.0, help="fraction of stored entries (the rest are zeros)")
     ap.add_argument("--dist", default="uniform", help="uniform | lognormal | sorted (columns by increasing weight)")
     ap.add_argument("--variants", default="path=0;path=2")
+    ap.add_argument("--values", action="store_true", help="hand over the values, not their logs: the device takes the log (np_logf)")
     ap.add_argument("--csr", action="store_true", help="hand the rows over as CSR (mhx_weighted_minhash_many_dev) instead of dense")
     args = ap.parse_args()
 
@@ -67,7 +68,7 @@ def main():
             d_val = ctx.to_device(np.log(csr.data).astype(np.float32))
         nnz = int(csr.nnz)
     else:
-        d_x = ctx.to_device(logs)
+        d_x = ctx.to_device(x if args.values else logs)
     first = None
     for variant in args.variants.split(";"):
         opts = dict(kv.split("=") for kv in variant.split(",") if kv)
@@ -82,7 +83,7 @@ def main():
             if args.csr:
                 _native.check(lib.mhx_weighted_minhash_many_dev(handle, d_ptr.ptr, d_idx.ptr, d_val.ptr, 1, n, nnz, d_o.ptr, d_ne.ptr))
             else:
-                _native.check(lib.mhx_weighted_minhash_many_dense_dev(handle, d_x.ptr, 1, n, d_o.ptr, d_ne.ptr))
+                _native.check(lib.mhx_weighted_minhash_many_dense_dev(handle, d_x.ptr, 0 if args.values else 1, n, d_o.ptr, d_ne.ptr))
 
         call()
         ctx.synchronize()
