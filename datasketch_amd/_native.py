@@ -40,6 +40,7 @@ _PROTOTYPES = {
     "mhx_dev_alloc": [_vp, _sz, ctypes.POINTER(_vp)],
     "mhx_dev_free": [_vp, _vp],
     "mhx_debug_guard_alloc": [_int, ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
+    "mhx_debug_poison_alloc": [_int],
     "mhx_host_alloc": [_vp, _sz, ctypes.POINTER(_vp)],
     "mhx_host_free": [_vp, _vp],
     "mhx_memcpy_h2d": [_vp, _vp, _vp, _sz],
@@ -260,6 +261,12 @@ def guard_alloc(align: int):
     g, live = _i64(0), _i64(0)
     check(load().mhx_debug_guard_alloc(int(align), ctypes.byref(g), ctypes.byref(live)))
     return int(g.value), int(live.value)
+
+
+def poison_alloc(byte_value: int) -> None:
+    """Debugging (mhx_debug_poison_alloc): fresh device allocations of the library are filled with this byte (0..255;
+    -1 = off) -- the dirty memory of a board that has been in use, made deterministic."""
+    check(load().mhx_debug_poison_alloc(int(byte_value)))
 
 
 class DeviceBuffer:

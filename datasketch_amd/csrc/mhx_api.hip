@@ -120,11 +120,35 @@ hipError_t guard_malloc(void **p, size_t bytes, int align) {
 
 // caller: a block handed out by mhx_dev_alloc (placed with the guard alignment as it is); the library's own blocks --
 // staging, tables, rocPRIM temporaries -- keep the 256-byte alignment hipMalloc gives them and that they are carved up by
+// Poison mode (environment MHX_POISON_ALLOC=<byte 0..255>, or mhx_debug_poison_alloc): every fresh block is filled with
+// that byte before it is handed out.  hipMalloc's memory is zero on a freshly booted board and whatever the previous
+// tenant left on a used one; a kernel that reads a word nobody wrote works on the first and faults -- or answers
+// wrongly -- on the second, box by box.  0xFF makes such a read a NaN, a -1 or a huge offset, every time.
+static int g_poison = -0x7fffffff;  // not read yet
+static int poison_byte() {
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    if (g_poison == -0x7fffffff) {
+        const char *e = getenv("MHX_POISON_ALLOC");
+        g_poison = e ? (atoi(e) & 255) : -1;
+    }
+    return g_poison;
+}
+
 hipError_t dev_malloc(void **p, size_t bytes, bool caller) {
     int align = guard_align();
-    if (align == 0) return hipMalloc(p, bytes);
-    if (!caller) align = align < 0 ? std::min(align, -256) : std::max(align, 256);
-    return guard_malloc(p, bytes, align);
+    hipError_t e;
+    if (align == 0) {
+        e = hipMalloc(p, bytes);
+    } else {
+        if (!caller) align = align < 0 ? std::min(align, -256) : std::max(align, 256);
+        e = guard_malloc(p, bytes, align);
+    }
+    const int poison = poison_byte();
+    if (e == hipSuccess && poison >= 0) {
+        e = hipMemset(*p, poison, bytes);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    return e;
 }
 
 hipError_t dev_free(void *p) {
@@ -337,6 +361,7 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "weighted.split")) ctx->opt_weighted_split = value;
     else if (!strcmp(key, "weighted.tail")) ctx->opt_weighted_tail = value;
     else if (!strcmp(key, "weighted.debug")) ctx->opt_weighted_debug = value;
+    else if (!strcmp(key, "weighted.kernel")) ctx->opt_weighted_kernel = value;
     else if (!strcmp(key, "host.chunk_bytes")) ctx->opt_host_chunk_bytes = value;
     else if (!strcmp(key, "lsh.sort_bits")) ctx->opt_lsh_sort_bits = value;
     else if (!strcmp(key, "lsh.gather")) ctx->opt_lsh_gather = value;
@@ -401,6 +426,14 @@ int mhx_debug_guard_alloc(int align, int64_t *granule, int64_t *live) {
         }
         *granule = (int64_t)g;
     }
+    return MHX_OK;
+}
+
+int mhx_debug_poison_alloc(int byte_value) {
+    if (byte_value < -1 || byte_value > 255) return fail(MHX_ERR_INVALID, "poison byte must be -1 (off) or 0..255, got %d", byte_value);
+    (void)mhx::poison_byte();  // read the environment first: this call overrides it
+    std::lock_guard<std::mutex> lk(mhx::g_guard_mu);
+    mhx::g_poison = byte_value;
     return MHX_OK;
 }
 

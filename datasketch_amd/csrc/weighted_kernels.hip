@@ -939,6 +939,151 @@ __global__ __launch_bounds__(256, 4) void weighted_walk_dense_kernel(const float
     }
 }
 
+
+// ---- dense rows, one WAVE per row (round 4) -----------------------------------------------------------------------
+// The workgroup-per-row kernel above spends a row's time waiting: four waves stage, a barrier, two of them walk (at 128
+// samples) while the other two idle, a barrier -- 8 700 cycles per row with one workgroup per CU (stage 2 200, reduce +
+// barrier 800, walk 4 700, the rest barriers: tools/experiments/r04_walk_phase_cycles.patch), of which the VALU issues a
+// sixth, and LDS (a row, a list and 20 KB of cached walk tables per workgroup) caps a CU at four rows in flight.
+// Here a wave owns a row: it fetches it (two rows ahead, into registers), stages it in its OWN 16-KB stripe of LDS,
+// scans it with ballots (no atomics, no barrier: LDS operations of one wave complete in order) and walks every chunk of
+// samples itself.  The waves of a workgroup share nothing but the cached walk tables (read-only after the start), so
+// one workgroup of eight waves per CU keeps EIGHT rows in flight in the same 160 KB, no wave ever idles at a barrier,
+// and the row's stream (16 x 1-KB loads per row and wave) overlaps with the walks of the seven other waves.
+// Same arithmetic, same rules, same helper (walk_row) as the kernel above; rows it does not take (dim > 4096 or not a
+// multiple of 4, fewer than two stripes fitting the LDS) stay with that kernel.
+template <bool LOGS, int NV>  // NV: 16-byte loads per lane that hold a row (dim <= 256 NV)
+__global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__restrict__ x, int64_t n_rows, int32_t dim,
+                                                                 const WalkPlan *__restrict__ plan, const float4 *__restrict__ walk_a,
+                                                                 const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos,
+                                                                 int32_t sample_size, int32_t s_pad, int32_t list_cap, int32_t direct_permille,
+                                                                 int32_t stripe_words, int64_t *__restrict__ out, uint8_t *__restrict__ nonempty) {
+    extern __shared__ float lds[];  // cached list positions of the first n_cc chunks | per wave: row[dim] | list[list_cap] u16
+    const int tid = threadIdx.x, lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), n_waves = blockDim.x >> 6;
+    const int32_t chunks = s_pad / kWave;
+    const int32_t n_cc = chunks < kCachedChunks ? chunks : kCachedChunks;
+    float4 *s_cache_a = reinterpret_cast<float4 *>(lds);
+    uint32_t *s_cache_c = reinterpret_cast<uint32_t *>(s_cache_a + n_cc * kWalkCached * kWave);
+    for (int j = tid; j < n_cc * kWalkCached * kWave; j += blockDim.x) {
+        const int ch = j / (kWalkCached * kWave), k = j / kWave % kWalkCached;
+        if (ch < chunks && k < dim) {
+            s_cache_a[j] = walk_a[((int64_t)ch * dim + k) * kWave + (j & (kWave - 1))];
+            s_cache_c[j] = walk_c[((int64_t)ch * dim + k) * kWave + (j & (kWave - 1))];
+        }
+    }
+    __syncthreads();  // the only barrier of the kernel
+    float *row = lds + 5 * n_cc * kWalkCached * kWave + (int64_t)wave * stripe_words;
+    uint16_t *list = reinterpret_cast<uint16_t *>(row + ((dim + 3) & ~3));
+    const float lcut = plan->lcut;
+    const int64_t stride = (int64_t)gridDim.x * n_waves;
+    // every lane always issues exactly NV loads per row (clamped to the matrix and to the row), so that the number of loads
+    // in flight behind a row's is known at compile time and the wait for a row is not a wait for the one behind it
+    const auto fetch = [&](float4 (&pre)[NV], int64_t d) {
+        const float *src = x + (d < n_rows ? d : n_rows - 1) * dim;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = (u * kWave + lane) * 4;
+            pre[u] = *reinterpret_cast<const float4 *>(src + (c < dim ? c : dim - 4));
+        }
+    };
+    const auto one_row = [&](float4 (&pre)[NV], int64_t d) {
+        // stage + scan: the row's logs into the stripe (-inf: not stored), its stored entries counted, NaNs and entries
+        // above the cut noted in a bit mask per lane (bit 4 u + e: column (64 u + lane) 4 + e)
+        int cnt = 0;
+        bool nan = false;
+        unsigned long long above = 0;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = (u * kWave + lane) * 4;
+            if (c < dim) {
+                const float v[4] = {pre[u].x, pre[u].y, pre[u].z, pre[u].w};
+                float l[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lg = LOGS ? v[e] : np_logf(v[e]);
+                    const bool stored = LOGS ? !(lg == -__builtin_inff()) : (v[e] != 0.0f);  // scipy's nonzero(): NaN stays
+                    cnt += stored;
+                    nan |= lg != lg;
+                    above |= (unsigned long long)(lg > lcut) << (4 * u + e);  // +inf too
+                    l[e] = stored ? lg : -__builtin_inff();
+                }
+                *reinterpret_cast<float4 *>(row + c) = make_float4(l[0], l[1], l[2], l[3]);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        const int n_stored = cnt;
+        const bool has_nan = __any(nan);
+        int n_out = 0;
+        while (true) {  // (wave-uniform) the columns above the cut: every lane hands in its lowest one per turn
+            const bool has = above != 0;
+            const unsigned long long mask = __ballot(has);
+            if (!mask) break;
+            if (has) {
+                const int b = __builtin_ctzll(above);
+                above &= above - 1;
+                const int at = n_out + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                if (at < list_cap) list[at] = (uint16_t)(((b >> 2) * kWave + lane) * 4 + (b & 3));
+            }
+            n_out += __popcll(mask);
+        }
+        int n_list = n_out;
+        // as in the workgroup-per-row kernel: few stored entries, or more above the cut than the list holds -> entry by entry
+        const bool by_entry = n_out > list_cap || (int64_t)n_stored * 1000 <= (int64_t)direct_permille * dim;
+        const bool listable = by_entry && !has_nan && n_stored > 0 && n_stored <= list_cap;
+        if (listable) {  // list the stored columns (ascending)
+            int at = 0;
+            for (int c0 = 0; c0 < dim; c0 += kWave) {
+                const int c = c0 + lane;
+                const bool keep = c < dim && !(row[c] == -__builtin_inff());
+                const unsigned long long mask = __ballot(keep);
+                if (keep) list[at + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint16_t)c;
+                at += __popcll(mask);
+            }
+            n_list = n_stored;
+        }
+        for (int32_t ch = 0; ch < chunks; ++ch) {
+            const int32_t my = ch * kWave + lane;
+            int64_t k_out = 0, t_out = 0;
+            if (n_stored == 0) {
+                // nothing stored: (0, 0), and the row is reported empty
+            } else if (has_nan) {
+                nan_row(row, dim, my, aos, s_pad, k_out, t_out);
+            } else if (by_entry && !listable) {  // every stored entry, in column order
+                Held held;
+                for (int32_t c = 0; c < dim; ++c) {
+                    const float l = row[c];
+                    if (!(l == -__builtin_inff())) held.offer(l, aos[(int64_t)c * s_pad + my], (uint32_t)c);
+                }
+                k_out = held.c, t_out = (int64_t)held.t;
+            } else {
+                const Held held = walk_row(row, list, n_list, by_entry, dim, ch, my, sample_size, walk_a, walk_c, aos, s_pad,
+                                           ch < n_cc ? s_cache_a + ch * kWalkCached * kWave : nullptr,
+                                           ch < n_cc ? s_cache_c + ch * kWalkCached * kWave : nullptr, 0, 1);
+                k_out = held.c, t_out = (int64_t)held.t;
+            }
+            if (my < sample_size) {
+                int64_t *o = out + (d * sample_size + my) * 2;
+                o[0] = k_out;
+                o[1] = t_out;
+            }
+        }
+        if (lane == 0) nonempty[d] = n_stored > 0 ? 1 : 0;
+        // the refill goes out behind the walk (vector loads complete in order: a walk's own table load must not sit out
+        // the HBM latency of a row that is not needed for two rows)
+        fetch(pre, d + 2 * stride);
+    };
+    float4 pre0[NV], pre1[NV];
+    const int64_t d0 = (int64_t)blockIdx.x * n_waves + wave;
+    fetch(pre0, d0);
+    fetch(pre1, d0 + stride);
+    for (int64_t d = d0; d < n_rows; d += 2 * stride) {
+        one_row(pre0, d);
+        if (d + stride < n_rows) one_row(pre1, d + stride);
+    }
+}
+
 // ---- CSR rows ---------------------------------------------------------------------------------------
 // A row that stores few of the columns is evaluated entry by entry (weighted_csr_direct_kernel: one wave per row and
 // 64 samples, four table entries in flight); a row that stores many is spread out in LDS (-inf where nothing is stored)
@@ -1193,8 +1338,43 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
     hipLaunchKernelGGL(walk_build_kernel, dim3((unsigned)gen->sample_size), dim3(256), sizeof(unsigned long long) * (size_t)p2, ctx->stream, plan,
                        reinterpret_cast<const float4 *>(gen->d_aos), dim, p2, gen->s_pad, walk_a, gen->d_walk_c);
     MHX_HIP_CHECK(hipGetLastError());
-    const unsigned threads = 256;  // four waves stage a row; its chunks of 64 samples are then shared out among them
     const int32_t list_cap = std::max(64, dim / 4);
+    const int32_t direct_permille_w = ctx->opt_weighted_direct > 0 ? (int32_t)ctx->opt_weighted_direct : 100;
+    // one wave per row (weighted_walk_wave_kernel) when a row is 4 .. 16 sixteen-byte loads per lane and at least four
+    // stripes fit the LDS beside the cached tables; option weighted.kernel: 1 = the workgroup-per-row kernel always
+    {
+        const int32_t n_cc_w = std::min<int32_t>(gen->s_pad / kWave, kCachedChunks);
+        const size_t cache_bytes = 20 * (size_t)n_cc_w * kWalkCached * kWave;
+        const int32_t list_cap_w = std::max(64, dim / 8);  // (half the other kernel's: eight stripes of a 4096-column row then fit beside the tables)
+        const size_t stripe_bytes = (sizeof(float) * (size_t)((dim + 3) & ~3) + sizeof(uint16_t) * (size_t)((list_cap_w + 7) & ~7) + 15) & ~(size_t)15;
+        const int64_t fit = ((int64_t)ctx->lds_per_block - (int64_t)cache_bytes - 64) / (int64_t)stripe_bytes;
+        const int waves = (int)std::min<int64_t>(8, fit);
+        const bool shape_ok = (dim & 3) == 0 && (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 && dim >= 1024 && dim <= 4096;
+        if (shape_ok && waves >= 4 && ctx->opt_weighted_kernel != 1 && ctx->opt_weighted_debug == 0) {
+            const size_t lds = cache_bytes + stripe_bytes * (size_t)waves;
+            const int64_t groups = (n_rows + waves - 1) / waves;
+            const int64_t per_cu = ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu : std::max<int64_t>(1, (int64_t)ctx->lds_per_block / (int64_t)(lds + 64));
+            const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, per_cu * ctx->num_cus));
+            const int nv = dim <= 1024 ? 4 : dim <= 2048 ? 8 : 16;
+#define MHX_WALK_WAVE(LOGS, NV_)                                                                                                          \
+    hipLaunchKernelGGL((weighted_walk_wave_kernel<LOGS, NV_>), dim3(blocks), dim3(64 * waves), lds, ctx->stream, d_x, n_rows, dim, plan, walk_a, \
+                       gen->d_walk_c, reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, list_cap_w, direct_permille_w,  \
+                       (int32_t)(stripe_bytes / 4), d_out, d_nonempty)
+            if (values_are_logs) {
+                if (nv == 4) MHX_WALK_WAVE(true, 4);
+                else if (nv == 8) MHX_WALK_WAVE(true, 8);
+                else MHX_WALK_WAVE(true, 16);
+            } else {
+                if (nv == 4) MHX_WALK_WAVE(false, 4);
+                else if (nv == 8) MHX_WALK_WAVE(false, 8);
+                else MHX_WALK_WAVE(false, 16);
+            }
+#undef MHX_WALK_WAVE
+            MHX_HIP_CHECK(hipGetLastError());
+            return MHX_OK;
+        }
+    }
+    const unsigned threads = 256;  // four waves stage a row; its chunks of 64 samples are then shared out among them
     const int32_t direct_permille = ctx->opt_weighted_direct > 0 ? (int32_t)ctx->opt_weighted_direct : 100;  // rows storing less than 10 % of the columns: entry by entry (measured crossover, dense and CSR alike)
     const int32_t n_cc = std::min<int32_t>(gen->s_pad / kWave, kCachedChunks);
     const size_t lds = sizeof(float) * (size_t)((dim + 3) & ~3) + sizeof(uint16_t) * (size_t)((list_cap + 7) & ~7) + 20 * (size_t)n_cc * kWalkCached * kWave;

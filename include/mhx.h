@@ -110,6 +110,13 @@ MHX_API int mhx_dev_free(mhx_ctx *ctx, void *dptr);
  * environment variable MHX_GUARD_ALLOC=<align> does the same from the first allocation.  granule (may be NULL)
  * receives the mapping granularity in bytes, live (may be NULL) the number of guarded blocks currently allocated. */
 MHX_API int mhx_debug_guard_alloc(int align, int64_t *granule, int64_t *live);
+/* Debugging: poison.  From this call on every fresh device allocation of the library in this process is filled with
+ * byte_value (0..255; -1 switches it off) before it is handed out -- what a board that has been in use gives a process
+ * anyway, made deterministic: a kernel that reads a word nobody wrote then computes with 0xFF..FF (a NaN, a -1, an
+ * offset of 2^64-1) on every box instead of with the zeros of a freshly booted one.  Environment: MHX_POISON_ALLOC=<byte>.
+ * (The library's blocks inside guard mode keep hipMalloc's 256-byte alignment; only mhx_dev_alloc's blocks are placed
+ * with the guard alignment as given.) */
+MHX_API int mhx_debug_poison_alloc(int byte_value);
 /* page-locked host memory: buffers a caller fills and hands to the host entry points again and again (the pieces of
  * mhx_weighted_dense_feed, staging for mhx_minhash_bulk) go up by DMA straight from it, about 1.3x the rate of pageable memory */
 MHX_API int mhx_host_alloc(mhx_ctx *ctx, size_t bytes, void **ptr);

@@ -1,6 +1,7 @@
 """GPU parity tests added in round 4 (run on an MI355X: python -m pytest tests -m gpu -x -q).
 
-The weighted kernels with MORE ROWS THAN WORKGROUPS for every instantiation: a workgroup of the dense walk kernel keeps
+The weighted kernels with MORE ROWS THAN WORKGROUPS (and than waves, for the one-wave-per-row kernel of round 4) for every
+instantiation: a workgroup of the dense walk kernel keeps
 its cached walk tables, its prefetched rows and the row's LDS (which doubles as scratch for shared-out lists) across
 rows, so a bug in what survives from one row to the next only shows when a workgroup takes several rows
 (reference: datasketch/weighted_minhash.py:191-247).  Everything goes through the C ABI; the C
@@ -78,10 +79,17 @@ _SAMPLES = [1, 65, 129, 300, 513]
 
 def _case_id(dim, s):
     ahead = dim % 4 == 0 and 4 <= dim <= 4096
-    return f"walk_dense_AHEAD_{str(ahead).lower()}-dim{dim}-S{s}-chunks{(s + 63) // 64}"
+    kernel = "walk_wave" if dim % 4 == 0 and 1024 <= dim <= 4096 else "walk_dense"
+    return f"{kernel}_AHEAD_{str(ahead).lower()}-dim{dim}-S{s}-chunks{(s + 63) // 64}"
 
 
-_CASES = [(d, s) for d in _DIMS for s in _SAMPLES] + [(1024, 300), (1024, 513), (4096, 300), (4096, 513), (4096, 128)]
+# ... and dims the one-wave-per-row kernel takes (1024 <= dim <= 4096, a multiple of 4): both kernels, every row
+_CASES = [(d, s) for d in _DIMS for s in _SAMPLES] + [(1024, 300), (1024, 513), (4096, 300), (4096, 513), (4096, 128), (2048, 128), (1500, 65), (4092, 129),
+                                                       (3000, 1)]
+
+
+def _wave_kernel_takes(dim):
+    return dim % 4 == 0 and 1024 <= dim <= 4096
 
 
 @pytest.mark.parametrize("dim,s", _CASES, ids=[_case_id(d, s) for d, s in _CASES])
@@ -126,9 +134,19 @@ def test_weighted_kernels_with_several_rows_per_workgroup(ctx, dim, s):
         assert np.array_equal(ne_v, ne_v2) and np.array_equal(out_v[ne_v.astype(bool)], every_v[ne_v.astype(bool)])
         return out, ne
 
-    n_dense = 3 * dense_blocks + 37
+    n_dense = 3 * (2048 if _wave_kernel_takes(dim) else dense_blocks) + 37  # (256 workgroups of eight waves: one row per wave and turn)
     x = _fuzz_matrix(rng, n_dense, dim, heavy)
     out0, ne0 = check(x, False)
+    if _wave_kernel_takes(dim):  # the workgroup-per-row kernel on the same rows (its AHEAD instantiation)
+        wctx.set_option("weighted.kernel", 1)
+        try:
+            out_w, ne_w = g.minhash_many_arrays(x)
+            out_wv, ne_wv = gv.minhash_many_arrays(x)
+        finally:
+            wctx.set_option("weighted.kernel", 0)
+        assert np.array_equal(out_w, out0) and np.array_equal(ne_w, ne0)
+        out_v, ne_v = gv.minhash_many_arrays(x)
+        assert np.array_equal(out_wv[ne_v.astype(bool)], out_v[ne_v.astype(bool)]) and np.array_equal(ne_wv, ne_v)
     if (s + 63) // 64 * 2 <= 4:  # the waves of a workgroup can share a chunk's list: both settings of weighted.split
         wctx.set_option("weighted.split", 1)
         try:

@@ -78,6 +78,7 @@ def main():
         ctx.set_option("weighted.debug", int(opts.get("debug", 0)))
         ctx.set_option("weighted.split", int(opts.get("split", 0)))
         ctx.set_option("weighted.tail", int(opts.get("tail", 0)))
+        ctx.set_option("weighted.kernel", int(opts.get("kernel", 0)))
 
         def call():
             if args.csr:
@@ -121,6 +122,7 @@ def main():
     ctx.set_option("blocks_per_cu", 0)
     ctx.set_option("weighted.direct", 0)
     ctx.set_option("weighted.debug", 0)
+    ctx.set_option("weighted.kernel", 0)
 
 
 if __name__ == "__main__":
