@@ -362,6 +362,7 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "weighted.tail")) ctx->opt_weighted_tail = value;
     else if (!strcmp(key, "weighted.debug")) ctx->opt_weighted_debug = value;
     else if (!strcmp(key, "weighted.kernel")) ctx->opt_weighted_kernel = value;
+    else if (!strcmp(key, "weighted.plan")) ctx->opt_weighted_plan = value;
     else if (!strcmp(key, "host.chunk_bytes")) ctx->opt_host_chunk_bytes = value;
     else if (!strcmp(key, "lsh.sort_bits")) ctx->opt_lsh_sort_bits = value;
     else if (!strcmp(key, "lsh.gather")) ctx->opt_lsh_gather = value;
@@ -1350,7 +1351,7 @@ int mhx_wgen_create(mhx_ctx *ctx, const float *rs, const float *ln_cs, const flo
     for (size_t j = 0; j < n && g->walk_ok; ++j)
         g->walk_ok = rs[j] > 0.0f && fabsf(ln_cs[j]) < __builtin_inff() && fabsf(betas[j]) < __builtin_inff();
     const size_t a_bytes = sizeof(float) * 4 * (size_t)g->s_pad * (size_t)dim;
-    const float plan0[4] = {__builtin_nanf(""), 0.0f, 0.0f, 0.0f};  // WalkPlan: no tables yet
+    const float plan0[8] = {__builtin_nanf(""), 0.0f, 0.0f, 0.0f, __builtin_nanf(""), 0.0f, 0.0f, 0.0f};  // two WalkPlan records: no tables yet
     hipError_t e = mhx::dev_malloc((void **)&g->d_params, t_bytes);
     if (e == hipSuccess) e = mhx::dev_malloc((void **)&g->d_aos, a_bytes);
     if (e == hipSuccess && g->walk_ok) e = mhx::dev_malloc((void **)&g->d_walk_a, a_bytes);

@@ -71,7 +71,8 @@ struct mhx_ctx {
     int64_t opt_minhash_prefetch = 1; // warm L2 with the next set's tokens (vector load per set)
     int64_t opt_minhash_alias = -1; // profiling only: >= 0 makes set i read the tokens of set (i & mask)
     int64_t opt_weighted_path = 0;  // 0 auto (dense rows: bound-ordered walk; CSR: reciprocal-multiply quotient + row blocks), 1 IEEE division for every element, 2 every element evaluated (dense rows compacted to CSR: the round-2 path)
-    int64_t opt_weighted_kernel = 0; // dense walk: 0 auto (one wave per row where the shape allows), 1 = one workgroup per row always
+    int64_t opt_weighted_plan = 0;   // walk plan + tables: 0 = one launch (every workgroup plans, then sorts its sample's list if need be), 1 = round 3's two launches
+    int64_t opt_weighted_kernel = 0; // dense walk: 0 auto (one wave per row where the shape allows, two chunks of samples walked as one stream), 1 = one workgroup per row always, 2 = one wave per row, chunk after chunk
     int64_t opt_weighted_debug = 0;  // profiling only (results are wrong): 1 = rows staged and scanned, not walked; 2 = staged without the scan
     int64_t opt_weighted_split = 0;  // dense walk kernel, rows evaluated entry by entry: 0 = the waves of a workgroup that share a chunk of samples split the list, 1 = one wave per chunk
     int64_t opt_weighted_tail = 0;   // walk plan: 0 = the cut with the smallest estimated cost, 1 .. 5 = that entry of kCutTail (profiling)
@@ -126,7 +127,8 @@ struct mhx_wgen {
     // were built for.  walk_ok: r > 0, ln_c and beta finite everywhere (the bound's monotonicity) and dim <= 16384 (LDS)
     float *d_walk_a = nullptr;
     uint32_t *d_walk_c = nullptr;
-    void *d_walk_plan = nullptr;
+    void *d_walk_plan = nullptr;  // two WalkPlan records: the one the last call wrote (plan_index) and the one the next call will write
+    int plan_index = 0;
     bool walk_ok = false;
 };
 

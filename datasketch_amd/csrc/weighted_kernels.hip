@@ -124,6 +124,37 @@ __device__ __forceinline__ float np_logf(float x) {
     return r;
 }
 
+// The same function for positive normal x only (0x00800000 <= bits < 0x7f800000: no denormal normalisation, no special
+// values), arranged for the VALU: the two Horner chains run as ONE packed fused multiply-add per step (v_pk_fma_f32), the
+// split at 1/sqrt(2) is a multiplier (m * 2 - 1 and m * 1 - 1 are exact, like m + m - 1 and m - 1), and the quotient is
+// the reciprocal refined once and the product corrected twice by its exact remainder -- the hardware's own division
+// sequence without the operand scaling it needs for extreme exponents (here 0.44 < Q < 3.4 and |P| < 0.61).  That this
+// sequence rounds P/Q like the IEEE division for EVERY (P, Q) that can occur is not argued but checked: the 2^32-pattern
+// test covers every mantissa there is.
+typedef float vec2f_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float np_logf_normal(float x) {
+    const uint32_t b = __float_as_uint(x);
+    float m = __uint_as_float((b & 0x007fffffu) | 0x3f000000u);
+    const bool low = m <= 0.707106781186547524400844362104849039f;
+    m = __builtin_fmaf(m, low ? 2.0f : 1.0f, -1.0f);
+    const float ef = (float)(b >> 23) - (low ? 127.0f : 126.0f);
+    const vec2f_t mm = {m, m};
+    vec2f_t pq = __builtin_elementwise_fma(vec2f_t{2.589979117907922693523e-02f, 5.875095403124574342950e-03f}, mm,
+                                           vec2f_t{3.808837741388407920751e-01f, 1.546476374983906719538e-01f});
+    pq = __builtin_elementwise_fma(pq, mm, vec2f_t{1.480000633576506585156e+00f, 9.864942958519418960339e-01f});
+    pq = __builtin_elementwise_fma(pq, mm, vec2f_t{2.112677543073053063722e+00f, 2.453006071784736363091e+00f});
+    pq = __builtin_elementwise_fma(pq, mm, vec2f_t{9.999999999999998702752e-01f, 2.612677543073109236779e+00f});
+    pq = __builtin_elementwise_fma(pq, mm, vec2f_t{0.0f, 1.0f});
+    const float num = pq.x, den = pq.y;
+    float r = __builtin_amdgcn_rcpf(den);
+    r = __builtin_fmaf(__builtin_fmaf(-den, r, 1.0f), r, r);
+    float q = num * r;
+    q = __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
+    q = __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
+    return __builtin_fmaf(ef, 0.693147180559945309417232121458176568f, q);
+}
+__device__ __forceinline__ bool np_logf_is_normal(float x) { return __float_as_uint(x) - 0x00800000u < 0x7f000000u; }
+
 // ---- pre-pass: one wave per row -------------------------------------------------------------
 // logs[j] = ln(x) (device-log mode only), flags[row] = kFlagSamePattern (same column list as the
 // first row of its block of 8) | kFlagSane (every log value is 0, +-inf or 2^-40 <= |L| <= 2^40).
@@ -599,6 +630,201 @@ __global__ __launch_bounds__(256) void walk_build_kernel(const WalkPlan *__restr
     }
 }
 
+// Plan and tables in ONE launch (round 4; the two kernels above remain for reference runs, option weighted.plan = 1).
+// One workgroup per sample.  Every workgroup computes the plan itself -- the same ~16k sampled logs, the same integer
+// histogram, hence the same cut, no communication -- and then, when the tables standing on the generator do not fit that
+// cut, sorts its own sample's list.  The plan is double-buffered (`cur` read, `next` written by workgroup 0): a workgroup
+// that is late must not read the verdict of one that has already finished.  Against the two launches: the sampled logs are
+// all requested before the first one is counted (the old kernel paid a memory round trip per segment: 18 us), the suffix
+// sums go through wave shuffles (2 barriers instead of 20), and a call whose tables stand costs one short launch, not two.
+template <bool LOGS>
+__global__ __launch_bounds__(1024) void walk_plan_build_kernel(const float *__restrict__ v, int64_t total, int32_t seg_len, int32_t n_seg, float per_row,
+                                                               int32_t forced, const WalkPlan *__restrict__ cur, WalkPlan *__restrict__ next,
+                                                               const float4 *__restrict__ aos, int32_t dim, int32_t p2, int32_t s_pad,
+                                                               float4 *__restrict__ walk_a, uint32_t *__restrict__ walk_c) {
+    extern __shared__ unsigned long long keys[];  // p2 sort keys (the build), behind them the histogram
+    uint32_t *hist = reinterpret_cast<uint32_t *>(keys + p2);
+    __shared__ uint32_t wave_sum[16];
+    __shared__ uint32_t part_above[1024];  // per thread: the sampled values in bins above the thread's own
+    __shared__ uint32_t s_top, s_cut[kCuts], s_above[kCuts];
+    __shared__ float s_lcut;
+    __shared__ int s_rebuild;
+    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    for (int b = tid; b < (1 << kHistBits); b += 1024) hist[b] = 0;
+    if (tid == 0) s_top = 0;
+    if (tid < kCuts) s_cut[tid] = 0, s_above[tid] = 0;
+    __syncthreads();
+    {   // the sample: n_seg runs of seg_len values spread over v[0 .. total); 16 values per thread in flight at a time
+        const int64_t span = total - seg_len;
+        const int64_t n_sampled = (int64_t)seg_len * n_seg;
+        for (int64_t base = 0; base < n_sampled; base += 16 * 1024) {
+            float val[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int64_t q = base + u * 1024 + tid;
+                const int64_t sgm = q / seg_len, j = q - sgm * seg_len;
+                const int64_t start = n_seg > 1 ? span * sgm / (n_seg - 1) : 0;
+                val[u] = q < n_sampled ? v[start + j] : __builtin_nanf("");
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                float l = val[u];
+                if (!LOGS) l = np_logf(l);
+                if (fabsf(l) < __builtin_inff()) atomicAdd(&hist[ordered_bits(l) >> (32 - kHistBits)], 1u);  // finite, not NaN
+            }
+        }
+    }
+    __syncthreads();
+    // thread t owns bins [16 t, 16 t + 16); suffix sums over the threads by wave shuffles, then inside the thread's bins from the top
+    constexpr int kPer = (1 << kHistBits) / 1024;
+    uint32_t mine = 0;
+    for (int b = 0; b < kPer; ++b) mine += hist[tid * kPer + b];
+    uint32_t suf = mine;  // inclusive suffix sum inside the wave
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_down((int)suf, o);
+        if (lane + o < kWave) suf += up;
+    }
+    if (lane == 0) wave_sum[wave] = suf;
+    __syncthreads();
+    uint32_t later = 0, all = 0;
+    for (int w = 0; w < 16; ++w) {
+        all += wave_sum[w];
+        if (w > wave) later += wave_sum[w];
+    }
+    uint32_t above = later + suf - mine;  // values in bins above this thread's
+    part_above[tid] = above;
+    for (int b = kPer - 1; b >= 0; --b) {
+        const uint32_t h = hist[tid * kPer + b];
+        if (h) atomicMax(&s_top, (uint32_t)(tid * kPer + b));
+#pragma unroll
+        for (int i = 0; i < kCuts; ++i) {
+            const uint32_t tail = (uint32_t)((float)all * kCutTail[i]);
+            if (above <= tail && above + h > tail) s_cut[i] = (uint32_t)(tid * kPer + b), s_above[i] = above;  // the bin holding the quantile: one thread
+        }
+        above += h;
+    }
+    __syncthreads();
+    if (wave == 0) {  // the five candidate cuts, one lane each: what the walk would cost with it (see kCutTail above)
+        const auto upper = [](uint32_t bin) { return from_ordered_bits(((bin + 1u) << (32 - kHistBits)) - 1u); };
+        float top = all ? upper(s_top) : 0.0f;
+        if (!(top < __builtin_inff())) top = __FLT_MAX__;
+        float cut = top, cost = __builtin_inff(), q = top;
+        if (lane < kCuts && all) {
+            cut = upper(s_cut[lane]);
+            if (!(cut < __builtin_inff())) cut = __FLT_MAX__;
+            uint32_t listed = s_above[lane];
+            if (lane == 0) {
+                q = cut;
+                if (top - cut < kCutSlack) cut = top, listed = 0;
+            }
+            const float near_lo = cut - kNearCut;
+            const uint32_t lo_bin = near_lo > -__FLT_MAX__ ? ordered_bits(near_lo) >> (32 - kHistBits) : 0u;
+            uint32_t near = part_above[lo_bin / kPer];  // sampled values in bins above lo_bin ...
+            for (uint32_t b = lo_bin + 1; b < (lo_bin / kPer + 1) * kPer; ++b) near += hist[b];
+            near -= listed;                             // ... and not above the cut: the logs in (cut - kNearCut, cut], by whole bins
+            const float scale = per_row / (float)all;
+            const float positions = kWalkPerNear / fmaxf((float)near * scale, 1e-3f);
+            cost = (float)listed * scale * kCostListed + fmaxf(positions - (float)kWalkCached, 0.0f) * kCostPosition;
+            if (forced > 0) cost = lane == forced - 1 ? 0.0f : __builtin_inff();  // option weighted.tail (profiling)
+        }
+        // the cheapest (the first among equals), across the lanes
+        float best_cost = cost, best_cut = cut;
+        int best_lane = lane;
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            const float oc = __shfl_xor(best_cost, o), ocut = __shfl_xor(best_cut, o);
+            const int ol = __shfl_xor(best_lane, o);
+            if (oc < best_cost || (oc == best_cost && ol < best_lane)) best_cost = oc, best_cut = ocut, best_lane = ol;
+        }
+        if (lane == 0) {
+            const float want = all ? best_cut : top;
+            const float have = cur->lcut;
+            const bool keep = have >= want && have - want <= kCutKeep;  // false for the initial NaN
+            s_lcut = keep ? have : want;
+            s_rebuild = keep ? 0 : 1;
+            if (blockIdx.x == 0) {
+                next->lcut = keep ? have : want;
+                next->rebuild = keep ? 0 : 1;
+                next->sample_max = top;
+                next->sample_quantile = __shfl(q, 0);
+            }
+        }
+    }
+    __syncthreads();
+    if (!s_rebuild) return;
+    // this workgroup's sample: LB of every column at the cut, a bitonic sort of (LB, column) in LDS, the walk tables
+    const float lcut = s_lcut;
+    const int i = blockIdx.x;
+    for (int c = tid; c < p2; c += 1024) {
+        unsigned long long key = ~0ull;
+        if (c < dim) {
+            float t, ln_a;
+            evaluate<false>(lcut, entry_of(aos[(int64_t)c * s_pad + i]), t, ln_a);
+            key = ((unsigned long long)ordered_bits(ln_a + 0.0f) << 32) | (uint32_t)c;
+        }
+        keys[c] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= p2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < p2 / 2; t += 1024) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const unsigned long long a = keys[lo], b = keys[hi];
+                const bool up = (lo & k) == 0;
+                if ((a > b) == up) {
+                    keys[lo] = b;
+                    keys[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const int64_t base = (int64_t)(i / kWave) * dim * kWave + (i % kWave);
+    for (int k = tid; k < dim; k += 1024) {
+        const uint32_t c = (uint32_t)keys[k];
+        const float4 e = aos[(int64_t)c * s_pad + i];
+        walk_a[base + (int64_t)k * kWave] = make_float4(from_ordered_bits((uint32_t)(keys[k] >> 32)), e.x, e.y, e.z);
+        walk_c[base + (int64_t)k * kWave] = c;
+    }
+}
+
+// plan (and tables, where the standing ones do not fit) for a call's logs; returns the plan the row kernels read
+static int launch_walk_plan(mhx_wgen *gen, const float *d_v, bool logs, int64_t total, int32_t seg_len, int32_t n_seg, float per_row, WalkPlan **plan_out) {
+    mhx_ctx *ctx = gen->ctx;
+    const int32_t dim = gen->dim;
+    WalkPlan *plans = reinterpret_cast<WalkPlan *>(gen->d_walk_plan);
+    float4 *walk_a = reinterpret_cast<float4 *>(gen->d_walk_a);
+    int32_t p2 = 1;
+    while (p2 < dim) p2 <<= 1;
+    const size_t lds = sizeof(unsigned long long) * (size_t)p2 + sizeof(uint32_t) * ((size_t)1 << kHistBits);
+    if (ctx->opt_weighted_plan == 1 || lds + 8192 > (size_t)ctx->lds_per_block) {  // round 3's two launches (reference runs; dim > 8192: keys and histogram do not fit one workgroup's LDS together)
+        WalkPlan *plan = plans + gen->plan_index;
+        if (logs)
+            hipLaunchKernelGGL(walk_plan_kernel<true>, dim3(1), dim3(1024), 0, ctx->stream, d_v, total, seg_len, n_seg, per_row, (int32_t)ctx->opt_weighted_tail, plan);
+        else
+            hipLaunchKernelGGL(walk_plan_kernel<false>, dim3(1), dim3(1024), 0, ctx->stream, d_v, total, seg_len, n_seg, per_row, (int32_t)ctx->opt_weighted_tail, plan);
+        MHX_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(walk_build_kernel, dim3((unsigned)gen->sample_size), dim3(256), sizeof(unsigned long long) * (size_t)p2, ctx->stream, plan,
+                           reinterpret_cast<const float4 *>(gen->d_aos), dim, p2, gen->s_pad, walk_a, gen->d_walk_c);
+        MHX_HIP_CHECK(hipGetLastError());
+        *plan_out = plan;
+        return MHX_OK;
+    }
+    const WalkPlan *cur = plans + gen->plan_index;
+    WalkPlan *next = plans + (gen->plan_index ^ 1);
+    if (logs)
+        hipLaunchKernelGGL(walk_plan_build_kernel<true>, dim3((unsigned)gen->sample_size), dim3(1024), lds, ctx->stream, d_v, total, seg_len, n_seg, per_row,
+                           (int32_t)ctx->opt_weighted_tail, cur, next, reinterpret_cast<const float4 *>(gen->d_aos), dim, p2, gen->s_pad, walk_a, gen->d_walk_c);
+    else
+        hipLaunchKernelGGL(walk_plan_build_kernel<false>, dim3((unsigned)gen->sample_size), dim3(1024), lds, ctx->stream, d_v, total, seg_len, n_seg, per_row,
+                           (int32_t)ctx->opt_weighted_tail, cur, next, reinterpret_cast<const float4 *>(gen->d_aos), dim, p2, gen->s_pad, walk_a, gen->d_walk_c);
+    MHX_HIP_CHECK(hipGetLastError());
+    gen->plan_index ^= 1;
+    *plan_out = next;
+    return MHX_OK;
+}
+
 // what a lane holds for its sample: the smallest ln_a so far, its column (ties: the smaller one) and its t
 struct Held {
     float ln_a = __builtin_inff();
@@ -606,6 +832,11 @@ struct Held {
     uint32_t c = 0xFFFFFFFFu;
     __device__ __forceinline__ void take(float a, float tt, uint32_t col) {
         if (a < ln_a || (a == ln_a && col < c)) ln_a = a, t = tt, c = col;
+    }
+    // the same as a select (no branch): inside the walk's rounds, where a branch per position costs more than the position
+    __device__ __forceinline__ void take_if(bool ok, float a, float tt, uint32_t col) {
+        const bool better = ok && (a < ln_a || (a == ln_a && col < c));
+        ln_a = better ? a : ln_a, t = better ? tt : t, c = better ? col : c;
     }
     __device__ __forceinline__ void offer(float l, const float4 e, uint32_t col) {  // e = {r, ln_c, beta, .}
         float tt, a;
@@ -667,10 +898,13 @@ __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list,
             for (int u = 0; u < kU; ++u) e[u] = cache_a[(k + u) * kWave + lane], c[u] = cache_c[(k + u) * kWave + lane];
             done = done || e[0].x > held.ln_a;  // an equal bound may still hide a tie at a smaller column
             if (!__any(!done)) break;
-            if (!done) {
+            {
                 // e = {LB, r, ln_c, beta}; t without the division (evaluate_guarded with the hardware's reciprocal, 1 ulp:
                 // still inside the proof's margin), which is the longest dependent chain of a round; a column the row does
-                // not store (-inf: dropped below) is evaluated at 0 so that it does not count as open
+                // not store (-inf: dropped below) is evaluated at 0 so that it does not count as open.  No branch inside a
+                // round: every lane evaluates, a lane that has finished drops what it computed (round 3 had `if (!done)`
+                // around the round and around every take: ten exec-mask branches per round, 1 400 cycles for ~150
+                // instructions of arithmetic)
                 float l[kU], t[kU], a[kU];
                 bool open = false;
 #pragma unroll
@@ -679,14 +913,14 @@ __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list,
                     open |= evaluate_guarded<true>(l[u] == -__builtin_inff() ? 0.0f : l[u],
                                                    make_float4(e[u].y, e[u].z, e[u].w, __builtin_amdgcn_rcpf(e[u].y)), t[u], a[u]);
                 }
-                if (__builtin_expect(__any(open), 0)) {
+                if (__builtin_expect(__any(open && !done), 0)) {
 #pragma unroll
                     for (int u = 0; u < kU; ++u) evaluate<false>(l[u], entry_of(make_float4(e[u].y, e[u].z, e[u].w, 0.0f)), t[u], a[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < kU; ++u) {
                     done = done || e[u].x > held.ln_a;
-                    if (!done && !(l[u] == -__builtin_inff())) held.take(a[u], t[u], c[u]);
+                    held.take_if(!done && !(l[u] == -__builtin_inff()), a[u], t[u], c[u]);
                 }
             }
         }
@@ -712,7 +946,7 @@ __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list,
                 }
                 done = done || e[0].x > held.ln_a;
                 if (!__any(!done)) break;
-                if (!done) {
+                {
                     float l[kG], t[kG], a[kG];
                     bool open = false;
 #pragma unroll
@@ -721,14 +955,14 @@ __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list,
                         open |= evaluate_guarded<true>(l[u] == -__builtin_inff() ? 0.0f : l[u],
                                                        make_float4(e[u].y, e[u].z, e[u].w, __builtin_amdgcn_rcpf(e[u].y)), t[u], a[u]);
                     }
-                    if (__builtin_expect(__any(open), 0)) {
+                    if (__builtin_expect(__any(open && !done), 0)) {
 #pragma unroll
                         for (int u = 0; u < kG; ++u) evaluate<false>(l[u], entry_of(make_float4(e[u].y, e[u].z, e[u].w, 0.0f)), t[u], a[u]);
                     }
 #pragma unroll
                     for (int u = 0; u < kG; ++u) {
                         done = done || e[u].x > held.ln_a;  // (a position past the end repeats the last one: taken twice, the same)
-                        if (!done && !(l[u] == -__builtin_inff())) held.take(a[u], t[u], c[u]);
+                        held.take_if(!done && !(l[u] == -__builtin_inff()), a[u], t[u], c[u]);
                     }
                 }
 #pragma unroll
@@ -737,6 +971,163 @@ __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list,
         }
     }
     return held;
+}
+
+// walk_row for NC chunks of samples of ONE row at a time, as one instruction stream: the walk is a chain of dependent
+// LDS round trips and divisions (4 700 cycles per chunk for ~400 instructions), and a wave that owns a row has the row's
+// other chunk to fill the gaps with.  Same rules, same results: every lane's evaluations are computed whether the lane
+// still walks or not (a finished lane's are dropped), so a finished lane can at most cause the exact re-evaluation of a
+// round, never a different value.  The chunks ch0 .. ch0 + NC - 1 all have their first positions cached (cache_a /
+// cache_c: chunk ch0's, the others' behind it).
+template <int NC>
+__device__ __forceinline__ void walk_chunks(const float *row, const uint16_t *list, int n_list, bool all_listed, int32_t dim, int32_t ch0,
+                                            int lane, int32_t sample_size, const float4 *__restrict__ walk_a,
+                                            const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos, int32_t s_pad,
+                                            const float4 *cache_a, const uint32_t *cache_c, Held (&held)[NC]) {
+    int32_t my[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) my[i] = (ch0 + i) * kWave + lane;
+    int j = 0;
+    for (; j + 4 <= n_list; j += 4) {  // the listed columns: the row's entry is the same for every chunk
+        uint32_t c[4];
+        float l[4];
+        float4 e[NC][4];
+        float t[NC][4], a[NC][4];
+        bool open = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            c[u] = list[j + u];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) e[i][u] = aos[(int64_t)c[u] * s_pad + my[i]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            l[u] = row[c[u]];
+#pragma unroll
+            for (int i = 0; i < NC; ++i) open |= evaluate_guarded<true>(l[u], e[i][u], t[i][u], a[i][u]);
+        }
+        if (__builtin_expect(__any(open), 0)) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < NC; ++i) evaluate<false>(l[u], entry_of(e[i][u]), t[i][u], a[i][u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int i = 0; i < NC; ++i) held[i].take(a[i][u], t[i][u], c[u]);
+    }
+    for (; j < n_list; ++j) {
+        const uint32_t c = list[j];
+        const float l = row[c];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) held[i].offer(l, aos[(int64_t)c * s_pad + my[i]], c);
+    }
+    if (all_listed) return;
+    bool done[NC];
+#pragma unroll
+    for (int i = 0; i < NC; ++i) done[i] = my[i] >= sample_size;
+    const auto walking = [&]() {
+        bool w = false;
+#pragma unroll
+        for (int i = 0; i < NC; ++i) w |= !done[i];
+        return __any(w);
+    };
+    constexpr int kU = 4;
+    const int32_t n_cached = (dim < kWalkCached ? dim : kWalkCached) / kU * kU;
+    int32_t k = 0;
+    for (; k < n_cached; k += kU) {
+        float4 e[NC][kU];
+        uint32_t c[NC][kU];
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                e[i][u] = cache_a[(i * kWalkCached + k + u) * kWave + lane];
+                c[i][u] = cache_c[(i * kWalkCached + k + u) * kWave + lane];
+            }
+#pragma unroll
+        for (int i = 0; i < NC; ++i) done[i] = done[i] || e[i][0].x > held[i].ln_a;  // an equal bound may still hide a tie at a smaller column
+        if (!walking()) break;
+        float l[NC][kU], t[NC][kU], a[NC][kU];
+        bool open = false;
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                l[i][u] = row[c[i][u]];
+                open |= evaluate_guarded<true>(l[i][u] == -__builtin_inff() ? 0.0f : l[i][u],
+                                               make_float4(e[i][u].y, e[i][u].z, e[i][u].w, __builtin_amdgcn_rcpf(e[i][u].y)), t[i][u], a[i][u]);
+            }
+        if (__builtin_expect(__any(open), 0)) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+#pragma unroll
+                for (int u = 0; u < kU; ++u) evaluate<false>(l[i][u], entry_of(make_float4(e[i][u].y, e[i][u].z, e[i][u].w, 0.0f)), t[i][u], a[i][u]);
+        }
+#pragma unroll
+        for (int i = 0; i < NC; ++i)
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                done[i] = done[i] || e[i][u].x > held[i].ln_a;
+                held[i].take_if(!done[i] && !(l[i][u] == -__builtin_inff()), a[i][u], t[i][u], c[i][u]);
+            }
+    }
+    if (k == n_cached && k < dim && walking()) {  // beyond the cached positions: rounds of two from registers, the next round's entries on their way
+        constexpr int kG = 2;
+        const float4 *wa[NC];
+        const uint32_t *wc[NC];
+        float4 e[NC][kG];
+        uint32_t c[NC][kG];
+#pragma unroll
+        for (int i = 0; i < NC; ++i) {
+            wa[i] = walk_a + (int64_t)(ch0 + i) * dim * kWave + lane;
+            wc[i] = walk_c + (int64_t)(ch0 + i) * dim * kWave + lane;
+#pragma unroll
+            for (int u = 0; u < kG; ++u) {
+                const int32_t at = k + u < dim ? k + u : dim - 1;
+                e[i][u] = wa[i][(int64_t)at * kWave], c[i][u] = wc[i][(int64_t)at * kWave];
+            }
+        }
+        for (; k < dim; k += kG) {
+            float4 e_next[NC][kG];
+            uint32_t c_next[NC][kG];
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+#pragma unroll
+                for (int u = 0; u < kG; ++u) {
+                    const int32_t at = k + kG + u < dim ? k + kG + u : dim - 1;
+                    e_next[i][u] = wa[i][(int64_t)at * kWave], c_next[i][u] = wc[i][(int64_t)at * kWave];
+                }
+#pragma unroll
+            for (int i = 0; i < NC; ++i) done[i] = done[i] || e[i][0].x > held[i].ln_a;
+            if (!walking()) break;
+            float l[NC][kG], t[NC][kG], a[NC][kG];
+            bool open = false;
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+#pragma unroll
+                for (int u = 0; u < kG; ++u) {
+                    l[i][u] = row[c[i][u]];
+                    open |= evaluate_guarded<true>(l[i][u] == -__builtin_inff() ? 0.0f : l[i][u],
+                                                   make_float4(e[i][u].y, e[i][u].z, e[i][u].w, __builtin_amdgcn_rcpf(e[i][u].y)), t[i][u], a[i][u]);
+                }
+            if (__builtin_expect(__any(open), 0)) {
+#pragma unroll
+                for (int i = 0; i < NC; ++i)
+#pragma unroll
+                    for (int u = 0; u < kG; ++u) evaluate<false>(l[i][u], entry_of(make_float4(e[i][u].y, e[i][u].z, e[i][u].w, 0.0f)), t[i][u], a[i][u]);
+            }
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+#pragma unroll
+                for (int u = 0; u < kG; ++u) {
+                    done[i] = done[i] || e[i][u].x > held[i].ln_a;  // (a position past the end repeats the last one: taken twice, the same)
+                    held[i].take_if(!done[i] && !(l[i][u] == -__builtin_inff()), a[i][u], t[i][u], c[i][u]);
+                    e[i][u] = e_next[i][u], c[i][u] = c_next[i][u];
+                }
+        }
+    }
 }
 
 // the results of the waves that shared a chunk, through LDS: part p >= 1 of chunk ch writes slot (p - 1) * chunks + ch
@@ -952,7 +1343,7 @@ __global__ __launch_bounds__(256, 4) void weighted_walk_dense_kernel(const float
 // and the row's stream (16 x 1-KB loads per row and wave) overlaps with the walks of the seven other waves.
 // Same arithmetic, same rules, same helper (walk_row) as the kernel above; rows it does not take (dim > 4096 or not a
 // multiple of 4, fewer than two stripes fitting the LDS) stay with that kernel.
-template <bool LOGS, int NV>  // NV: 16-byte loads per lane that hold a row (dim <= 256 NV)
+template <bool LOGS, int NV, bool PAIRS>  // NV: 16-byte loads per lane that hold a row (dim <= 256 NV); PAIRS: two chunks of samples walked as one instruction stream
 __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__restrict__ x, int64_t n_rows, int32_t dim,
                                                                  const WalkPlan *__restrict__ plan, const float4 *__restrict__ walk_a,
                                                                  const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos,
@@ -988,45 +1379,58 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
         }
     };
     const auto one_row = [&](float4 (&pre)[NV], int64_t d) {
-        // stage + scan: the row's logs into the stripe (-inf: not stored), its stored entries counted, NaNs and entries
-        // above the cut noted in a bit mask per lane (bit 4 u + e: column (64 u + lane) 4 + e)
-        int cnt = 0;
-        bool nan = false;
-        unsigned long long above = 0;
+        // stage + scan: the row's logs into the stripe (-inf: not stored).  What the scan looks for is rare, so it is kept
+        // on the scalar unit: a lane's "seen one" flags are lane masks in scalar registers, OR-ed per element (s_or_b64; 128
+        // explicit ballots instead made the compiler keep every mask alive: 440 spilled SGPRs), and only a row that has an
+        // entry above the cut, a NaN or an absent entry is looked at again, from LDS.
+        bool lane_above = false, lane_odd = false;
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int c = (u * kWave + lane) * 4;
-            if (c < dim) {
-                const float v[4] = {pre[u].x, pre[u].y, pre[u].z, pre[u].w};
-                float l[4];
+            const bool in = c < dim;  // (a lane behind the row's end holds a clamped copy of its last entries: computed, not kept)
+            float l[4] = {pre[u].x, pre[u].y, pre[u].z, pre[u].w};
+            if (!LOGS) {
+                const bool plain = np_logf_is_normal(l[0]) && np_logf_is_normal(l[1]) && np_logf_is_normal(l[2]) && np_logf_is_normal(l[3]);
+                if (__builtin_expect(__all(plain), 1)) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float lg = LOGS ? v[e] : np_logf(v[e]);
-                    const bool stored = LOGS ? !(lg == -__builtin_inff()) : (v[e] != 0.0f);  // scipy's nonzero(): NaN stays
-                    cnt += stored;
-                    nan |= lg != lg;
-                    above |= (unsigned long long)(lg > lcut) << (4 * u + e);  // +inf too
-                    l[e] = stored ? lg : -__builtin_inff();
+                    for (int e = 0; e < 4; ++e) l[e] = np_logf_normal(l[e]);
+                } else {  // zeros (absent entries: log = -inf), denormals, negatives, NaNs
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) l[e] = np_logf(l[e]);
                 }
-                *reinterpret_cast<float4 *>(row + c) = make_float4(l[0], l[1], l[2], l[3]);
             }
-        }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-        const int n_stored = cnt;
-        const bool has_nan = __any(nan);
-        int n_out = 0;
-        while (true) {  // (wave-uniform) the columns above the cut: every lane hands in its lowest one per turn
-            const bool has = above != 0;
-            const unsigned long long mask = __ballot(has);
-            if (!mask) break;
-            if (has) {
-                const int b = __builtin_ctzll(above);
-                above &= above - 1;
-                const int at = n_out + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                if (at < list_cap) list[at] = (uint16_t)(((b >> 2) * kWave + lane) * 4 + (b & 3));
+            for (int e = 0; e < 4; ++e) {
+                lane_above |= in && l[e] > lcut;
+                lane_odd |= in && __builtin_amdgcn_class(l[e], 0x007);
             }
-            n_out += __popcll(mask);
+            if (in) *reinterpret_cast<float4 *>(row + c) = make_float4(l[0], l[1], l[2], l[3]);
+        }
+        const bool any_above = __any(lane_above), any_odd = __any(lane_odd);
+        int n_stored = dim, n_out = 0;
+        bool has_nan = false;
+        if (any_odd) {  // (wave-uniform) count what is stored, look for NaNs
+            n_stored = 0;
+            unsigned long long nan_lanes = 0;
+            for (int c0 = 0; c0 < dim; c0 += kWave) {
+                const int c = c0 + lane;
+                const float l = c < dim ? row[c] : -__builtin_inff();
+                n_stored += __popcll(__ballot(!(l == -__builtin_inff())));
+                nan_lanes |= __ballot(l != l);
+            }
+            has_nan = nan_lanes != 0;
+        }
+        if (any_above) {  // (wave-uniform) list the columns above the cut
+            for (int c0 = 0; c0 < dim; c0 += kWave) {
+                const int c = c0 + lane;
+                const bool is_above = c < dim && row[c] > lcut;
+                const unsigned long long mask = __ballot(is_above);
+                if (is_above) {
+                    const int at = n_out + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                    if (at < list_cap) list[at] = (uint16_t)c;
+                }
+                n_out += __popcll(mask);
+            }
         }
         int n_list = n_out;
         // as in the workgroup-per-row kernel: few stored entries, or more above the cut than the list holds -> entry by entry
@@ -1043,7 +1447,24 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
             }
             n_list = n_stored;
         }
+        const bool walked = n_stored > 0 && !has_nan && !(by_entry && !listable);
         for (int32_t ch = 0; ch < chunks; ++ch) {
+            if (PAIRS && walked && ch + 1 < n_cc) {  // (wave-uniform) two chunks of samples as one instruction stream
+                Held held[2];
+                walk_chunks<2>(row, list, n_list, by_entry, dim, ch, lane, sample_size, walk_a, walk_c, aos, s_pad,
+                               s_cache_a + ch * kWalkCached * kWave, s_cache_c + ch * kWalkCached * kWave, held);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int32_t my = (ch + i) * kWave + lane;
+                    if (my < sample_size) {
+                        int64_t *o = out + (d * sample_size + my) * 2;
+                        o[0] = held[i].c;
+                        o[1] = (int64_t)held[i].t;
+                    }
+                }
+                ++ch;
+                continue;
+            }
             const int32_t my = ch * kWave + lane;
             int64_t k_out = 0, t_out = 0;
             if (n_stored == 0) {
@@ -1324,20 +1745,11 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
                                       uint8_t *d_nonempty) {
     mhx_ctx *ctx = gen->ctx;
     const int32_t dim = gen->dim;
-    WalkPlan *plan = reinterpret_cast<WalkPlan *>(gen->d_walk_plan);
     const int64_t total = n_rows * (int64_t)dim;
     const int32_t n_seg = (int32_t)std::min<int64_t>(n_rows, std::max<int64_t>(1, (16 << 10) / dim));  // about 16k sampled logs
-    if (values_are_logs)
-        hipLaunchKernelGGL(walk_plan_kernel<true>, dim3(1), dim3(1024), 0, ctx->stream, d_x, total, dim, n_seg, (float)dim, (int32_t)ctx->opt_weighted_tail, plan);
-    else
-        hipLaunchKernelGGL(walk_plan_kernel<false>, dim3(1), dim3(1024), 0, ctx->stream, d_x, total, dim, n_seg, (float)dim, (int32_t)ctx->opt_weighted_tail, plan);
-    MHX_HIP_CHECK(hipGetLastError());
-    int32_t p2 = 1;
-    while (p2 < dim) p2 <<= 1;
+    WalkPlan *plan = nullptr;
+    if (int rc = launch_walk_plan(gen, d_x, values_are_logs != 0, total, dim, n_seg, (float)dim, &plan)) return rc;
     float4 *walk_a = reinterpret_cast<float4 *>(gen->d_walk_a);
-    hipLaunchKernelGGL(walk_build_kernel, dim3((unsigned)gen->sample_size), dim3(256), sizeof(unsigned long long) * (size_t)p2, ctx->stream, plan,
-                       reinterpret_cast<const float4 *>(gen->d_aos), dim, p2, gen->s_pad, walk_a, gen->d_walk_c);
-    MHX_HIP_CHECK(hipGetLastError());
     const int32_t list_cap = std::max(64, dim / 4);
     const int32_t direct_permille_w = ctx->opt_weighted_direct > 0 ? (int32_t)ctx->opt_weighted_direct : 100;
     // one wave per row (weighted_walk_wave_kernel) when a row is 4 .. 16 sixteen-byte loads per lane and at least four
@@ -1356,19 +1768,25 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
             const int64_t per_cu = ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu : std::max<int64_t>(1, (int64_t)ctx->lds_per_block / (int64_t)(lds + 64));
             const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, per_cu * ctx->num_cus));
             const int nv = dim <= 1024 ? 4 : dim <= 2048 ? 8 : 16;
-#define MHX_WALK_WAVE(LOGS, NV_)                                                                                                          \
-    hipLaunchKernelGGL((weighted_walk_wave_kernel<LOGS, NV_>), dim3(blocks), dim3(64 * waves), lds, ctx->stream, d_x, n_rows, dim, plan, walk_a, \
+#define MHX_WALK_WAVE(LOGS, NV_, PAIRS_)                                                                                                  \
+    hipLaunchKernelGGL((weighted_walk_wave_kernel<LOGS, NV_, PAIRS_>), dim3(blocks), dim3(64 * waves), lds, ctx->stream, d_x, n_rows, dim, plan, walk_a, \
                        gen->d_walk_c, reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, list_cap_w, direct_permille_w,  \
                        (int32_t)(stripe_bytes / 4), d_out, d_nonempty)
+#define MHX_WALK_WAVE_NV(LOGS, PAIRS_)            \
+    do {                                          \
+        if (nv == 4) MHX_WALK_WAVE(LOGS, 4, PAIRS_);      \
+        else if (nv == 8) MHX_WALK_WAVE(LOGS, 8, PAIRS_); \
+        else MHX_WALK_WAVE(LOGS, 16, PAIRS_);             \
+    } while (0)
+            const bool pairs = ctx->opt_weighted_kernel != 2;  // two chunks of samples as one stream (0.424 -> 0.405 ms on config 4); 2 = chunk after chunk
             if (values_are_logs) {
-                if (nv == 4) MHX_WALK_WAVE(true, 4);
-                else if (nv == 8) MHX_WALK_WAVE(true, 8);
-                else MHX_WALK_WAVE(true, 16);
+                if (pairs) MHX_WALK_WAVE_NV(true, true);
+                else MHX_WALK_WAVE_NV(true, false);
             } else {
-                if (nv == 4) MHX_WALK_WAVE(false, 4);
-                else if (nv == 8) MHX_WALK_WAVE(false, 8);
-                else MHX_WALK_WAVE(false, 16);
+                if (pairs) MHX_WALK_WAVE_NV(false, true);
+                else MHX_WALK_WAVE_NV(false, false);
             }
+#undef MHX_WALK_WAVE_NV
 #undef MHX_WALK_WAVE
             MHX_HIP_CHECK(hipGetLastError());
             return MHX_OK;
@@ -1435,7 +1853,10 @@ int launch_weighted_dense(mhx_wgen *gen, const float *d_x, int values_are_logs, 
 // the log of the device-log mode on its own (tests and the bench's tolerance gate look at it)
 __global__ __launch_bounds__(256) void weighted_log_kernel(const float *__restrict__ x, int64_t n, float *__restrict__ out) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = np_logf(x[i]);
+    {
+        const float v = x[i];
+        out[i] = np_logf_is_normal(v) ? np_logf_normal(v) : np_logf(v);  // (both paths are what the row kernels take: the 2^32-pattern test runs through here)
+    }
 }
 
 int launch_weighted_log(mhx_ctx *ctx, const float *d_x, int64_t n, float *d_out) {
@@ -1459,19 +1880,14 @@ static int launch_weighted_csr_walk(mhx_wgen *gen, const int64_t *d_indptr, cons
         d_logs = (const float *)ctx->scratch[3];
     }
     const int32_t direct_permille = ctx->opt_weighted_direct > 0 ? (int32_t)ctx->opt_weighted_direct : 100;
-    WalkPlan *plan = reinterpret_cast<WalkPlan *>(gen->d_walk_plan);
+    WalkPlan *plan = reinterpret_cast<WalkPlan *>(gen->d_walk_plan) + gen->plan_index;
     float4 *walk_a = reinterpret_cast<float4 *>(gen->d_walk_a);
     const bool any_walk = nnz * 1000 > (int64_t)direct_permille * dim;  // some row may be long enough
     if (any_walk) {
         const int32_t seg = (int32_t)std::min<int64_t>(nnz, 1024);
-        hipLaunchKernelGGL(walk_plan_kernel<true>, dim3(1), dim3(1024), 0, ctx->stream, d_logs, nnz, seg, (int32_t)std::min<int64_t>(16, nnz / seg),
-                           (float)std::min<double>((double)dim, (double)nnz / (double)std::max<int64_t>(n_rows, 1)), (int32_t)ctx->opt_weighted_tail, plan);
-        MHX_HIP_CHECK(hipGetLastError());
-        int32_t p2 = 1;
-        while (p2 < dim) p2 <<= 1;
-        hipLaunchKernelGGL(walk_build_kernel, dim3((unsigned)gen->sample_size), dim3(256), sizeof(unsigned long long) * (size_t)p2, ctx->stream, plan,
-                           reinterpret_cast<const float4 *>(gen->d_aos), dim, p2, gen->s_pad, walk_a, gen->d_walk_c);
-        MHX_HIP_CHECK(hipGetLastError());
+        if (int rc = launch_walk_plan(gen, d_logs, true, nnz, seg, (int32_t)std::min<int64_t>(16, nnz / seg),
+                                      (float)std::min<double>((double)dim, (double)nnz / (double)std::max<int64_t>(n_rows, 1)), &plan))
+            return rc;
     }
     const int64_t chunks = gen->s_pad / kWave;
     const int64_t want = (n_rows + 3) / 4;

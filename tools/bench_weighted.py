@@ -79,6 +79,7 @@ def main():
         ctx.set_option("weighted.split", int(opts.get("split", 0)))
         ctx.set_option("weighted.tail", int(opts.get("tail", 0)))
         ctx.set_option("weighted.kernel", int(opts.get("kernel", 0)))
+        ctx.set_option("weighted.plan", int(opts.get("plan", 0)))
 
         def call():
             if args.csr:
@@ -123,6 +124,7 @@ def main():
     ctx.set_option("weighted.direct", 0)
     ctx.set_option("weighted.debug", 0)
     ctx.set_option("weighted.kernel", 0)
+    ctx.set_option("weighted.plan", 0)
 
 
 if __name__ == "__main__":
