@@ -988,32 +988,33 @@ __device__ __forceinline__ void walk_chunks(const float *row, const uint16_t *li
 #pragma unroll
     for (int i = 0; i < NC; ++i) my[i] = (ch0 + i) * kWave + lane;
     int j = 0;
-    for (; j + 4 <= n_list; j += 4) {  // the listed columns: the row's entry is the same for every chunk
-        uint32_t c[4];
-        float l[4];
-        float4 e[NC][4];
-        float t[NC][4], a[NC][4];
+    constexpr int kL = 4;  // listed columns per turn: their table entries are one trip to the L2 together (8: no faster, 40 more VGPRs)
+    for (; j + kL <= n_list; j += kL) {  // the listed columns: the row's entry is the same for every chunk
+        uint32_t c[kL];
+        float l[kL];
+        float4 e[NC][kL];
+        float t[NC][kL], a[NC][kL];
         bool open = false;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kL; ++u) {
             c[u] = list[j + u];
 #pragma unroll
             for (int i = 0; i < NC; ++i) e[i][u] = aos[(int64_t)c[u] * s_pad + my[i]];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kL; ++u) {
             l[u] = row[c[u]];
 #pragma unroll
             for (int i = 0; i < NC; ++i) open |= evaluate_guarded<true>(l[u], e[i][u], t[i][u], a[i][u]);
         }
         if (__builtin_expect(__any(open), 0)) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < kL; ++u)
 #pragma unroll
                 for (int i = 0; i < NC; ++i) evaluate<false>(l[u], entry_of(e[i][u]), t[i][u], a[i][u]);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < kL; ++u)
 #pragma unroll
             for (int i = 0; i < NC; ++i) held[i].take(a[i][u], t[i][u], c[u]);
     }
@@ -1073,7 +1074,7 @@ __device__ __forceinline__ void walk_chunks(const float *row, const uint16_t *li
                 held[i].take_if(!done[i] && !(l[i][u] == -__builtin_inff()), a[i][u], t[i][u], c[i][u]);
             }
     }
-    if (k == n_cached && k < dim && walking()) {  // beyond the cached positions: rounds of two from registers, the next round's entries on their way
+    if (k == n_cached && k < dim && walking()) {  // beyond the cached positions: rounds of two from registers (four: no faster on heavy-tailed rows, whose walks wait for the slowest of 128 lanes), the next round's entries on their way
         constexpr int kG = 2;
         const float4 *wa[NC];
         const uint32_t *wc[NC];
