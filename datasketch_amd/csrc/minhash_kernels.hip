@@ -1497,6 +1497,10 @@ int launch_p(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_t to
     if (args.num_perm <= 64) return launch_typed<1, TokT, OutT>(ctx, args, first_token, total_tokens, split);
     const int slots4 = (args.num_perm + 255) / 256 * 256, slots2 = (args.num_perm + 127) / 128 * 128;  // lanes x P x passes
     // (uint64 tokens only: with uint32 tokens -- a row per chunk, two rows per loop body -- four permutations need 207 VGPRs)
+    // 129 .. 192 permutations: three per lane, one pass with every lane busy up to 192 (four per lane left a quarter of the
+    // lanes idle there: K = 150 ran 0.59 of them); option minhash.p3 = 1 switches it off (A/B)
+    if (args.num_perm > 128 && args.num_perm <= 192 && !split && ctx->opt_minhash_p3 != 1)  // (uint32 tokens too: 121 VGPRs, where four per lane need 207)
+        return launch_typed<3, TokT, OutT, 2>(ctx, args, first_token, total_tokens, split);
     if (args.num_perm > 128 && !split && slots4 <= slots2 && sizeof(TokT) == 8)
         return launch_typed<4, TokT, OutT, 2>(ctx, args, first_token, total_tokens, split);
     return launch_typed<2, TokT, OutT>(ctx, args, first_token, total_tokens, split);

@@ -202,3 +202,33 @@ def test_device_log_equals_numpy_log_for_every_float32(ctx):
             want = np.log(x).view(np.uint32)
             bad += int(np.count_nonzero(got != want))
     assert bad == 0
+
+
+@pytest.mark.parametrize("k", list(range(129, 257, 7)) + [192, 193, 255, 256])
+def test_num_perm_sweep_129_to_256(ctx, k):
+    """Every shape class of 129 <= num_perm <= 256 (ref: datasketch/minhash.py:113-132 allows any num_perm): three
+    permutations per lane up to 192 (round 4), four beyond; dense rows of whole 16-token rows, dense rows with a tail, ragged
+    sets with empty ones and 64-bit tokens, uint32 tokens, an initial state -- against the C oracle, and the three-per-lane
+    launch against the four-per-lane one."""
+    from oracle import oracle as O2
+
+    rng = np.random.RandomState(k)
+    a, b = O2.np_init_permutations(k, 11)
+    for n, t in ((1500, 256), (700, 100)):
+        tok = rng.randint(0, 2**32, size=(n, t), dtype=np.uint64)
+        want = O2.c_minhash_bulk_dense(tok, a, b)
+        assert np.array_equal(ctx.minhash_bulk((a, b), tok.reshape(-1), None, t, n), want)
+        assert np.array_equal(ctx.minhash_bulk((a, b), tok.reshape(-1).astype(np.uint32), None, t, n, out_dtype=np.uint32), want.astype(np.uint32))
+        if k <= 192:
+            ctx.set_option("minhash.p3", 1)
+            try:
+                assert np.array_equal(ctx.minhash_bulk((a, b), tok.reshape(-1), None, t, n), want)
+            finally:
+                ctx.set_option("minhash.p3", 0)
+    lens = rng.randint(0, 90, size=900)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    hv = rng.randint(0, 2**32, size=int(off[-1]), dtype=np.uint64)
+    hv[rng.randint(0, hv.size, size=hv.size // 10)] += np.uint64(2**45)
+    hv[5:9] = hv[4]  # repeated tokens: the dedup launch
+    init = rng.randint(0, 2**32, size=(900, k), dtype=np.uint64)
+    assert np.array_equal(ctx.minhash_bulk((a, b), hv, off, 0, 900, init=init), O2.c_minhash_bulk(hv, off, a, b, init=init))
