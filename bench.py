@@ -439,23 +439,32 @@ def _cpu_worker(args):
     return time.perf_counter() - t0, int(sig[:, 0].sum())
 
 
-def _usable_cores(cap=64):
+def _usable_cores(cap=64, why=None):
     """Cores this process may really use: affinity mask, clipped by the cgroup CPU quota (a container
-    can see 256 CPUs and own 8) and by `cap` (start-up of hundreds of interpreters is not the point)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    can see 256 CPUs and own 8) and by `cap` (start-up of hundreds of interpreters is not the point).
+    `why` (a dict) receives where the number came from, for the bench line."""
+    seen = os.cpu_count() or 1
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else seen
+    if why is not None:
+        why.update({"os_cpu_count": seen, "sched_getaffinity": n, "cgroup_quota_cpus": None, "cap": cap})
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
         try:
             with open(path) as f:
                 parts = f.read().split()
             if path.endswith("cpu.max"):
                 if parts[0] != "max":
-                    n = min(n, max(1, int(int(parts[0]) / int(parts[1]))))
+                    q = max(1, int(int(parts[0]) / int(parts[1])))
+                    n = min(n, q)
+                    if why is not None:
+                        why["cgroup_quota_cpus"] = q
             else:
                 quota = int(parts[0])
                 with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
                     period = int(f.read())
                 if quota > 0:
                     n = min(n, max(1, quota // period))
+                    if why is not None:
+                        why["cgroup_quota_cpus"] = max(1, quota // period)
             break
         except (OSError, ValueError, IndexError):
             continue
@@ -503,7 +512,8 @@ def cpu_baseline(tokens, a, b, sample, k, t, gpu_rows, seed=1):
     m = 0 if gpu_rows is None else min(single, len(gpu_rows))
     if m and not np.array_equal(got[:m], gpu_rows[:m]):
         raise SystemExit("PARITY FAILURE: GPU signatures differ from the oracle on the cpu_baseline sample")
-    cores = _usable_cores()
+    cores_why = {}
+    cores = _usable_cores(why=cores_why)
     per = max(2_000, sample // 8)  # sets per process: 1.5-3 s of numpy each, 41 MB of tokens
     out = {
         "value": single / dt,
@@ -521,6 +531,7 @@ def cpu_baseline(tokens, a, b, sample, k, t, gpu_rows, seed=1):
         out.update({
             "value": cores * per / busy,
             "cores": cores,
+            "cores_source": dict(cores_why, used=cores, rule="min(affinity mask, cgroup CPU quota, cap)"),
             "sample": f"{cores} processes x {per} sets of the same shape ({t} tokens, num_perm={k}), numpy per-set loop as "
                       f"MinHash.bulk; slowest process {busy:.1f} s (pool wall {wall:.1f} s incl. start-up)",
         })
@@ -611,6 +622,11 @@ def extra_configs(ctx, tokens, d_tok, seed, only):
         finally:
             ctx.set_option("lsh.sort", 0)
         ms_sort = _timed(ctx, sort)
+        # config 3 as a chain computes the digests once: the bucketing takes the [n, bands] digest matrix that was just written
+        sort_dig = lambda: _native.check(lib.mhx_lsh_sort_digests_dev(ctx.handle, d_dig.ptr, n3, bands, d_sd.ptr, d_sr.ptr))
+        ms_sort_dig = _timed(ctx, sort_dig)
+        sd_dig, sr_dig = d_sd.download((bands, n3), np.uint64), d_sr.download((bands, n3), np.uint32)
+        ms_sort = _timed(ctx, sort)  # (d_sd / d_sr hold the sort-from-signatures result again for the checks below)
         # parity: signature rows against the C oracle, digests against FNV-1a of the reference's key bytes, order of the sort
         rows, tok = sample_rows()
         a3, b3 = p3
@@ -631,7 +647,9 @@ def extra_configs(ctx, tokens, d_tok, seed, only):
                 raise SystemExit("PARITY FAILURE (extra.c3): sorted bands are not the digests in ascending order")
         if not (np.array_equal(sd, sd_radix) and np.array_equal(sr, sr_radix)):
             raise SystemExit("PARITY FAILURE (extra.c3): the bucketing passes and the stable radix sort disagree")
-        del sig, dig, sd, sr, sd_radix, sr_radix
+        if not (np.array_equal(sd, sd_dig) and np.array_equal(sr, sr_dig)):
+            raise SystemExit("PARITY FAILURE (extra.c3): bucketing from the digest matrix differs from bucketing from the signatures")
+        del sig, dig, sd, sr, sd_radix, sr_radix, sd_dig, sr_dig
         res["c3"] = {
             "workload": f"config 3 per-GPU shard: {n3} sets x {t} tokens, num_perm={k3} (uint64 tokens in, uint32 signatures out = the all-gather's wire format), then LSH band digests ({bands} bands x {r}) and the bucketing sort",
             "signatures": dict(_roof(n3 * (8 * t + 4 * k3), ms_sig), signatures_per_s=n3 / (ms_sig * 1e-3),
@@ -644,8 +662,13 @@ def extra_configs(ctx, tokens, d_tok, seed, only):
             "lsh_sort_bands_radix": dict(_roof(n3 * (4 * k3 + 12 * bands), ms_sort_radix), keys_per_s=n3 * bands / (ms_sort_radix * 1e-3),
                                          note="lsh.sort=1: digests + the library radix sort of (band, digest prefix, row) + exact clean-up (round 2's path, "
                                               "now the fallback), same call, same box"),
-            "pipeline_ms": ms_sig + ms_sort,
-            "parity": f"{len(rows)} signature rows vs the C oracle, 64 x {bands} digests vs FNV-1a-64 of the reference's key bytes, 2 bands' order, all {bands} sorted bands equal to the stable radix sort's",
+            "lsh_sort_digests": dict(_roof(n3 * (8 * bands + 12 * bands), ms_sort_dig), keys_per_s=n3 * bands / (ms_sort_dig * 1e-3),
+                                     note="mhx_lsh_sort_digests_dev: the same two passes on the [n, bands] digest matrix band_digests has just written "
+                                          "(8 B read per key, no hashing); bytes = digests in, (digest, row) out"),
+            "pipeline_ms": ms_sig + ms_dig + ms_sort_dig,
+            "pipeline": "signatures -> band_digests (kept: the index's keys) -> lsh_sort_digests; digests computed once",
+            "pipeline_ms_digests_twice": ms_sig + ms_dig + ms_sort,
+            "parity": f"{len(rows)} signature rows vs the C oracle, 64 x {bands} digests vs FNV-1a-64 of the reference's key bytes, 2 bands' order, all {bands} sorted bands equal to the stable radix sort's and to the sort from the digest matrix",
         }
         for d in (d_dig, d_sd, d_sr):
             d.free()

@@ -83,6 +83,7 @@ _PROTOTYPES = {
     "mhx_band_digests": [_vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp],
     "mhx_lsh_sort_bands_dev": [_vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
     "mhx_lsh_sort_bands": [_vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _vp],
+    "mhx_lsh_sort_digests_dev": [_vp, _vp, _i64, ctypes.c_int32, _vp, _vp],
     "mhx_lsh_candidate_pairs_dev": [_vp, _vp, _vp, _i64, ctypes.c_int32, _vp, _i64, ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
     "mhx_lsh_candidate_pairs": [_vp, _vp, _i64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, _vp, _i64,
                                 ctypes.POINTER(_i64), ctypes.POINTER(_i64)],

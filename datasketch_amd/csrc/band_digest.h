@@ -3,6 +3,7 @@
 #pragma once
 
 #include <cstdint>
+#include <type_traits>
 
 #include <hip/hip_runtime.h>
 
@@ -11,8 +12,17 @@ namespace mhx {
 // FNV-1a-64 of the band key of band `band` of row `row`: exactly the bytes the reference uses as that band's dictionary
 // key (ref: datasketch/lsh.py:199,344,537-538: the r hashvalues of the band, each as 8 big-endian bytes) -- what
 // MinHashLSH(hashfunc=fnv1a_64) would store (ref: lsh.py:540-543).
+// a "signature matrix" that already holds the digests ([n, bands]: what band_digest_kernel wrote): the LSH sort then reads 8
+// bytes per (row, band) instead of hashing r values again (config 3 computes the digests once)
+struct Digest64 {
+    uint64_t v;
+};
+
 template <typename SigT>
 __device__ __forceinline__ uint64_t band_digest_of(const SigT *__restrict__ sig, int64_t row, int band, int32_t k, int32_t r) {
+    if constexpr (std::is_same<SigT, Digest64>::value) {
+        return sig[row * k + band].v;  // (k = bands here)
+    } else {
     constexpr uint64_t kPrime = 0x100000001b3ull;
     constexpr uint64_t kPrime4 = kPrime * kPrime * kPrime * kPrime;  // four zero bytes: h ^= 0 leaves h, so h *= prime^4
     const SigT *src = sig + row * k + (int64_t)band * r;
@@ -61,6 +71,7 @@ __device__ __forceinline__ uint64_t band_digest_of(const SigT *__restrict__ sig,
         for (int c = 0; c < r; ++c) absorb((uint64_t)src[c]);
     }
     return h;
+    }
 }
 
 }  // namespace mhx

@@ -558,7 +558,7 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     // bands whose r values of a row share a 128-byte line go to one workgroup (at most four) -- as far as the teams'
     // staging areas fit the LDS of a workgroup (4096 bins x 4 teams would be 272 KB: ADVICE r3); not even one team
     // fitting, a slab that cannot be had, a launch that is refused: the radix sort below handles every size
-    const int piece = r * (sig_dtype == MHX_U32 ? 4 : 8);
+    const int piece = r * (sig_dtype == MHX_U32 ? 4 : 8);  // (digests: r = 1, 8 bytes)
     int band_share = piece < 128 && 128 % piece == 0 ? std::min(4, 128 / piece) : 1;
     while (bands % band_share) band_share >>= 1;
     const size_t team_bytes = 8 * (size_t)(256 * kScatterRows) + 8 * ((3 * (size_t)nb * 4 + 256 * kScatterRows * 2 + 16 + 7) / 8);
@@ -575,7 +575,10 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     const size_t lds1 = team_bytes * band_share;
     const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(32 / (4 * band_share), (int64_t)((160 << 10) / (lds1 + 64))));
     const unsigned grid1 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, (int64_t)ctx->num_cus * per_cu * 2));
-    if (sig_dtype == MHX_U32)
+    if (sig_dtype == kSigDigests)
+        hipLaunchKernelGGL(lsh_bin_scatter_kernel<Digest64>, dim3(grid1), dim3(256 * band_share), lds1, ctx->stream, (const Digest64 *)d_sig, k, r, n, bands,
+                           bin_bits, band_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
+    else if (sig_dtype == MHX_U32)
         hipLaunchKernelGGL(lsh_bin_scatter_kernel<uint32_t>, dim3(grid1), dim3(256 * band_share), lds1, ctx->stream, (const uint32_t *)d_sig, k, r, n, bands,
                            bin_bits, band_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
     else
@@ -633,7 +636,10 @@ int launch_lsh_sort_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_
     const bool luggage = n <= ((int64_t)1 << (32 - band_bits)) && ctx->opt_lsh_gather != 1;  // the row and band_bits digest bits fit the 32-bit value
     if (luggage) {
         // the digest region receives the sorted values, d_sorted_rows the final rows
-        if (sig_dtype == MHX_U32)
+        if (sig_dtype == kSigDigests)
+            hipLaunchKernelGGL(band_keys_with_luggage_kernel<Digest64>, dim3(grid_for(ctx, total)), dim3(256), 0, ctx->stream, (const Digest64 *)d_sig, k, r, n,
+                               bands, band_bits, sort_bits, d_keys, d_rows);
+        else if (sig_dtype == MHX_U32)
             hipLaunchKernelGGL(band_keys_with_luggage_kernel<uint32_t>, dim3(grid_for(ctx, total) ), dim3(256), 0, ctx->stream, (const uint32_t *)d_sig, k, r, n,
                                bands, band_bits, sort_bits, d_keys, d_rows);
         else
@@ -647,13 +653,15 @@ int launch_lsh_sort_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_
         hipLaunchKernelGGL(unpack_luggage_kernel, grid, dim3(256), 0, ctx->stream, d_keys_sorted, d_vals_sorted, total, band_bits, sort_bits,
                            d_keys_sorted, d_sorted_digests, d_sorted_rows);
     } else {
-        if (int rc = launch_band_digests(ctx, d_sig, sig_dtype, n, k, bands, r, d_dig)) return rc;
-        hipLaunchKernelGGL(band_keys_for_sort_kernel, grid, dim3(256), 0, ctx->stream, d_dig, n, bands, band_bits, sort_bits, d_keys, d_rows);
+        const uint64_t *d_dig_in = d_dig;
+        if (sig_dtype == kSigDigests) d_dig_in = static_cast<const uint64_t *>(d_sig);  // they are there already
+        else if (int rc = launch_band_digests(ctx, d_sig, sig_dtype, n, k, bands, r, d_dig)) return rc;
+        hipLaunchKernelGGL(band_keys_for_sort_kernel, grid, dim3(256), 0, ctx->stream, d_dig_in, n, bands, band_bits, sort_bits, d_keys, d_rows);
         MHX_HIP_CHECK(hipGetLastError());
         e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, (const uint64_t *)d_keys, d_keys_sorted, (const uint32_t *)d_rows,
                                       d_sorted_rows, (size_t)total, 0, sort_bits, ctx->stream);
         if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(gather_digests_kernel, grid, dim3(256), 0, ctx->stream, d_dig, d_sorted_rows, n, bands, total,
+        hipLaunchKernelGGL(gather_digests_kernel, grid, dim3(256), 0, ctx->stream, d_dig_in, d_sorted_rows, n, bands, total,
                            d_sorted_digests);
     }
     MHX_HIP_CHECK(hipMemsetAsync(d_mixed, 0, (size_t)total, ctx->stream));

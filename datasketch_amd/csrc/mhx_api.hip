@@ -1152,6 +1152,17 @@ int mhx_band_digests(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, in
     return fetch_out(ctx, out, out_bytes);
 }
 
+int mhx_lsh_sort_digests_dev(mhx_ctx *ctx, const uint64_t *d_digests, int64_t n, int32_t bands, uint64_t *d_sorted_digests,
+                             uint32_t *d_sorted_rows) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    MHX_REQUIRE(n >= 0 && bands > 0, "bad shape");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(d_digests && d_sorted_digests && d_sorted_rows, "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_lsh_sort_bands(ctx, d_digests, mhx::kSigDigests, n, bands, bands, 1, d_sorted_digests, d_sorted_rows);
+}
+
 int mhx_lsh_sort_bands_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
                            uint64_t *d_sorted_digests, uint32_t *d_sorted_rows) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");

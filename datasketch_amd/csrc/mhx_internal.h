@@ -29,6 +29,9 @@ int fail(int code, const char *fmt, ...);
         }                                                                                        \
     } while (0)
 
+// internal "signature type" of launch_lsh_sort_bands: the matrix holds band digests already ([n, bands] uint64)
+constexpr int kSigDigests = 2;
+
 // mhx_ctx::d_work: 16 counter words, then the list of sets the second MinHash launch leaves to the pairwise one
 constexpr unsigned int kPairListCap = 16384;
 constexpr size_t kWorkBytes = 64 + sizeof(unsigned int) * kPairListCap;

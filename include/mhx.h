@@ -318,6 +318,10 @@ MHX_API int mhx_lsh_sort_bands_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t 
                                    uint32_t *d_sorted_rows);
 MHX_API int mhx_lsh_sort_bands(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs, int32_t num_perm,
                                int32_t bands, int32_t r, uint64_t *sorted_digests, uint32_t *sorted_rows);
+/* The same from digests that are already there: d_digests [n_sigs, bands] as mhx_band_digests* wrote them (a caller that
+ * keeps the digest matrix -- config 3 stores it as the index's keys -- does not pay for hashing the bands twice). */
+MHX_API int mhx_lsh_sort_digests_dev(mhx_ctx *ctx, const uint64_t *d_digests, int64_t n_sigs, int32_t bands,
+                                     uint64_t *d_sorted_digests, uint32_t *d_sorted_rows);
 /* Candidate pairs: every pair of rows i < j that share the digest of at least one band -- the rows
  * MinHashLSH.query (ref: datasketch/lsh.py:370-400) would return for each other -- from the output of
  * mhx_lsh_sort_bands.  pairs: int64[capacity, 2], ascending by (i, j), unique.  *n_pairs receives the

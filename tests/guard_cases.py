@@ -237,6 +237,9 @@ def pack_and_lsh_cases(ctx):
                     check(lib.mhx_lsh_sort_bands_dev_typed(ctx.handle, _p(d_sig), code, n, k, bands, r, _p(d_sd), _p(d_sr)))
                     assert np.array_equal(d_sr.download((bands, n), np.uint32), order.astype(np.uint32)), ("sort", n, k, bands, r, dt, sort_opt)
                     assert np.array_equal(d_sd.download((bands, n), np.uint64), np.take_along_axis(dig.T, order, axis=1))
+                    check(lib.mhx_lsh_sort_digests_dev(ctx.handle, _p(d_dig), n, bands, _p(d_sd), _p(d_sr)))  # the same from the digest matrix
+                    assert np.array_equal(d_sr.download((bands, n), np.uint32), order.astype(np.uint32)), ("sort digests", n, k, bands, r, sort_opt)
+                    assert np.array_equal(d_sd.download((bands, n), np.uint64), np.take_along_axis(dig.T, order, axis=1))
                 ctx.set_option("lsh.sort", 0)
                 want_pairs, _ = ctx.lsh_candidate_pairs(sig, bands, r)
                 cap = max(1, len(want_pairs))

@@ -232,3 +232,25 @@ def test_num_perm_sweep_129_to_256(ctx, k):
     hv[5:9] = hv[4]  # repeated tokens: the dedup launch
     init = rng.randint(0, 2**32, size=(900, k), dtype=np.uint64)
     assert np.array_equal(ctx.minhash_bulk((a, b), hv, off, 0, 900, init=init), O2.c_minhash_bulk(hv, off, a, b, init=init))
+
+
+@pytest.mark.parametrize("n,bands", [(1, 1), (5, 3), (3000, 32), (70000, 16), (300000, 4), (20000, 128)])
+def test_bands_bucketed_from_the_digest_matrix(ctx, n, bands):
+    """mhx_lsh_sort_digests_dev (config 3 computes its band digests once, ref: datasketch/lsh.py:326-347,537-543): the order
+    is the sort from the signatures' -- (band, digest, row) -- on both sort paths, with shared buckets."""
+    rng = np.random.RandomState(n + bands)
+    r = 4
+    sig = rng.randint(0, 2**32, size=(n, bands * r), dtype=np.uint64)
+    if n > 10:
+        sig[n // 2 : n // 2 + n // 10] = sig[: n // 10]
+    dig = ctx.band_digests(sig, bands, r)
+    want_d, want_r = ctx.lsh_sort_bands(sig, bands, r)
+    d_dig, d_sd, d_sr = ctx.to_device(dig), ctx.alloc(8 * bands * n), ctx.alloc(4 * bands * n)
+    for opt in (0, 1):
+        ctx.set_option("lsh.sort", opt)
+        try:
+            _native.check(ctx.lib.mhx_lsh_sort_digests_dev(ctx.handle, d_dig.ptr, n, bands, d_sd.ptr, d_sr.ptr))
+            got_d, got_r = d_sd.download((bands, n), np.uint64), d_sr.download((bands, n), np.uint32)
+        finally:
+            ctx.set_option("lsh.sort", 0)
+        assert np.array_equal(got_d, want_d) and np.array_equal(got_r, want_r), opt
