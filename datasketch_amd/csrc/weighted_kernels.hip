@@ -973,6 +973,64 @@ __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list,
     return held;
 }
 
+// The tail of a walk, by the whole wave.  The lanes of a wave walk in lock step, so a round costs the same whether one
+// lane still walks or all of them, and heavy-tailed rows leave a handful of lanes walking dozens of positions after the
+// others have stopped (lognormal weights, sigma 2: the slowest of 128 lanes goes ~90 positions, the mean ~10).  When few
+// lanes are left, each of them in turn gets all 64 lanes: lane j evaluates position k + j of THAT sample's list (one trip to
+// the L2 for 64 positions instead of one per two), an inclusive prefix minimum gives every position the value the
+// sequential walk would hold on reaching it, the first position whose bound exceeds that is where the walk stops, and the
+// smallest (ln_a, column) in front of it -- np.argmin's choice, ties to the smaller column -- is its result.  Same
+// evaluations (IEEE division here), same stop rule, same answer as position by position.
+__device__ __forceinline__ void walk_rescue(const float *row, int32_t dim, int32_t ch, int ls, int32_t k, const float4 *__restrict__ walk_a,
+                                            const uint32_t *__restrict__ walk_c, int lane, Held &held) {
+    const auto lane_value = [](float v, int from) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), from)); };  // (the builtin is int -> int)
+    float best_a = lane_value(held.ln_a, ls), best_t = lane_value(held.t, ls);
+    uint32_t best_c = (uint32_t)__builtin_amdgcn_readlane((int)held.c, ls);
+    const float4 *wa = walk_a + (int64_t)ch * dim * kWave + ls;
+    const uint32_t *wc = walk_c + (int64_t)ch * dim * kWave + ls;
+    for (; k < dim; k += kWave) {
+        const int32_t p = k + lane;
+        const bool in = p < dim;
+        const int32_t pc = in ? p : dim - 1;
+        const float4 e = wa[(int64_t)pc * kWave];  // {LB, r, ln_c, beta}
+        const uint32_t col = wc[(int64_t)pc * kWave];
+        const float l = row[col];
+        float t, a;
+        evaluate<false>(l == -__builtin_inff() ? 0.0f : l, entry_of(make_float4(e.y, e.z, e.w, 0.0f)), t, a);
+        const bool valid = in && !(l == -__builtin_inff()) && a == a;
+        const float am = valid ? a + 0.0f : __builtin_inff();
+        float pm = am;  // inclusive prefix minimum over the lanes
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const float up = __shfl_up(pm, o);
+            if (lane >= o) pm = fminf(pm, up);
+        }
+        float before = __shfl_up(pm, 1);  // what the sequential walk holds when it reaches this position
+        before = lane == 0 ? best_a : fminf(before, best_a);
+        const unsigned long long stops = __ballot(!in || e.x > before);
+        const int first = stops ? __builtin_ctzll(stops) : kWave;
+        const bool cand = valid && lane < first;
+        unsigned long long key = cand ? (((unsigned long long)ordered_bits(am) << 32) | col) : ~0ull;
+        unsigned long long best_key = key;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = ((unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)(best_key >> 32), o) << 32) |
+                                             (uint32_t)__shfl_xor((int)(uint32_t)best_key, o);
+            best_key = other < best_key ? other : best_key;
+        }
+        if (best_key != ~0ull) {  // (wave-uniform)
+            const float wa_ = from_ordered_bits((uint32_t)(best_key >> 32));
+            const uint32_t wc_ = (uint32_t)best_key;
+            if (wa_ < best_a || (wa_ == best_a && wc_ < best_c)) {
+                const int owner = __builtin_ctzll(__ballot(key == best_key));
+                best_a = wa_, best_c = wc_, best_t = lane_value(t, owner);
+            }
+        }
+        if (first < kWave) break;
+    }
+    if (lane == ls) held.ln_a = best_a, held.t = best_t, held.c = best_c;
+}
+
 // walk_row for NC chunks of samples of ONE row at a time, as one instruction stream: the walk is a chain of dependent
 // LDS round trips and divisions (4 700 cycles per chunk for ~400 instructions), and a wave that owns a row has the row's
 // other chunk to fill the gaps with.  Same rules, same results: every lane's evaluations are computed whether the lane
@@ -983,7 +1041,7 @@ template <int NC>
 __device__ __forceinline__ void walk_chunks(const float *row, const uint16_t *list, int n_list, bool all_listed, int32_t dim, int32_t ch0,
                                             int lane, int32_t sample_size, const float4 *__restrict__ walk_a,
                                             const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos, int32_t s_pad,
-                                            const float4 *cache_a, const uint32_t *cache_c, Held (&held)[NC]) {
+                                            const float4 *cache_a, const uint32_t *cache_c, int32_t rescue_lanes, Held (&held)[NC]) {
     int32_t my[NC];
 #pragma unroll
     for (int i = 0; i < NC; ++i) my[i] = (ch0 + i) * kWave + lane;
@@ -1103,6 +1161,24 @@ __device__ __forceinline__ void walk_chunks(const float *row, const uint16_t *li
 #pragma unroll
             for (int i = 0; i < NC; ++i) done[i] = done[i] || e[i][0].x > held[i].ln_a;
             if (!walking()) break;
+            if (rescue_lanes > 0 && k >= n_cached + 2 * kG) {  // few lanes left after two rounds out here: each of them in turn gets the whole wave (walk_rescue; a tail of a round or two is cheaper in lock step: uniform weights)
+                unsigned long long act[NC];
+                int n_act = 0;
+#pragma unroll
+                for (int i = 0; i < NC; ++i) act[i] = __ballot(!done[i]), n_act += __popcll(act[i]);
+                if (n_act <= rescue_lanes) {
+#pragma unroll
+                    for (int i = 0; i < NC; ++i) {
+                        while (act[i]) {
+                            const int ls = __builtin_ctzll(act[i]);
+                            act[i] &= act[i] - 1;
+                            walk_rescue(row, dim, ch0 + i, ls, k, walk_a, walk_c, lane, held[i]);
+                        }
+                        done[i] = true;
+                    }
+                    break;
+                }
+            }
             float l[NC][kG], t[NC][kG], a[NC][kG];
             bool open = false;
 #pragma unroll
@@ -1349,7 +1425,8 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
                                                                  const WalkPlan *__restrict__ plan, const float4 *__restrict__ walk_a,
                                                                  const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos,
                                                                  int32_t sample_size, int32_t s_pad, int32_t list_cap, int32_t direct_permille,
-                                                                 int32_t stripe_words, int64_t *__restrict__ out, uint8_t *__restrict__ nonempty) {
+                                                                 int32_t stripe_words, int32_t rescue_lanes, int64_t *__restrict__ out,
+                                                                 uint8_t *__restrict__ nonempty) {
     extern __shared__ float lds[];  // cached list positions of the first n_cc chunks | per wave: row[dim] | list[list_cap] u16
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), n_waves = blockDim.x >> 6;
@@ -1453,7 +1530,7 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
             if (PAIRS && walked && ch + 1 < n_cc) {  // (wave-uniform) two chunks of samples as one instruction stream
                 Held held[2];
                 walk_chunks<2>(row, list, n_list, by_entry, dim, ch, lane, sample_size, walk_a, walk_c, aos, s_pad,
-                               s_cache_a + ch * kWalkCached * kWave, s_cache_c + ch * kWalkCached * kWave, held);
+                               s_cache_a + ch * kWalkCached * kWave, s_cache_c + ch * kWalkCached * kWave, rescue_lanes, held);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int32_t my = (ch + i) * kWave + lane;
@@ -1772,13 +1849,14 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
 #define MHX_WALK_WAVE(LOGS, NV_, PAIRS_)                                                                                                  \
     hipLaunchKernelGGL((weighted_walk_wave_kernel<LOGS, NV_, PAIRS_>), dim3(blocks), dim3(64 * waves), lds, ctx->stream, d_x, n_rows, dim, plan, walk_a, \
                        gen->d_walk_c, reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, list_cap_w, direct_permille_w,  \
-                       (int32_t)(stripe_bytes / 4), d_out, d_nonempty)
+                       (int32_t)(stripe_bytes / 4), rescue_lanes, d_out, d_nonempty)
 #define MHX_WALK_WAVE_NV(LOGS, PAIRS_)            \
     do {                                          \
         if (nv == 4) MHX_WALK_WAVE(LOGS, 4, PAIRS_);      \
         else if (nv == 8) MHX_WALK_WAVE(LOGS, 8, PAIRS_); \
         else MHX_WALK_WAVE(LOGS, 16, PAIRS_);             \
     } while (0)
+            const int32_t rescue_lanes = ctx->opt_weighted_rescue < 0 ? 0 : ctx->opt_weighted_rescue > 0 ? (int32_t)ctx->opt_weighted_rescue : 4;
             const bool pairs = ctx->opt_weighted_kernel != 2;  // two chunks of samples as one stream (0.424 -> 0.405 ms on config 4); 2 = chunk after chunk
             if (values_are_logs) {
                 if (pairs) MHX_WALK_WAVE_NV(true, true);

@@ -254,3 +254,38 @@ def test_bands_bucketed_from_the_digest_matrix(ctx, n, bands):
         finally:
             ctx.set_option("lsh.sort", 0)
         assert np.array_equal(got_d, want_d) and np.array_equal(got_r, want_r), opt
+
+
+@pytest.mark.parametrize("kind", ["lognormal2", "pareto", "uniform", "sparse_lognormal"])
+def test_a_walks_last_lanes_taken_by_the_whole_wave(ctx, kind):
+    """walk_rescue (round 4): when few lanes of a wave still walk, each of them gets all 64 lanes -- 64 list positions per
+    turn, a prefix minimum for the stop rule, np.argmin's tie rule for the winner.  Same (k, t) whatever the threshold
+    (never, 1 lane, the default, every lane from the third round on), against the C oracle
+    (ref: datasketch/weighted_minhash.py:216-229)."""
+    rng = np.random.RandomState(zlib.crc32(kind.encode()))
+    n, dim, s = 5000, 2048, 128
+    if kind == "lognormal2":
+        x = rng.lognormal(0, 2.0, (n, dim))
+    elif kind == "pareto":
+        x = rng.pareto(1.2, (n, dim)) + 1e-3
+    elif kind == "uniform":
+        x = rng.uniform(0, 100, (n, dim))
+    else:
+        x = rng.lognormal(0, 2.5, (n, dim))
+        x[rng.random_sample(x.shape) < 0.7] = 0
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    x[:, 7] = x[:, 9]  # equal logs in two columns: ties are decided by the column
+    g = WeightedMinHashGenerator(dim, s, seed=5, gpu_mode="always")
+    rows = np.arange(0, n, 7)
+    want, wn = _oracle_rows(g, sp.csr_matrix(x), rows)
+    wctx, _ = g._device_handle()
+    outs = []
+    for lanes in (-1, 1, 0, 64):
+        wctx.set_option("weighted.rescue", lanes)
+        try:
+            out, ne = g.minhash_many_arrays(x)
+        finally:
+            wctx.set_option("weighted.rescue", 0)
+        assert ne.all() and wn.all() and np.array_equal(out[rows], want), lanes
+        outs.append(out)
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])

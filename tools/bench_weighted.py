@@ -80,6 +80,7 @@ def main():
         ctx.set_option("weighted.tail", int(opts.get("tail", 0)))
         ctx.set_option("weighted.kernel", int(opts.get("kernel", 0)))
         ctx.set_option("weighted.plan", int(opts.get("plan", 0)))
+        ctx.set_option("weighted.rescue", int(opts.get("rescue", 0)))
 
         def call():
             if args.csr:
@@ -125,6 +126,7 @@ def main():
     ctx.set_option("weighted.debug", 0)
     ctx.set_option("weighted.kernel", 0)
     ctx.set_option("weighted.plan", 0)
+    ctx.set_option("weighted.rescue", 0)
 
 
 if __name__ == "__main__":
