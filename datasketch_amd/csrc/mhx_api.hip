@@ -244,6 +244,7 @@ int mhx_ctx::ensure_work() {
         d_work = nullptr;
         return fail(MHX_ERR_OOM, "work counter allocation failed: %s", hipGetErrorString(e));
     }
+    MHX_HIP_CHECK(hipMemset(d_work, 0, mhx::kWorkBytes));  // (word 8, what the last call learned about the corpus, lives across calls)
     return MHX_OK;
 }
 
@@ -354,6 +355,7 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "minhash.packed")) ctx->opt_minhash_packed = value;
     else if (!strcmp(key, "minhash.ties")) ctx->opt_minhash_ties = value;
     else if (!strcmp(key, "minhash.p3")) ctx->opt_minhash_p3 = value;
+    else if (!strcmp(key, "minhash.adapt")) ctx->opt_minhash_adapt = value;
     else if (!strcmp(key, "blocks_per_cu")) ctx->opt_blocks_per_cu = value;
     else if (!strcmp(key, "minhash.alias")) ctx->opt_minhash_alias = value;
     else if (!strcmp(key, "minhash.prefetch")) ctx->opt_minhash_prefetch = value;

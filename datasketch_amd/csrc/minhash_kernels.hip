@@ -50,6 +50,8 @@ struct BulkArgs {
                                 // == 2 <=> the dedup launch left it to the pairwise (full) launch
     int32_t redo_match;         // the flag value this launch works on (MODE_DEDUP: 1, MODE_FULL after it: 2)
     unsigned int *sieve_hint;   // sieve launch: [0] sets tried, [1] proofs failed so far in this launch (zeroed before it)
+    unsigned int *mode_word;    // what the previous call on this context learned about the corpus: 1 = most sets defeat the
+                                // one-candidate proof (repeated tokens), so the first launch is the tie-tolerant one (MODE_SIEVE_TIES)
     unsigned int *pair_count;   // flagged launches: [0] sets the dedup launch left to the pairwise one; the first kPairListCap of
     unsigned int *pair_list;    // them are listed here (set numbers), so that the pairwise launch need not scan the flags for a handful
     int32_t prefetch;        // warm the next set's tokens with a vector load (option minhash.prefetch)
@@ -419,7 +421,7 @@ __device__ __forceinline__ bool finish_block(const Two (&rows)[P], const uint32_
 // to the dedup pass.  (Keys near 2^32 are refused so that the 2^32-1 a fold starts from never looks like a tie.)
 template <int P, int STRIDE, int WPT>
 __device__ __forceinline__ bool finish_block_ties(const Three (&rows)[P], const uint32_t *tile, const Perms<P> &pm,
-                                                  const SievePerms<P> &sp, uint32_t (&res)[P]) {
+                                                  const SievePerms<P> &sp, uint32_t (&res)[P], bool *tied = nullptr) {
     bool fail = false;
 #pragma unroll
     for (int q = 0; q < P; ++q) {
@@ -454,6 +456,7 @@ __device__ __forceinline__ bool finish_block_ties(const Three (&rows)[P], const 
             }
         }
         fail |= sp.active[q] && !ok;
+        if (tied) *tied |= sp.active[q] && (row_tie || col_tie);  // the one-candidate proof would have failed here
         uint32_t l0, h0, l1, h1;
         mad_wide((uint32_t)t1, (uint32_t)(t1 >> 32), pm.a_lo[q], pm.a_hi[q], pm.b[q], l0, h0);
         mad_wide((uint32_t)t2, (uint32_t)(t2 >> 32), pm.a_lo[q], pm.a_hi[q], pm.b[q], l1, h1);
@@ -469,7 +472,7 @@ __device__ __forceinline__ bool finish_block_ties(const Three (&rows)[P], const 
 template <int P, typename TokT, bool TIES = false>
 __device__ __forceinline__ bool sieve_range(const TokT MHX_CONST_AS *hv, const TokT *hv_vec, int64_t beg,
                                             int nrows, const Perms<P> &pm, const SievePerms<P> &sp,
-                                            uint32_t *lds, int lane, uint32_t (&res)[P], int &nblocks) {
+                                            uint32_t *lds, int lane, uint32_t (&res)[P], int &nblocks, bool *tied = nullptr) {
     constexpr int N = Chunk<TokT>::N;
     constexpr int CPR = kRowTokens / N;  // chunks per row: 2 (uint64 tokens) or 1 (uint32)
     constexpr int STRIDE = StageLayout<TokT>::kStride, WPT = StageLayout<TokT>::kWordsPerTok;
@@ -541,7 +544,7 @@ __device__ __forceinline__ bool sieve_range(const TokT MHX_CONST_AS *hv, const T
             if (WPT == 2) dst[1] = st1;
         }
         if constexpr (TIES)
-            fail |= finish_block_ties<P, STRIDE, WPT>(rows, lds, pm, sp, res);
+            fail |= finish_block_ties<P, STRIDE, WPT>(rows, lds, pm, sp, res, tied);
         else
             fail |= finish_block<P, STRIDE, WPT>(rows, lds, pm, sp, res);
         ++nblocks;
@@ -754,7 +757,7 @@ template <int P, typename TokT, bool TAIL = true, bool TIES = false>
 __device__ __forceinline__ bool sieve_minima(const TokT MHX_CONST_AS *hv, const TokT *hv_vec, int64_t beg,
                                              int64_t end, const Perms<P> &pm, const Perms<P> &pm_biased,
                                              const SievePerms<P> &sp, unsigned long long *stats, int lane,
-                                             uint32_t *lds, uint32_t (&res)[P]) {
+                                             uint32_t *lds, uint32_t (&res)[P], bool *tied = nullptr) {
     const int64_t n = end - beg;
     const int nrows = (int)min(n / kRowTokens, (int64_t)(1 << 27));
 #pragma unroll
@@ -762,7 +765,7 @@ __device__ __forceinline__ bool sieve_minima(const TokT MHX_CONST_AS *hv, const 
     bool bad = false;
     if (nrows > 0) {
         int nblocks = 0;
-        bad = sieve_range<P, TokT, TIES>(hv, hv_vec, beg, nrows, pm, sp, lds, lane, res, nblocks);
+        bad = sieve_range<P, TokT, TIES>(hv, hv_vec, beg, nrows, pm, sp, lds, lane, res, nblocks, tied);
         if (stats && lane == 0) atomicAdd(stats + 2, (unsigned long long)nblocks);
     }
     const int64_t tail = beg + (int64_t)nrows * kRowTokens;
@@ -881,7 +884,13 @@ __device__ __forceinline__ void load_perms(const BulkArgs &args, int kbase, int 
 //               over what is left) and NOTHING else -- a set it cannot settle either is re-flagged for MODE_FULL.  Without
 //               the pair-by-pair code this launch needs far fewer registers than MODE_FULL, and a corpus full of
 //               repeated tokens is settled here at close to the sieve's own rate.
-enum { MODE_SIEVE = 0, MODE_FULL = 1, MODE_DEDUP = 2 };
+//   MODE_SIEVE_TIES  (round 4) MODE_SIEVE with the proof that tolerates one tie (finish_block_ties), as a kernel of its own:
+//               on a corpus whose sets repeat tokens 97 % of the sets fail the one-candidate proof, the sieve launch is
+//               wasted on them and the tie-tolerant proof then runs in the second launch at its occupancy and with its flag
+//               scan.  Both first launches are always enqueued; which one works is decided ON THE DEVICE from what the
+//               previous call on the context learned (BulkArgs::mode_word, written by the last launch of every call): the
+//               other returns at once (~10 us).  No host read-back, nothing added to the hot kernel's per-set code.
+enum { MODE_SIEVE = 0, MODE_FULL = 1, MODE_DEDUP = 2, MODE_SIEVE_TIES = 3 };
 enum { SHAPE_GENERAL = 0, SHAPE_PLAIN = 1, SHAPE_PLAIN_FIXED = 2, SHAPE_PLAIN_FIXED_ROWS = 3 };
 
 template <int P, typename TokT, typename OutT, int MODE, int SHAPE>
@@ -891,6 +900,27 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
     // not compiled in at all.  The fields become compile-time constants, so their SGPRs and address arithmetic
     // leave the per-set path (spilled SGPRs 49 -> 32 -> 4, VGPRs 78 -> 73 -> 53): 3 % of the headline launch.
     BulkArgs args = args_in;
+    constexpr bool kSieve = MODE == MODE_SIEVE || MODE == MODE_SIEVE_TIES;
+    if (kSieve && args.mode_word) {  // (wave-uniform) the first launch that the corpus calls for works, the other one leaves
+        const unsigned int want_ties = *as_const(args.mode_word);
+        if ((want_ties == 1u) != (MODE == MODE_SIEVE_TIES)) return;
+    }
+    if (MODE == MODE_FULL && args.mode_word && args.sieve_hint && blockIdx.x == 0 && threadIdx.x == 0) {
+        // the last launch of the call: what the first launch saw decides the next call's first launch (a quarter of the
+        // sets defeating the one-candidate proof is where the tie-tolerant one, 1.18x the instructions, starts to pay)
+        // 0: the one-candidate proof first; 1: the tie-tolerant proof first; 2: the one-candidate proof first because even the
+        // tie-tolerant one left a fifth of the sets to the dedup pass last time it ran first (10 % repeated tokens: 2.16 ms per
+        // 500k sets that way round against 2.0) -- until the corpus changes
+        const unsigned int t = __builtin_nontemporal_load(args.sieve_hint), f = __builtin_nontemporal_load(args.sieve_hint + 1);
+        const unsigned int g = __builtin_nontemporal_load(args.sieve_hint + 2), m = *args.mode_word;
+        // (what the second launch saw when IT tried the tie-tolerant proof, words 3 and 5: tried / left to its dedup pass)
+        const unsigned int tt = __builtin_nontemporal_load(args.sieve_hint + 3), tf = __builtin_nontemporal_load(args.sieve_hint + 5);
+        if (t >= 64u) {
+            const bool defeated = 4u * f > t;
+            const bool heavy = m == 1u ? 5u * g > t : (tt >= 64u ? 5u * tf > tt : m == 2u);
+            *args.mode_word = !defeated ? 0u : heavy ? 2u : 1u;
+        }
+    }
     if (SHAPE != SHAPE_GENERAL) {
         args.init = nullptr;
         args.init_stride = 0;
@@ -909,7 +939,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
     Perms<P> pm, pm_biased;
     SievePerms<P> sp;
     int kidx[P];
-    if (MODE == MODE_SIEVE || MODE == MODE_DEDUP) load_perms<P>(args, 0, lane, pm, pm_biased, sp, kidx);
+    if (kSieve || MODE == MODE_DEDUP) load_perms<P>(args, 0, lane, pm, pm_biased, sp, kidx);
 
     const TokT MHX_CONST_AS *hv = as_const(static_cast<const TokT *>(args.hv));
     const TokT *hv_vec = static_cast<const TokT *>(args.hv);
@@ -919,7 +949,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
     // MODE_FULL after a sieve launch walks the flags 64 sets at a time: one byte load per lane, a
     // ballot, then the flagged sets one by one (a flag array, not an appended list: hundreds of
     // thousands of atomics on one counter serialise -- measured 8 ms for 500k failed sets)
-    const bool flagged_only = MODE != MODE_SIEVE && args.redo != nullptr;
+    const bool flagged_only = !kSieve && args.redo != nullptr;
     // (the four waves of a workgroup share one group of 64 flags and take every fourth flagged set of it:
     // one wave per 64 sets left 2.5 rounds of 64-set waves when everything was flagged)
     // the pairwise launch takes its sets from the list when all of them fit in it (no flag scan: 41 -> ~15 us per step
@@ -933,8 +963,8 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
     const int64_t n_items = listed ? (int64_t)listed_n : flagged_only ? (args.n_sets + kWave - 1) / kWave * waves_per_block : args.n_sets;
     SieveBackoff backoff;
     TiesBackoff ties;
-    int tried = 0, failed = 0;  // MODE_SIEVE: this wave's contribution to args.sieve_hint
-    if (MODE == MODE_SIEVE && args.sieve_hint) {
+    int tried = 0, failed = 0, left = 0;  // the first launch: this wave's contribution to args.sieve_hint (left: MODE_SIEVE_TIES, sets it could not settle)
+    if (MODE == MODE_SIEVE && args.sieve_hint) {  // (the tie-tolerant first launch never skips: what it cannot settle is rare)
         // a launch over a corpus whose sets defeat the sieve (repeated tokens) should not find that out wave by wave
         // (a wave sees only a handful of sets): waves publish their counts when they leave, and a wave that starts
         // after most proofs have failed begins in the skipping state
@@ -1040,17 +1070,27 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
         }
         for (int kc = 0; kc < kchunks && !defer; ++kc) {
             uint32_t res[P];
-            if (MODE == MODE_SIEVE) {
+            if (kSieve) {
                 if (kchunks > 1) load_perms<P>(args, kc * (kWave * P), lane, pm, pm_biased, sp, kidx);
                 if (end > beg) {
-                    defer = sieve_minima<P, TokT, SHAPE != SHAPE_PLAIN_FIXED_ROWS>(hv, hv_vec, beg, end, pm, pm_biased, sp, args.stats, lane, lds, res);
+                    bool tied = false;
+                    defer = sieve_minima<P, TokT, SHAPE != SHAPE_PLAIN_FIXED_ROWS, MODE == MODE_SIEVE_TIES>(hv, hv_vec, beg, end, pm, pm_biased, sp, args.stats, lane, lds, res,
+                                                                                                          MODE == MODE_SIEVE_TIES ? &tied : nullptr);
                     if (kc == 0) ++tried;
-                    if (defer) {
-                        ++failed;
-                        backoff.failed();
-                        break;
+                    if (MODE == MODE_SIEVE_TIES) {  // "failed" = the one-candidate proof would have: the corpus still calls for this kernel
+                        if (defer || __any(tied)) ++failed;
+                        if (defer) {
+                            ++left;
+                            break;
+                        }
+                    } else {
+                        if (defer) {
+                            ++failed;
+                            backoff.failed();
+                            break;
+                        }
+                        backoff.succeeded();
                     }
-                    backoff.succeeded();
                 }
             } else {
 #pragma unroll
@@ -1065,11 +1105,12 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
                         if (kchunks > 1) load_perms<P>(args, kc * (kWave * P), lane, pm, pm_biased, sp, kidx);
                         // the sieve again with the proof that tolerates one tie (a token occurring twice, two close keys)
                         bool open = true;
-                        if (!args.ties) {
+                        if (!args.ties || (args.mode_word && *as_const(args.mode_word) == 1u)) {  // (the tie-tolerant proof has been tried: by the first launch)
                         } else if (ties.skip > 0) {
                             if (kc == kchunks - 1) --ties.skip;
                         } else {
                             open = sieve_minima<P, TokT, true, true>(hv, hv_vec, beg, end, pm, pm_biased, sp, nullptr, lane, lds, res);
+                            if (kc == 0) ++tried, failed += open ? 1 : 0;
                             if (open) ties.failed(); else ties.succeeded();
                         }
                         if (open) {
@@ -1110,7 +1151,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
                 out[set * args.num_perm + kidx[p]] = (OutT)v;
             }
         }
-        if (MODE == MODE_SIEVE && lane == 0) {
+        if (kSieve && lane == 0) {
             args.redo[set] = defer ? 1 : 0;
             if (defer && args.stats) atomicAdd(args.stats, 1ull);
         }
@@ -1125,9 +1166,14 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
       }
     }
     // (a sample of the waves publishes: atomics of all 65 536 waves on one word would serialise for over a millisecond)
-    if (MODE == MODE_SIEVE && args.sieve_hint && lane == 0 && wave == 0 && (blockIdx.x & 15u) == 0 && tried > 0) {
+    if (kSieve && args.sieve_hint && lane == 0 && wave == 0 && (blockIdx.x & 15u) == 0 && tried > 0) {
         atomicAdd(args.sieve_hint, (unsigned int)tried);
         if (failed) atomicAdd(args.sieve_hint + 1, (unsigned int)failed);
+        if (left) atomicAdd(args.sieve_hint + 2, (unsigned int)left);
+    }
+    if (MODE == MODE_DEDUP && args.sieve_hint && args.mode_word && lane == 0 && tried > 0) {
+        atomicAdd(args.sieve_hint + 3, (unsigned int)tried);
+        if (failed) atomicAdd(args.sieve_hint + 5, (unsigned int)failed);
     }
 }
 
@@ -1413,6 +1459,9 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_
             MHX_HIP_CHECK(hipMemsetAsync(ctx->d_work, 0, 8 * sizeof(unsigned int), ctx->stream));
             BulkArgs sieve_args = args;
             sieve_args.sieve_hint = ctx->d_work;
+            // (word 8 of d_work: not zeroed per call; minhash.adapt = 1 switches the device-side choice off; the packed kernels
+            // of short signatures and counting runs -- whose counters are pinned by tests -- keep the one first launch)
+            sieve_args.mode_word = ctx->opt_minhash_adapt == 1 || args.stats ? nullptr : ctx->d_work + 8;
             const BulkArgs &args_s = sieve_args;
             const bool plain = !args.init && !args.stats && args.alias_mask < 0;
             // short signatures: several sets per wave (kernel C) instead of a wave with most of its lanes idle
@@ -1437,8 +1486,9 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_
                 else if (np <= 96) MHX_PACKED(32, 3);
                 else MHX_PACKED(64, 2);
 #undef MHX_PACKED
-            } else
-            if (plain && !args.offsets && args.fixed_len % kRowTokens == 0)  // whole 16-token rows: no tail code in the kernel
+            } else {
+            const bool fixed_rows = plain && !args.offsets && args.fixed_len % kRowTokens == 0;
+            if (fixed_rows)  // whole 16-token rows: no tail code in the kernel
                 hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN_FIXED_ROWS>), grid, dim3(256), 0, ctx->stream, args_s);
             else if (plain && !args.offsets)
                 hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN_FIXED>), grid, dim3(256), 0, ctx->stream, args_s);
@@ -1446,12 +1496,22 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_
                 hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN>), grid, dim3(256), 0, ctx->stream, args_s);
             else
                 hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_GENERAL>), grid, dim3(256), 0, ctx->stream, args_s);
+            // the tie-tolerant first launch: works instead of the one above when the context's last call said so (see MODE_SIEVE_TIES)
+            if (args_s.mode_word) {
+                if (fixed_rows)
+                    hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE_TIES, SHAPE_PLAIN_FIXED_ROWS>), grid, dim3(256), 0, ctx->stream, args_s);
+                else
+                    hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE_TIES, SHAPE_GENERAL>), grid, dim3(256), 0, ctx->stream, args_s);
+            }
+            }
             // the flagged sets: dedup sieve, then pair by pair what is still open (usually nothing: these launches read
             // n_sets bytes of flags and return).  A workgroup scans 64 flags at a time and strides over the flag
             // groups: a grid of one short-lived workgroup per group cost 60 us per step in workgroup launches alone
             const int64_t flag_groups = (args.n_sets + kWave - 1) / kWave;
             BulkArgs dedup = args;
             dedup.redo_match = 1;
+            dedup.sieve_hint = sieve_args.sieve_hint;
+            dedup.mode_word = packed ? nullptr : sieve_args.mode_word;
             if (args.n_sets <= 0xFFFFFFFFll) {
                 dedup.pair_count = ctx->d_work + 4;
                 dedup.pair_list = ctx->d_work + 16;
@@ -1529,6 +1589,7 @@ int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const in
     args.redo = nullptr;
     args.redo_match = 1;
     args.sieve_hint = nullptr;
+    args.mode_word = nullptr;
     args.alias_mask = ctx->opt_minhash_alias;
     args.pair_count = nullptr;
     args.pair_list = nullptr;

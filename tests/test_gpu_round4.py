@@ -289,3 +289,33 @@ def test_a_walks_last_lanes_taken_by_the_whole_wave(ctx, kind):
         assert ne.all() and wn.all() and np.array_equal(out[rows], want), lanes
         outs.append(out)
     assert all(np.array_equal(outs[0], o) for o in outs[1:])
+
+
+def test_first_launch_follows_the_corpus_and_results_do_not(ctx):
+    """Round 4: a context remembers (on the device) whether the last call's sets mostly defeated the one-candidate proof and
+    then makes the tie-tolerant proof the first launch -- or not, when that leaves too many sets to the dedup pass.  The
+    signatures must not depend on what was learned: clean, lightly and heavily repeating corpora in every order, twice each,
+    against the C oracle (ref: datasketch/minhash.py:262-263 accepts any iterable, repeats included)."""
+    from oracle import oracle as O2
+
+    rng = np.random.RandomState(99)
+    k, n, t = 128, 6000, 256
+    a, b = O2.np_init_permutations(k, 4)
+
+    def corpus(rate):
+        hv = rng.randint(0, 2**32, size=(n, t), dtype=np.uint64)
+        m = int(rate * hv.size)
+        if m:
+            rows, dst, src = rng.randint(0, n, m), rng.randint(0, t, m), rng.randint(0, t, m)
+            hv[rows, dst] = hv[rows, src]
+        return hv
+
+    corpora = {rate: corpus(rate) for rate in (0.0, 0.01, 0.1, 0.5)}
+    want = {rate: O2.c_minhash_bulk_dense(hv, a, b) for rate, hv in corpora.items()}
+    order = [0.0, 0.01, 0.01, 0.1, 0.1, 0.1, 0.01, 0.01, 0.0, 0.0, 0.5, 0.5, 0.01, 0.0, 0.1, 0.01, 0.01]
+    for csr in (False, True):
+        for rate in order:
+            hv = corpora[rate]
+            off = np.arange(0, (n + 1) * t, t, dtype=np.int64) if csr else None
+            got = ctx.minhash_bulk((a, b), hv.reshape(-1), off, 0 if csr else t, n)
+            assert np.array_equal(got, want[rate]), (csr, rate)
