@@ -345,6 +345,7 @@ class Context:
         self.device = int(device)
         self._perms = {}  # (K, digest) -> perm handle
         self._wgens = {}
+        self._comms = weakref.WeakSet()  # RCCL communicators made on this context: destroyed before it (close())
 
     # -- info / knobs
     def info(self) -> dict:
@@ -721,6 +722,11 @@ class Context:
     def close(self) -> None:
         if self.handle is None:
             return
+        for comm in list(self._comms):  # (mhx_comm_destroy needs the context it was created on)
+            try:
+                comm.close()
+            except Exception:  # noqa: BLE001
+                pass
         for h in self._perms.values():
             self.lib.mhx_perm_destroy(h)
         for h in list(self._wgens):
@@ -756,6 +762,7 @@ class Communicator:
         h = _vp()
         check(ctx.lib.mhx_comm_create(ctx.handle, buf, self.rank, self.world_size, ctypes.byref(h)))
         self.handle = h
+        ctx._comms.add(self)
 
     @staticmethod
     def unique_id() -> bytes:

@@ -88,17 +88,22 @@ def communicator(ctx, group):
 
     comms = getattr(group, "_mhx_comms", None)
     if comms is None:
-        comms = weakref.WeakKeyDictionary()  # context -> communicator: gone with either of the two
+        # id(context) -> communicator.  The communicator holds its context (so the id cannot be recycled while the entry
+        # lives) and is destroyed by whichever closes first: group.close() walks this table, Context.close() its own list
+        # of communicators -- a closed one has handle None and is made afresh here.
+        comms = {}
         try:
             group._mhx_comms = comms
         except AttributeError:  # a foreign group object without a __dict__: no caching
             pass
-    comm = comms.get(ctx)
+    comm = comms.get(id(ctx))
+    if comm is not None and comm.ctx is not ctx:
+        comm = None
     if comm is None or comm.handle is None:
         uid = _native.Communicator.unique_id() if group.rank == 0 else b""
         uid = group.allgather(uid)[0]
         comm = _native.Communicator(ctx, uid, group.rank, group.world)
-        comms[ctx] = comm
+        comms[id(ctx)] = comm
     return comm
 
 

@@ -37,6 +37,7 @@ from typing import List, Optional, Sequence
 _MAGIC = b"MHXR"
 _HDR = struct.Struct("<4sIQ")  # magic, rank, payload length
 _HELLO_MAX = 256               # a hello frame carries the group's nonce and nothing else
+_ACK = b"mhx-joined"           # rank 0's answer to a hello it accepted
 MAX_FRAME = 1 << 32            # no frame is larger (the CPU stand-in carries signature shards; a GPU job a few hundred bytes)
 
 
@@ -172,12 +173,13 @@ class Group:
             except socket.timeout:
                 continue
             try:  # anything that is not a rank of this group is dropped, not fatal: a port scanner, a stale job
-                conn.settimeout(min(5.0, max(0.1, left)))
+                conn.settimeout(min(1.0, max(0.1, left)))  # (hellos are read one after the other: a silent connection holds the others up this long)
                 peer, hello = _recv_frame(conn, _HELLO_MAX)
                 if not (0 < peer < self.world) or self._peers[peer] is not None or not hmac.compare_digest(hello, want):
                     raise ConnectionError("unexpected rendezvous peer")
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 conn.settimeout(timeout)
+                _send_frame(conn, 0, _ACK)  # the joiner waits for this: a rank that was dropped must not believe it has joined
                 self._peers[peer] = conn
                 missing -= 1
             except (OSError, struct.error):
@@ -199,12 +201,22 @@ class Group:
                 try:
                     s = socket.create_connection(target, timeout=5.0)
                     s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                    s.settimeout(timeout)
+                    s.settimeout(min(timeout, 10.0))
                     _send_frame(s, self.rank, hello.encode())
+                    src, ack = _recv_frame(s, _HELLO_MAX)  # rank 0 answers an accepted hello; EOF (dropped) -> try again
+                    if src != 0 or ack != _ACK:
+                        raise ConnectionError("rank 0 did not acknowledge the hello")
+                    s.settimeout(timeout)
                     self._sock = s
                     break
-                except OSError as e:
+                except (OSError, struct.error) as e:
                     last = e
+                    if "s" in locals() and s is not None and s is not self._sock:
+                        try:
+                            s.close()
+                        except OSError:
+                            pass
+                        s = None
             if time.time() > deadline:
                 raise TimeoutError(f"rank {self.rank}: no rendezvous with rank 0 within {timeout:.0f} s ({last!r})")
             time.sleep(0.05)
