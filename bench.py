@@ -41,7 +41,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic_minhash_bulk.json")
+TRAFFIC_FILE = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_traffic_minhash_bulk.json") for r in (4, 3)) if os.path.exists(p)),
+                    os.path.join(ROOT, "profiles", "r03_traffic_minhash_bulk.json"))
 
 
 def parse_args(argv=None):

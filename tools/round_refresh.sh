@@ -7,7 +7,7 @@ set -uo pipefail
 TAG="${1:-run}"
 OUT="gpurun_out/refresh_${TAG}"
 mkdir -p "${OUT}"
-timeout 600 python -m pytest tests -q -m gpu -p no:cacheprovider > "${OUT}/pytest_gpu.log" 2>&1; echo "pytest rc=$?"; grep -aE "passed|failed" "${OUT}/pytest_gpu.log" | tail -1
+timeout 1100 python -m pytest tests -q -m gpu -p no:cacheprovider > "${OUT}/pytest_gpu.log" 2>&1; echo "pytest rc=$?"; grep -aE "passed|failed" "${OUT}/pytest_gpu.log" | tail -1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "${OUT}/smoke.log" 2>&1; rc=$?; echo "smoke rc=${rc}"
 # a box whose GPU faults on every launch (seen once: "Memory access fault ... Reason: Unknown" from every process) would make
 # each profiler pass below sit out its time limit: stop here instead of spending the budget on it
@@ -26,8 +26,11 @@ timeout 200 python tools/bench_sort.py > "${OUT}/bench_sort.txt" 2>&1; echo "sor
 { for d in 1.0 0.3 0.05 0.01; do timeout 200 python tools/bench_weighted.py --rows 20000 --density $d --variants "path=0;path=2" --reps 3;
     timeout 200 python tools/bench_weighted.py --csr --density $d --rows 20000 --variants "path=0;path=2" --reps 3; done;
   timeout 200 python tools/bench_weighted.py --rows 20000 --dist lognormal --variants "path=0;path=2";
-  timeout 200 python tools/bench_weighted.py --rows 20000 --dist sorted --variants "path=0;path=2"; } > "${OUT}/bench_weighted.txt" 2>&1; echo "weighted rc=$?"
-: > "${OUT}/ubench_filter.txt"
-for seq in 0 8 9 10 1 2 3 11 4 5 12 13 6 7; do timeout 40 tools/ubench_filter ${seq} >> "${OUT}/ubench_filter.txt" 2>&1 || echo "sequence ${seq}: stopped (rc=$?)" >> "${OUT}/ubench_filter.txt"; done; echo "ubench done"
+  timeout 200 python tools/bench_weighted.py --rows 20000 --dist sorted --variants "path=0;path=2";
+  echo "## config 4: one wave per row (kernel=0), chunk after chunk (2), one workgroup per row (1: round 3), the last lanes never rescued (rescue=-1), round 3 plan launches (plan=1)";
+  timeout 200 python tools/bench_weighted.py --check 2048 --reps 5 --variants "kernel=0;kernel=2;kernel=1;rescue=-1;plan=1;path=2";
+  echo "## config 4, values in (the device takes numpy's log)"; timeout 200 python tools/bench_weighted.py --values --check 0 --reps 5 --variants "kernel=0;kernel=1";
+  echo "## lognormal weights, 20k rows"; timeout 200 python tools/bench_weighted.py --rows 20000 --dist lognormal --check 2048 --reps 4 --variants "kernel=0;rescue=-1;kernel=1"; } > "${OUT}/bench_weighted.txt" 2>&1; echo "weighted rc=$?"
+timeout 300 python tools/bench_shapes.py --cases k128,k136,k150,k160,k192,k200,k256 --packed 0 --p3 0,1 --reps 4 > "${OUT}/bench_kshapes.jsonl" 2> "${OUT}/bench_kshapes.err"; echo "kshapes rc=$?"
 # the rocprofv3 databases are hundreds of MB; what is judged are the summaries made from them above
 find gpurun_out -name "*.db" -delete 2>/dev/null; find gpurun_out -type f -size +8M -delete 2>/dev/null; du -sh gpurun_out | tail -1
