@@ -154,6 +154,18 @@ __device__ __forceinline__ float np_logf_normal(float x) {
     return __builtin_fmaf(ef, 0.693147180559945309417232121458176568f, q);
 }
 __device__ __forceinline__ bool np_logf_is_normal(float x) { return __float_as_uint(x) - 0x00800000u < 0x7f000000u; }
+// an entry of a row staged in LDS: its log (VALS = false: the stripe holds logs, -inf where nothing is stored) or the log of the
+// value held there (VALS = true, round 4: the one-wave-per-row kernel stages VALUES when the device takes the log, and takes it
+// of the entries a walk actually meets -- a dozen per sample -- instead of all 4096 of a row; log(+-0) = -inf marks the absent
+// ones as before).  Called in wave-uniform control flow (the vote decides between the two forms of the same function).
+template <bool VALS>
+__device__ __forceinline__ float row_log(const float *row, uint32_t c, bool staged = false) {  // staged (wave-uniform): this row's logs have been taken in place after all
+    const float v = row[c];
+    if (!VALS || staged) return v;
+    const bool zero = v == 0.0f;  // an absent entry: log = -inf (a walk meets many of them on a row that stores a third of its columns)
+    if (__builtin_expect(__all(zero || np_logf_is_normal(v)), 1)) return zero ? -__builtin_inff() : np_logf_normal(v);
+    return np_logf(v);
+}
 
 // ---- pre-pass: one wave per row -------------------------------------------------------------
 // logs[j] = ln(x) (device-log mode only), flags[row] = kFlagSamePattern (same column list as the
@@ -854,10 +866,11 @@ constexpr int kCachedChunks = 4;
 // the smallest of their results, taken by Held's own rule, is the row's.  (Sharing out the list of a WALKED row with
 // many entries above the cut the same way, the walk starting from what the waves found, was measured: lognormal weights
 // 0.675 -> 0.652 ms per 20k rows, config 4 0.50 -> 0.535 ms -- the extra code costs the common case registers.  Not kept.)
+template <bool VALS = false>
 __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list, int n_list, bool all_listed, int32_t dim, int32_t ch,
                                          int32_t my, int32_t sample_size, const float4 *__restrict__ walk_a,
                                          const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos, int32_t s_pad,
-                                         const float4 *cache_a, const uint32_t *cache_c, int32_t part, int32_t parts) {
+                                         const float4 *cache_a, const uint32_t *cache_c, int32_t part, int32_t parts, bool staged = false) {
     Held held;
     int j = (int)((int64_t)n_list * part / parts);
     n_list = (int)((int64_t)n_list * (part + 1) / parts);
@@ -869,7 +882,7 @@ __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list,
 #pragma unroll
         for (int u = 0; u < 4; ++u) c[u] = list[j + u], e[u] = aos[(int64_t)c[u] * s_pad + my];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) l[u] = row[c[u]], open |= evaluate_guarded<true>(l[u], e[u], t[u], a[u]);
+        for (int u = 0; u < 4; ++u) l[u] = row_log<VALS>(row, c[u], staged), open |= evaluate_guarded<true>(l[u], e[u], t[u], a[u]);
         if (__builtin_expect(__any(open), 0)) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) evaluate<false>(l[u], entry_of(e[u]), t[u], a[u]);
@@ -879,7 +892,7 @@ __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list,
     }
     for (; j < n_list; ++j) {
         const uint32_t c = list[j];
-        held.offer(row[c], aos[(int64_t)c * s_pad + my], c);
+        held.offer(row_log<VALS>(row, c, staged), aos[(int64_t)c * s_pad + my], c);
     }
     if (!all_listed) {
         const int lane = my & (kWave - 1);
@@ -909,7 +922,7 @@ __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list,
                 bool open = false;
 #pragma unroll
                 for (int u = 0; u < kU; ++u) {
-                    l[u] = row[c[u]];
+                    l[u] = row_log<VALS>(row, c[u], staged);
                     open |= evaluate_guarded<true>(l[u] == -__builtin_inff() ? 0.0f : l[u],
                                                    make_float4(e[u].y, e[u].z, e[u].w, __builtin_amdgcn_rcpf(e[u].y)), t[u], a[u]);
                 }
@@ -951,7 +964,7 @@ __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list,
                     bool open = false;
 #pragma unroll
                     for (int u = 0; u < kG; ++u) {
-                        l[u] = row[c[u]];
+                        l[u] = row_log<VALS>(row, c[u], staged);
                         open |= evaluate_guarded<true>(l[u] == -__builtin_inff() ? 0.0f : l[u],
                                                        make_float4(e[u].y, e[u].z, e[u].w, __builtin_amdgcn_rcpf(e[u].y)), t[u], a[u]);
                     }
@@ -981,8 +994,9 @@ __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list,
 // sequential walk would hold on reaching it, the first position whose bound exceeds that is where the walk stops, and the
 // smallest (ln_a, column) in front of it -- np.argmin's choice, ties to the smaller column -- is its result.  Same
 // evaluations (IEEE division here), same stop rule, same answer as position by position.
+template <bool VALS = false>
 __device__ __forceinline__ void walk_rescue(const float *row, int32_t dim, int32_t ch, int ls, int32_t k, const float4 *__restrict__ walk_a,
-                                            const uint32_t *__restrict__ walk_c, int lane, Held &held) {
+                                            const uint32_t *__restrict__ walk_c, int lane, Held &held, bool staged = false) {
     const auto lane_value = [](float v, int from) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), from)); };  // (the builtin is int -> int)
     float best_a = lane_value(held.ln_a, ls), best_t = lane_value(held.t, ls);
     uint32_t best_c = (uint32_t)__builtin_amdgcn_readlane((int)held.c, ls);
@@ -994,7 +1008,7 @@ __device__ __forceinline__ void walk_rescue(const float *row, int32_t dim, int32
         const int32_t pc = in ? p : dim - 1;
         const float4 e = wa[(int64_t)pc * kWave];  // {LB, r, ln_c, beta}
         const uint32_t col = wc[(int64_t)pc * kWave];
-        const float l = row[col];
+        const float l = row_log<VALS>(row, col, staged);
         float t, a;
         evaluate<false>(l == -__builtin_inff() ? 0.0f : l, entry_of(make_float4(e.y, e.z, e.w, 0.0f)), t, a);
         const bool valid = in && !(l == -__builtin_inff()) && a == a;
@@ -1037,11 +1051,11 @@ __device__ __forceinline__ void walk_rescue(const float *row, int32_t dim, int32
 // still walks or not (a finished lane's are dropped), so a finished lane can at most cause the exact re-evaluation of a
 // round, never a different value.  The chunks ch0 .. ch0 + NC - 1 all have their first positions cached (cache_a /
 // cache_c: chunk ch0's, the others' behind it).
-template <int NC>
+template <int NC, bool VALS = false>
 __device__ __forceinline__ void walk_chunks(const float *row, const uint16_t *list, int n_list, bool all_listed, int32_t dim, int32_t ch0,
                                             int lane, int32_t sample_size, const float4 *__restrict__ walk_a,
                                             const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos, int32_t s_pad,
-                                            const float4 *cache_a, const uint32_t *cache_c, int32_t rescue_lanes, Held (&held)[NC]) {
+                                            const float4 *cache_a, const uint32_t *cache_c, int32_t rescue_lanes, Held (&held)[NC], bool staged = false) {
     int32_t my[NC];
 #pragma unroll
     for (int i = 0; i < NC; ++i) my[i] = (ch0 + i) * kWave + lane;
@@ -1061,7 +1075,7 @@ __device__ __forceinline__ void walk_chunks(const float *row, const uint16_t *li
         }
 #pragma unroll
         for (int u = 0; u < kL; ++u) {
-            l[u] = row[c[u]];
+            l[u] = row_log<VALS>(row, c[u], staged);
 #pragma unroll
             for (int i = 0; i < NC; ++i) open |= evaluate_guarded<true>(l[u], e[i][u], t[i][u], a[i][u]);
         }
@@ -1078,7 +1092,7 @@ __device__ __forceinline__ void walk_chunks(const float *row, const uint16_t *li
     }
     for (; j < n_list; ++j) {
         const uint32_t c = list[j];
-        const float l = row[c];
+        const float l = row_log<VALS>(row, c, staged);
 #pragma unroll
         for (int i = 0; i < NC; ++i) held[i].offer(l, aos[(int64_t)c * s_pad + my[i]], c);
     }
@@ -1114,7 +1128,7 @@ __device__ __forceinline__ void walk_chunks(const float *row, const uint16_t *li
         for (int i = 0; i < NC; ++i)
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
-                l[i][u] = row[c[i][u]];
+                l[i][u] = row_log<VALS>(row, c[i][u], staged);
                 open |= evaluate_guarded<true>(l[i][u] == -__builtin_inff() ? 0.0f : l[i][u],
                                                make_float4(e[i][u].y, e[i][u].z, e[i][u].w, __builtin_amdgcn_rcpf(e[i][u].y)), t[i][u], a[i][u]);
             }
@@ -1172,7 +1186,7 @@ __device__ __forceinline__ void walk_chunks(const float *row, const uint16_t *li
                         while (act[i]) {
                             const int ls = __builtin_ctzll(act[i]);
                             act[i] &= act[i] - 1;
-                            walk_rescue(row, dim, ch0 + i, ls, k, walk_a, walk_c, lane, held[i]);
+                            walk_rescue<VALS>(row, dim, ch0 + i, ls, k, walk_a, walk_c, lane, held[i], staged);
                         }
                         done[i] = true;
                     }
@@ -1185,7 +1199,7 @@ __device__ __forceinline__ void walk_chunks(const float *row, const uint16_t *li
             for (int i = 0; i < NC; ++i)
 #pragma unroll
                 for (int u = 0; u < kG; ++u) {
-                    l[i][u] = row[c[i][u]];
+                    l[i][u] = row_log<VALS>(row, c[i][u], staged);
                     open |= evaluate_guarded<true>(l[i][u] == -__builtin_inff() ? 0.0f : l[i][u],
                                                    make_float4(e[i][u].y, e[i][u].z, e[i][u].w, __builtin_amdgcn_rcpf(e[i][u].y)), t[i][u], a[i][u]);
                 }
@@ -1221,12 +1235,13 @@ __device__ __forceinline__ void take_parts(const float *shared, int32_t ch, int3
 }
 
 // a row with a NaN among its logs: numpy's argmin, the first NaN wins (every stored entry, in column order)
+template <bool VALS = false>
 __device__ __forceinline__ void nan_row(const float *row, int32_t dim, int32_t my, const float4 *__restrict__ aos, int32_t s_pad,
-                                        int64_t &k_out, int64_t &t_out) {
+                                        int64_t &k_out, int64_t &t_out, bool staged = false) {
     Best best;
     best.ln_a = 0.0f, best.t = 0.0f, best.k = -1;
     for (int32_t c = 0; c < dim; ++c) {
-        const float l = row[c];
+        const float l = row_log<VALS>(row, (uint32_t)c, staged);
         if (l == -__builtin_inff()) continue;
         consider(best, l, entry_of(aos[(int64_t)c * s_pad + my]), c);
     }
@@ -1445,6 +1460,12 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
     float *row = lds + 5 * n_cc * kWalkCached * kWave + (int64_t)wave * stripe_words;
     uint16_t *list = reinterpret_cast<uint16_t *>(row + ((dim + 3) & ~3));
     const float lcut = plan->lcut;
+    // values in (LOGS = false): the stripe holds the VALUES and the log is taken of the entries a walk meets (row_log<true>), not
+    // of all of them -- so "above the cut" is first asked of the value: v <= vcut guarantees np_logf(v) <= lcut (vcut = exp of the
+    // cut less 10^-5 relative: numpy's log is within 4 ulp of the true one, expf within 2), and only values above vcut have their
+    // log taken and compared
+    // (below exp(-87) the values are denormal and a rounded exp is no bound: there every positive value has its log taken)
+    const float vcut = LOGS ? 0.0f : (lcut >= 88.0f ? __FLT_MAX__ : lcut <= -87.0f ? 0.0f : expf(lcut - 1e-5f * fmaxf(1.0f, fabsf(lcut))));
     const int64_t stride = (int64_t)gridDim.x * n_waves;
     // every lane always issues exactly NV loads per row (clamped to the matrix and to the row), so that the number of loads
     // in flight behind a row's is known at compile time and the wait for a row is not a wait for the one behind it
@@ -1466,21 +1487,16 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
         for (int u = 0; u < NV; ++u) {
             const int c = (u * kWave + lane) * 4;
             const bool in = c < dim;  // (a lane behind the row's end holds a clamped copy of its last entries: computed, not kept)
-            float l[4] = {pre[u].x, pre[u].y, pre[u].z, pre[u].w};
-            if (!LOGS) {
-                const bool plain = np_logf_is_normal(l[0]) && np_logf_is_normal(l[1]) && np_logf_is_normal(l[2]) && np_logf_is_normal(l[3]);
-                if (__builtin_expect(__all(plain), 1)) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) l[e] = np_logf_normal(l[e]);
-                } else {  // zeros (absent entries: log = -inf), denormals, negatives, NaNs
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) l[e] = np_logf(l[e]);
-                }
-            }
+            const float l[4] = {pre[u].x, pre[u].y, pre[u].z, pre[u].w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                lane_above |= in && l[e] > lcut;
-                lane_odd |= in && __builtin_amdgcn_class(l[e], 0x007);
+                if (LOGS) {
+                    lane_above |= in && l[e] > lcut;                              // +inf too
+                    lane_odd |= in && __builtin_amdgcn_class(l[e], 0x007);        // signalling / quiet NaN, -inf (= not stored)
+                } else {
+                    lane_above |= in && l[e] > vcut;                              // candidates: their logs are taken below
+                    lane_odd |= in && __builtin_amdgcn_class(l[e], 0x07F);        // NaN, negative (log: NaN), +-0 (= not stored)
+                }
             }
             if (in) *reinterpret_cast<float4 *>(row + c) = make_float4(l[0], l[1], l[2], l[3]);
         }
@@ -1492,13 +1508,31 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
             unsigned long long nan_lanes = 0;
             for (int c0 = 0; c0 < dim; c0 += kWave) {
                 const int c = c0 + lane;
-                const float l = c < dim ? row[c] : -__builtin_inff();
-                n_stored += __popcll(__ballot(!(l == -__builtin_inff())));
-                nan_lanes |= __ballot(l != l);
+                const float l = c < dim ? row[c] : (LOGS ? -__builtin_inff() : 0.0f);
+                n_stored += __popcll(__ballot(LOGS ? !(l == -__builtin_inff()) : l != 0.0f));
+                nan_lanes |= __ballot(LOGS ? l != l : (l != l || l < 0.0f));  // (the log of a negative value is a NaN)
             }
             has_nan = nan_lanes != 0;
         }
-        if (any_above) {  // (wave-uniform) list the columns above the cut
+        // values in: a row with entries above the cut -- a heavy tail: its walks are long (dozens of positions per sample) -- and
+        // a row gone through entry by entry (every sample meets every stored entry) have all their logs taken now, in place; any
+        // other row keeps its values and has the log taken of what its walks meet
+        const bool few_stored = (int64_t)n_stored * 1000 <= (int64_t)direct_permille * dim;
+        bool logs_staged = LOGS;
+        if (!LOGS && (any_above || few_stored)) {
+#pragma unroll 1
+            for (int u = 0; u < NV; ++u) {  // (not unrolled: it runs beside two rows held in registers)
+                const int c = (u * kWave + lane) * 4;
+                const bool in = c < dim;
+                float4 v = in ? *reinterpret_cast<const float4 *>(row + c) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+                const bool plain = np_logf_is_normal(v.x) && np_logf_is_normal(v.y) && np_logf_is_normal(v.z) && np_logf_is_normal(v.w);
+                if (__builtin_expect(__all(plain), 1)) v = make_float4(np_logf_normal(v.x), np_logf_normal(v.y), np_logf_normal(v.z), np_logf_normal(v.w));
+                else v = make_float4(np_logf(v.x), np_logf(v.y), np_logf(v.z), np_logf(v.w));  // zeros (-> -inf: absent), denormals, negatives, NaNs
+                if (in) *reinterpret_cast<float4 *>(row + c) = v;
+            }
+            logs_staged = true;
+        }
+        if (any_above) {  // (wave-uniform; the stripe holds logs by now) list the columns above the cut
             for (int c0 = 0; c0 < dim; c0 += kWave) {
                 const int c = c0 + lane;
                 const bool is_above = c < dim && row[c] > lcut;
@@ -1512,13 +1546,13 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
         }
         int n_list = n_out;
         // as in the workgroup-per-row kernel: few stored entries, or more above the cut than the list holds -> entry by entry
-        const bool by_entry = n_out > list_cap || (int64_t)n_stored * 1000 <= (int64_t)direct_permille * dim;
+        const bool by_entry = n_out > list_cap || few_stored;
         const bool listable = by_entry && !has_nan && n_stored > 0 && n_stored <= list_cap;
         if (listable) {  // list the stored columns (ascending)
             int at = 0;
             for (int c0 = 0; c0 < dim; c0 += kWave) {
                 const int c = c0 + lane;
-                const bool keep = c < dim && !(row[c] == -__builtin_inff());
+                const bool keep = c < dim && (logs_staged ? !(row[c] == -__builtin_inff()) : row[c] != 0.0f);
                 const unsigned long long mask = __ballot(keep);
                 if (keep) list[at + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u))] = (uint16_t)c;
                 at += __popcll(mask);
@@ -1526,46 +1560,49 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
             n_list = n_stored;
         }
         const bool walked = n_stored > 0 && !has_nan && !(by_entry && !listable);
-        for (int32_t ch = 0; ch < chunks; ++ch) {
-            if (PAIRS && walked && ch + 1 < n_cc) {  // (wave-uniform) two chunks of samples as one instruction stream
-                Held held[2];
-                walk_chunks<2>(row, list, n_list, by_entry, dim, ch, lane, sample_size, walk_a, walk_c, aos, s_pad,
-                               s_cache_a + ch * kWalkCached * kWave, s_cache_c + ch * kWalkCached * kWave, rescue_lanes, held);
+        {
+            constexpr bool VALS = !LOGS;  // (values in: the stripe holds values unless this row's logs were taken in place: logs_staged)
+            for (int32_t ch = 0; ch < chunks; ++ch) {
+                if (PAIRS && walked && ch + 1 < n_cc) {  // (wave-uniform) two chunks of samples as one instruction stream
+                    Held held[2];
+                    walk_chunks<2, VALS>(row, list, n_list, by_entry, dim, ch, lane, sample_size, walk_a, walk_c, aos, s_pad,
+                                         s_cache_a + ch * kWalkCached * kWave, s_cache_c + ch * kWalkCached * kWave, rescue_lanes, held, logs_staged);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int32_t my = (ch + i) * kWave + lane;
-                    if (my < sample_size) {
-                        int64_t *o = out + (d * sample_size + my) * 2;
-                        o[0] = held[i].c;
-                        o[1] = (int64_t)held[i].t;
+                    for (int i = 0; i < 2; ++i) {
+                        const int32_t my = (ch + i) * kWave + lane;
+                        if (my < sample_size) {
+                            int64_t *o = out + (d * sample_size + my) * 2;
+                            o[0] = held[i].c;
+                            o[1] = (int64_t)held[i].t;
+                        }
                     }
+                    ++ch;
+                    continue;
                 }
-                ++ch;
-                continue;
-            }
-            const int32_t my = ch * kWave + lane;
-            int64_t k_out = 0, t_out = 0;
-            if (n_stored == 0) {
-                // nothing stored: (0, 0), and the row is reported empty
-            } else if (has_nan) {
-                nan_row(row, dim, my, aos, s_pad, k_out, t_out);
-            } else if (by_entry && !listable) {  // every stored entry, in column order
-                Held held;
-                for (int32_t c = 0; c < dim; ++c) {
-                    const float l = row[c];
-                    if (!(l == -__builtin_inff())) held.offer(l, aos[(int64_t)c * s_pad + my], (uint32_t)c);
+                const int32_t my = ch * kWave + lane;
+                int64_t k_out = 0, t_out = 0;
+                if (n_stored == 0) {
+                    // nothing stored: (0, 0), and the row is reported empty
+                } else if (has_nan) {
+                    nan_row<VALS>(row, dim, my, aos, s_pad, k_out, t_out, logs_staged);
+                } else if (by_entry && !listable) {  // every stored entry, in column order
+                    Held held;
+                    for (int32_t c = 0; c < dim; ++c) {
+                        const float l = row_log<VALS>(row, (uint32_t)c, logs_staged);
+                        if (!(l == -__builtin_inff())) held.offer(l, aos[(int64_t)c * s_pad + my], (uint32_t)c);
+                    }
+                    k_out = held.c, t_out = (int64_t)held.t;
+                } else {
+                    const Held held = walk_row<VALS>(row, list, n_list, by_entry, dim, ch, my, sample_size, walk_a, walk_c, aos, s_pad,
+                                                     ch < n_cc ? s_cache_a + ch * kWalkCached * kWave : nullptr,
+                                                     ch < n_cc ? s_cache_c + ch * kWalkCached * kWave : nullptr, 0, 1, logs_staged);
+                    k_out = held.c, t_out = (int64_t)held.t;
                 }
-                k_out = held.c, t_out = (int64_t)held.t;
-            } else {
-                const Held held = walk_row(row, list, n_list, by_entry, dim, ch, my, sample_size, walk_a, walk_c, aos, s_pad,
-                                           ch < n_cc ? s_cache_a + ch * kWalkCached * kWave : nullptr,
-                                           ch < n_cc ? s_cache_c + ch * kWalkCached * kWave : nullptr, 0, 1);
-                k_out = held.c, t_out = (int64_t)held.t;
-            }
-            if (my < sample_size) {
-                int64_t *o = out + (d * sample_size + my) * 2;
-                o[0] = k_out;
-                o[1] = t_out;
+                if (my < sample_size) {
+                    int64_t *o = out + (d * sample_size + my) * 2;
+                    o[0] = k_out;
+                    o[1] = t_out;
+                }
             }
         }
         if (lane == 0) nonempty[d] = n_stored > 0 ? 1 : 0;

@@ -52,3 +52,23 @@ def test_boundaries_specials_and_negatives(simd_log):
     nans = np.concatenate([np.arange(0x7F800001, 0x7F800001 + 4096), np.arange(0x7FC00000, 0x7FC00000 + 4096),
                            np.arange(0xFF800000, 0xFF800000 + 4096), np.arange(0xFFC00000, 0xFFC00000 + 4096)]).astype(np.uint32)
     assert _equal_bits(nans.view(np.float32)) == 0
+
+
+def test_value_threshold_below_the_cut_is_conservative(simd_log):
+    """The one-wave-per-row kernel, values in: an entry counts as 'above the cut' only after its log has been taken, and the log
+    is taken only of values above vcut = exp(lcut - 1e-5 max(1, |lcut|)) (0 for cuts <= -87).  That is safe iff v <= vcut implies np.log(v) <= lcut --
+    checked here on the floats around vcut for cuts over the whole range, with vcut moved a few ulps either way (the device's
+    expf is not numpy's)."""
+    rng = np.random.RandomState(5)
+    cuts = np.concatenate([rng.uniform(-100, 88, 4000), rng.uniform(-2, 6, 4000), [0.0, 1e-3, -1e-3, 4.6051702, 87.9]]).astype(np.float32)
+    with np.errstate(all="ignore"):
+        vcut = np.exp((cuts - np.float32(1e-5) * np.maximum(np.float32(1), np.abs(cuts))).astype(np.float32)).astype(np.float32)
+    keep = cuts > -87.0  # (at and below -87 the kernel takes vcut = 0: denormal values, where a rounded exp bounds nothing)
+    cuts, vcut = cuts[keep], vcut[keep]
+    bits = vcut.view(np.uint32).astype(np.int64)
+    for shift in (-4, 0, 4):
+        top = np.clip(bits + shift, 1, 0x7F7FFFFF)
+        near = (top[:, None] - np.arange(0, 256)[None, :]).clip(1, None).astype(np.uint32).view(np.float32)  # the 256 floats at and below vcut
+        with np.errstate(all="ignore"):
+            logs = np.log(near)
+        assert (logs <= cuts[:, None]).all(), shift
