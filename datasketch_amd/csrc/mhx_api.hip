@@ -355,6 +355,7 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "minhash.packed")) ctx->opt_minhash_packed = value;
     else if (!strcmp(key, "minhash.ties")) ctx->opt_minhash_ties = value;
     else if (!strcmp(key, "minhash.p3")) ctx->opt_minhash_p3 = value;
+    else if (!strcmp(key, "minhash.share")) ctx->opt_minhash_share = value;
     else if (!strcmp(key, "minhash.adapt")) ctx->opt_minhash_adapt = value;
     else if (!strcmp(key, "blocks_per_cu")) ctx->opt_blocks_per_cu = value;
     else if (!strcmp(key, "minhash.alias")) ctx->opt_minhash_alias = value;

@@ -56,6 +56,7 @@ struct BulkArgs {
     unsigned int *pair_list;    // them are listed here (set numbers), so that the pairwise launch need not scan the flags for a handful
     int32_t prefetch;        // warm the next set's tokens with a vector load (option minhash.prefetch)
     int32_t ties;            // second launch: try the tie-tolerant sieve before the dedup pass (option minhash.ties)
+    int32_t share_last;      // 3 or 4 permutations per lane: lane groups share the rows of a partly filled last slot (option minhash.share)
     int64_t alias_mask;      // profiling only (option minhash.alias): sets read tokens of set (i & mask); -1 = off
     const uint64_t *init;
     int64_t init_stride;
@@ -324,6 +325,10 @@ struct SievePerms {
     uint32_t a_lo[P];
     uint64_t b8[P];  // b + 8 (only the low word matters)
     bool active[P];  // lane holds a real permutation (k < num_perm)
+    // (wave-uniform) lanes per group in the last slot: 64 = every lane its own permutation.  When the last slot holds r <= 32
+    // permutations (K = 136: 8 of 64 lanes busy in the third slot), 64/span lane groups hold the SAME r permutations and
+    // take every (64/span)-th row of a block each -- see sieve_range
+    uint32_t span = kWave;
 };
 
 // (smallest, second smallest) of the tagged keys seen so far
@@ -334,6 +339,11 @@ struct Two {
         k1 = min(k1, key);
     }
     __device__ __forceinline__ bool apart() const { return k2 - k1 >= 32u; }  // k2 >= k1 always
+    __device__ __forceinline__ void merge_from_lane(int other) {  // this record and lane `other`'s (over disjoint rows)
+        const uint32_t o1 = (uint32_t)__shfl((int)k1, other, kWave), o2 = (uint32_t)__shfl((int)k2, other, kWave);
+        add(o1);
+        add(o2);
+    }
 };
 
 // the three smallest: what the tie-tolerant proof of the second launch needs (see finish_block_ties)
@@ -344,17 +354,24 @@ struct Three {
         k2 = umed3(k1, k2, key);
         k1 = min(k1, key);
     }
+    __device__ __forceinline__ void merge_from_lane(int other) {
+        const uint32_t o1 = (uint32_t)__shfl((int)k1, other, kWave), o2 = (uint32_t)__shfl((int)k2, other, kWave);
+        const uint32_t o3 = (uint32_t)__shfl((int)k3, other, kWave);
+        add(o1);
+        add(o2);
+        add(o3);
+    }
 };
 
 // fold the keys of one chunk into the row minimum; OPEN: the chunk starts the row
-template <int P, typename TokT, bool OPEN>
+template <int P, typename TokT, bool OPEN, int PS = P>  // PS: the slots taken here (P, or P - 1 when the last one is shared out)
 __device__ __forceinline__ void sieve_chunk(const Chunk<TokT> &c, const SievePerms<P> &sp, uint32_t (&row)[P]) {
     constexpr int N = Chunk<TokT>::N;
     c.keep_whole();
 #pragma unroll
     for (int i = 0; i < N; i += 4) {
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
+        for (int p = 0; p < PS; ++p) {
             const uint32_t m0 = sieve_key(c.lo(i + 0), sp.a_lo[p], sp.b8[p]);
             const uint32_t m1 = sieve_key(c.lo(i + 1), sp.a_lo[p], sp.b8[p]);
             const uint32_t m2 = sieve_key(c.lo(i + 2), sp.a_lo[p], sp.b8[p]);
@@ -364,10 +381,10 @@ __device__ __forceinline__ void sieve_chunk(const Chunk<TokT> &c, const SievePer
         }
         // pin the minima here: left alone, the optimiser hoists every multiply of the chunk above
         // the first min3 and keeps all their results live (113 VGPRs instead of ~70)
-        if constexpr (P == 1)
+        if constexpr (PS == 1)
             asm volatile("" : "+v"(row[0]));
         else
-            asm volatile("" : "+v"(row[0]), "+v"(row[P - 1]));
+            asm volatile("" : "+v"(row[0]), "+v"(row[PS - 1]));
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -466,10 +483,41 @@ __device__ __forceinline__ bool finish_block_ties(const Three (&rows)[P], const 
     return fail;
 }
 
+// The last slot of a wave with 3 or 4 permutations per lane when it holds r <= 32 permutations (K = 136: 8; K = 150: 22;
+// K = 200: 8): in the row loop its 64 - r idle lanes would cost every token a multiply all the same.  Instead the row loop
+// leaves that slot out and, once the block's tile is in LDS, G = 64 / span lane groups -- each holding the same r
+// permutations in its first r lanes (load_perms) -- take every G-th row of the tile each: 16 keys of the row from LDS
+// (one address per group: broadcasts), their minimum tagged with the row, folded into the group's (smallest, second
+// [, third]) record.  The records of the groups cover disjoint rows, so merging them across the groups (an xor butterfly
+// over the group index) gives exactly the record the row loop would have produced: the proof that follows is the same.
+template <int P, int STRIDE, int WPT, typename Rows>
+__device__ __forceinline__ void share_last_slot(Rows &rec, const uint32_t *tile, const SievePerms<P> &sp, int rb, int lane) {
+    const uint32_t span = sp.span, groups = (uint32_t)kWave / span;  // powers of two, groups in 2 .. 16
+    const uint32_t mine = (uint32_t)lane / span;
+    const uint32_t a_lo = sp.a_lo[P - 1];
+    const uint64_t b8 = sp.b8[P - 1];
+    rec = Rows();
+#pragma unroll 1
+    for (uint32_t r0 = 0; r0 < (uint32_t)rb; r0 += groups) {
+        const uint32_t r = r0 + mine;                 // per lane group
+        const uint32_t *rowp = tile + (r & 15u) * STRIDE;
+        uint32_t m = kMaxHash;
+#pragma unroll
+        for (int c = 0; c < kRowTokens; c += 2) {  // (all 16 reads in flight: pinning four keys at a time as sieve_chunk does -- 69 instead of
+            // 81 VGPRs -- measured 1-2 % slower: what this pass waits for is the LDS round trip, not a free wave slot)
+            const uint32_t m0 = sieve_key(rowp[c * WPT], a_lo, b8);
+            const uint32_t m1 = sieve_key(rowp[(c + 1) * WPT], a_lo, b8);
+            m = umin3(m, m0, m1);
+        }
+        rec.add(r < (uint32_t)rb ? tag16(m, r) : kMaxHash);  // (2^32-1 changes nothing in the record)
+    }
+    for (uint32_t s = span; s < (uint32_t)kWave; s <<= 1) rec.merge_from_lane(lane ^ (int)s);
+}
+
 // Exact minima over the first nrows*16 tokens of [beg, ...) into res (min-combined); returns true
 // in lanes whose proof failed (the caller redoes the range).  All arguments wave-uniform except the
 // per-lane permutation registers.
-template <int P, typename TokT, bool TIES = false>
+template <int P, typename TokT, bool TIES = false, bool SHARE = false>
 __device__ __forceinline__ bool sieve_range(const TokT MHX_CONST_AS *hv, const TokT *hv_vec, int64_t beg,
                                             int nrows, const Perms<P> &pm, const SievePerms<P> &sp,
                                             uint32_t *lds, int lane, uint32_t (&res)[P], int &nblocks, bool *tied = nullptr) {
@@ -498,44 +546,49 @@ __device__ __forceinline__ bool sieve_range(const TokT MHX_CONST_AS *hv, const T
         typename std::conditional<TIES, Three, Two>::type rows[P];
         // Scalar loads return out of order, so the only wait is lgkmcnt(0): wait for the current
         // chunk (a use BEFORE the next prefetch is issued), THEN issue the prefetch, then hash.
-        if constexpr (CPR == 2) {
-            // uint64 tokens: a row is the chunk pair (a, b); one row per iteration, nothing conditional
-            for (int r = 0; r < rb; ++r) {
-                uint32_t row0[P];
-                a.arrived();
-                b.load(chunk_ptr(ci + 1));
-                __builtin_amdgcn_sched_barrier(0);
-                sieve_chunk<P, TokT, true>(a, sp, row0);
-                b.arrived();
-                a.load(chunk_ptr(ci + 2));
-                __builtin_amdgcn_sched_barrier(0);
-                sieve_chunk<P, TokT, false>(b, sp, row0);
-                ci += 2;
+        const auto row_loop = [&](auto slots) {
+            constexpr int PS = decltype(slots)::value;
+            if constexpr (CPR == 2) {
+                // uint64 tokens: a row is the chunk pair (a, b); one row per iteration, nothing conditional
+                for (int r = 0; r < rb; ++r) {
+                    uint32_t row0[P];
+                    a.arrived();
+                    b.load(chunk_ptr(ci + 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    sieve_chunk<P, TokT, true, PS>(a, sp, row0);
+                    b.arrived();
+                    a.load(chunk_ptr(ci + 2));
+                    __builtin_amdgcn_sched_barrier(0);
+                    sieve_chunk<P, TokT, false, PS>(b, sp, row0);
+                    ci += 2;
 #pragma unroll
-                for (int q = 0; q < P; ++q) rows[q].add(tag16(row0[q], (uint32_t)r));
-            }
-        } else {
-            // uint32 tokens: a row is one chunk; two rows per iteration keep the (a, b) ping-pong
-            for (int r = 0; r < rb; r += 2) {
-                uint32_t row0[P], row1[P];
-                a.arrived();
-                b.load(chunk_ptr(ci + 1));
-                __builtin_amdgcn_sched_barrier(0);
-                sieve_chunk<P, TokT, true>(a, sp, row0);
-                b.arrived();
-                a.load(chunk_ptr(ci + 2));
-                __builtin_amdgcn_sched_barrier(0);
-                sieve_chunk<P, TokT, true>(b, sp, row1);  // row r + 1
-                ci += 2;
-                const bool second = r + 1 < rb;  // wave-uniform
-                if (!second) ci -= 1;  // odd row count: chunk `b` was the clamped prefetch, not a row
+                    for (int q = 0; q < PS; ++q) rows[q].add(tag16(row0[q], (uint32_t)r));
+                }
+            } else {
+                // uint32 tokens: a row is one chunk; two rows per iteration keep the (a, b) ping-pong
+                for (int r = 0; r < rb; r += 2) {
+                    uint32_t row0[P], row1[P];
+                    a.arrived();
+                    b.load(chunk_ptr(ci + 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                    sieve_chunk<P, TokT, true, PS>(a, sp, row0);
+                    b.arrived();
+                    a.load(chunk_ptr(ci + 2));
+                    __builtin_amdgcn_sched_barrier(0);
+                    sieve_chunk<P, TokT, true, PS>(b, sp, row1);  // row r + 1
+                    ci += 2;
+                    const bool second = r + 1 < rb;  // wave-uniform
+                    if (!second) ci -= 1;  // odd row count: chunk `b` was the clamped prefetch, not a row
 #pragma unroll
-                for (int q = 0; q < P; ++q) {
-                    rows[q].add(tag16(row0[q], (uint32_t)r));
-                    if (second) rows[q].add(tag16(row1[q], (uint32_t)(r + 1)));
+                    for (int q = 0; q < PS; ++q) {
+                        rows[q].add(tag16(row0[q], (uint32_t)r));
+                        if (second) rows[q].add(tag16(row1[q], (uint32_t)(r + 1)));
+                    }
                 }
             }
-        }
+        };
+        constexpr bool kShare = SHARE && P >= 3;  // the last slot is left to share_last_slot (below)
+        row_loop(std::integral_constant<int, (kShare ? P - 1 : P)>());
         // block complete: tile -> LDS (wave-private, so program order is enough: no barrier), then
         // rescan the best row of every permutation, prove, hash the one candidate
         {
@@ -543,6 +596,7 @@ __device__ __forceinline__ bool sieve_range(const TokT MHX_CONST_AS *hv, const T
             dst[0] = st0;
             if (WPT == 2) dst[1] = st1;
         }
+        if constexpr (kShare) share_last_slot<P, STRIDE, WPT>(rows[P - 1], lds, sp, rb, lane);
         if constexpr (TIES)
             fail |= finish_block_ties<P, STRIDE, WPT>(rows, lds, pm, sp, res, tied);
         else
@@ -753,7 +807,7 @@ __device__ __forceinline__ Minima<P> full_minima(const TokT *hv_vec, int64_t beg
 // Sieve over the full 16-token rows of [beg,end) plus fast fold for the ragged tail.  Returns true
 // (wave-uniform) when a proof failed or a tail minimum is ambiguous: the caller then redoes the
 // range with full_minima.
-template <int P, typename TokT, bool TAIL = true, bool TIES = false>
+template <int P, typename TokT, bool TAIL = true, bool TIES = false, bool SHARE = false>
 __device__ __forceinline__ bool sieve_minima(const TokT MHX_CONST_AS *hv, const TokT *hv_vec, int64_t beg,
                                              int64_t end, const Perms<P> &pm, const Perms<P> &pm_biased,
                                              const SievePerms<P> &sp, unsigned long long *stats, int lane,
@@ -765,7 +819,7 @@ __device__ __forceinline__ bool sieve_minima(const TokT MHX_CONST_AS *hv, const 
     bool bad = false;
     if (nrows > 0) {
         int nblocks = 0;
-        bad = sieve_range<P, TokT, TIES>(hv, hv_vec, beg, nrows, pm, sp, lds, lane, res, nblocks, tied);
+        bad = sieve_range<P, TokT, TIES, SHARE>(hv, hv_vec, beg, nrows, pm, sp, lds, lane, res, nblocks, tied);
         if (stats && lane == 0) atomicAdd(stats + 2, (unsigned long long)nblocks);
     }
     const int64_t tail = beg + (int64_t)nrows * kRowTokens;
@@ -851,17 +905,28 @@ __device__ __forceinline__ void set_minima(const BulkArgs &args, const TokT MHX_
     }
 }
 
-template <int P>
+template <int P, bool SHARE = false>
 __device__ __forceinline__ void load_perms(const BulkArgs &args, int kbase, int lane, Perms<P> &pm,
                                            Perms<P> &pm_biased, SievePerms<P> &sp, int (&kidx)[P]) {
+    // SHARE (the launcher's choice: one pass over the permutations, r <= 32 of them left for the last slot of 3 or 4):
+    // 64/span lane groups hold the same r (share_last_slot); only the first group's lanes own them (kidx, active: they
+    // store, their proofs count)
+    uint32_t span = kWave;
+    if constexpr (SHARE && P >= 3) {
+        const int r = args.num_perm - (kbase + (P - 1) * kWave);
+        span = r > 16 ? 32u : r > 8 ? 16u : r > 4 ? 8u : 4u;
+    }
+    sp.span = span;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const int k = kbase + p * kWave + lane;
-        kidx[p] = k < args.num_perm ? k : -1;
-        const uint64_t a = kidx[p] >= 0 ? args.a[k] : 0;
+        const bool shared = SHARE && P >= 3 && p == P - 1;
+        const int k = kbase + p * kWave + (shared ? lane & (int)(span - 1) : lane);
+        const bool holds = k < args.num_perm;
+        kidx[p] = holds && !(shared && lane >= (int)span) ? k : -1;
+        const uint64_t a = holds ? args.a[k] : 0;
         pm.a_lo[p] = (uint32_t)a;
         pm.a_hi[p] = (uint32_t)(a >> 32);
-        pm.b[p] = kidx[p] >= 0 ? args.b[k] : 0;
+        pm.b[p] = holds ? args.b[k] : 0;
         pm_biased.a_lo[p] = pm.a_lo[p];
         pm_biased.a_hi[p] = pm.a_hi[p];
         pm_biased.b[p] = pm.b[p] + 1;  // wraps mod 2^64 like everything else
@@ -893,7 +958,7 @@ __device__ __forceinline__ void load_perms(const BulkArgs &args, int kbase, int 
 enum { MODE_SIEVE = 0, MODE_FULL = 1, MODE_DEDUP = 2, MODE_SIEVE_TIES = 3 };
 enum { SHAPE_GENERAL = 0, SHAPE_PLAIN = 1, SHAPE_PLAIN_FIXED = 2, SHAPE_PLAIN_FIXED_ROWS = 3 };
 
-template <int P, typename TokT, typename OutT, int MODE, int SHAPE>
+template <int P, typename TokT, typename OutT, int MODE, int SHAPE, bool SHARE = false>
 __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_in) {
     // SHAPE_PLAIN: no initial state, no counters, no aliasing; SHAPE_PLAIN_FIXED: and fixed-length sets;
     // SHAPE_PLAIN_FIXED_ROWS: and the length is a multiple of 16, so the fast-fold code for a ragged tail is
@@ -939,7 +1004,7 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
     Perms<P> pm, pm_biased;
     SievePerms<P> sp;
     int kidx[P];
-    if (kSieve || MODE == MODE_DEDUP) load_perms<P>(args, 0, lane, pm, pm_biased, sp, kidx);
+    if (kSieve || MODE == MODE_DEDUP) load_perms<P, SHARE>(args, 0, lane, pm, pm_biased, sp, kidx);
 
     const TokT MHX_CONST_AS *hv = as_const(static_cast<const TokT *>(args.hv));
     const TokT *hv_vec = static_cast<const TokT *>(args.hv);
@@ -1071,10 +1136,10 @@ __global__ __launch_bounds__(256) void minhash_bulk_kernel(const BulkArgs args_i
         for (int kc = 0; kc < kchunks && !defer; ++kc) {
             uint32_t res[P];
             if (kSieve) {
-                if (kchunks > 1) load_perms<P>(args, kc * (kWave * P), lane, pm, pm_biased, sp, kidx);
+                if (kchunks > 1) load_perms<P, SHARE>(args, kc * (kWave * P), lane, pm, pm_biased, sp, kidx);
                 if (end > beg) {
                     bool tied = false;
-                    defer = sieve_minima<P, TokT, SHAPE != SHAPE_PLAIN_FIXED_ROWS, MODE == MODE_SIEVE_TIES>(hv, hv_vec, beg, end, pm, pm_biased, sp, args.stats, lane, lds, res,
+                    defer = sieve_minima<P, TokT, SHAPE != SHAPE_PLAIN_FIXED_ROWS, MODE == MODE_SIEVE_TIES, SHARE>(hv, hv_vec, beg, end, pm, pm_biased, sp, args.stats, lane, lds, res,
                                                                                                           MODE == MODE_SIEVE_TIES ? &tied : nullptr);
                     if (kc == 0) ++tried;
                     if (MODE == MODE_SIEVE_TIES) {  // "failed" = the one-candidate proof would have: the corpus still calls for this kernel
@@ -1488,20 +1553,30 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_
 #undef MHX_PACKED
             } else {
             const bool fixed_rows = plain && !args.offsets && args.fixed_len % kRowTokens == 0;
-            if (fixed_rows)  // whole 16-token rows: no tail code in the kernel
-                hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN_FIXED_ROWS>), grid, dim3(256), 0, ctx->stream, args_s);
-            else if (plain && !args.offsets)
-                hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN_FIXED>), grid, dim3(256), 0, ctx->stream, args_s);
-            else if (plain)
-                hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_PLAIN>), grid, dim3(256), 0, ctx->stream, args_s);
-            else
-                hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE, SHAPE_GENERAL>), grid, dim3(256), 0, ctx->stream, args_s);
-            // the tie-tolerant first launch: works instead of the one above when the context's last call said so (see MODE_SIEVE_TIES)
-            if (args_s.mode_word) {
-                if (fixed_rows)
-                    hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE_TIES, SHAPE_PLAIN_FIXED_ROWS>), grid, dim3(256), 0, ctx->stream, args_s);
-                else
-                    hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_SIEVE_TIES, SHAPE_GENERAL>), grid, dim3(256), 0, ctx->stream, args_s);
+            // 3 or 4 permutations per lane with at most 32 left for the last slot (K = 129..160, 193..224): the kernels whose lane
+            // groups share that slot's rows (share_last_slot) instead of 64 - r lanes idling through every token
+            const int last_slot = args.num_perm - (P - 1) * kWave;
+            const bool share = P >= 3 && kchunks == 1 && args.share_last && last_slot > 0 && last_slot <= 32;
+            const auto first_launches = [&](auto share_tag) {
+                constexpr bool SH = decltype(share_tag)::value;
+#define MHX_SIEVE(MODE_, SHAPE_) hipLaunchKernelGGL((minhash_bulk_kernel<P, TokT, OutT, MODE_, SHAPE_, SH>), grid, dim3(256), 0, ctx->stream, args_s)
+                if (fixed_rows) MHX_SIEVE(MODE_SIEVE, SHAPE_PLAIN_FIXED_ROWS);  // whole 16-token rows: no tail code in the kernel
+                else if (plain && !args.offsets) MHX_SIEVE(MODE_SIEVE, SHAPE_PLAIN_FIXED);
+                else if (plain) MHX_SIEVE(MODE_SIEVE, SHAPE_PLAIN);
+                else MHX_SIEVE(MODE_SIEVE, SHAPE_GENERAL);
+                // the tie-tolerant first launch: works instead of the one above when the context's last call said so (see MODE_SIEVE_TIES)
+                if (args_s.mode_word) {
+                    if (fixed_rows) MHX_SIEVE(MODE_SIEVE_TIES, SHAPE_PLAIN_FIXED_ROWS);
+                    else MHX_SIEVE(MODE_SIEVE_TIES, SHAPE_GENERAL);
+                }
+#undef MHX_SIEVE
+            };
+            if constexpr (P >= 3) {
+                if (share) first_launches(std::true_type());
+                else first_launches(std::false_type());
+            } else {
+                (void)share;
+                first_launches(std::false_type());
             }
             }
             // the flagged sets: dedup sieve, then pair by pair what is still open (usually nothing: these launches read
@@ -1595,6 +1670,7 @@ int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const in
     args.pair_list = nullptr;
     args.prefetch = ctx->opt_minhash_prefetch != 0;
     args.ties = ctx->opt_minhash_ties != 1;
+    args.share_last = ctx->opt_minhash_share != 1;
     args.init = d_init;
     args.init_stride = init_stride;
     args.out = d_out;

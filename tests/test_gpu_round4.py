@@ -319,3 +319,52 @@ def test_first_launch_follows_the_corpus_and_results_do_not(ctx):
             off = np.arange(0, (n + 1) * t, t, dtype=np.int64) if csr else None
             got = ctx.minhash_bulk((a, b), hv.reshape(-1), off, 0 if csr else t, n)
             assert np.array_equal(got, want[rate]), (csr, rate)
+
+
+@pytest.mark.parametrize("k", [130, 132, 136, 137, 145, 150, 160, 161, 194, 196, 200, 209, 224, 225])
+def test_lane_groups_share_a_partly_filled_last_slot(ctx, k):
+    """Round 4: with 3 or 4 permutations per lane and at most 32 of them left for the last slot (K = 129..160, 193..224) lane
+    groups hold the same permutations and take every G-th row of a 256-token block each (share_last_slot: spans 4, 8, 16, 32).
+    Blocks of 16 rows, partial blocks (1..15 rows), tails, empty sets, both token widths, the tie-tolerant first launch (a
+    corpus full of repeats, called until the context has switched), an initial state -- against the C oracle and against the
+    same launch with the sharing switched off (ref: datasketch/minhash.py:113-132 allows any num_perm)."""
+    from oracle import oracle as O2
+
+    rng = np.random.RandomState(1000 + k)
+    a, b = O2.np_init_permutations(k, 5)
+    for n, t in ((600, 400), (300, 16), (200, 48), (150, 1024), (400, 250)):  # 25 rows; 1 row; 3 rows; 4 blocks; 15 rows + tail
+        tok = rng.randint(0, 2**32, size=(n, t), dtype=np.uint64)
+        want = O2.c_minhash_bulk_dense(tok, a, b)
+        assert np.array_equal(ctx.minhash_bulk((a, b), tok.reshape(-1), None, t, n), want), (n, t)
+        assert np.array_equal(ctx.minhash_bulk((a, b), tok.reshape(-1).astype(np.uint32), None, t, n, out_dtype=np.uint32), want.astype(np.uint32)), (n, t)
+    lens = rng.randint(0, 700, size=800)
+    lens[:40] = np.arange(40)  # every short length
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    hv = rng.randint(0, 2**32, size=int(off[-1]), dtype=np.uint64)
+    hv[rng.randint(0, hv.size, size=hv.size // 10)] += np.uint64(2**45)
+    init = rng.randint(0, 2**32, size=(800, k), dtype=np.uint64)
+    want = O2.c_minhash_bulk(hv, off, a, b, init=init)
+    assert np.array_equal(ctx.minhash_bulk((a, b), hv, off, 0, 800, init=init), want)
+    want = O2.c_minhash_bulk(hv, off, a, b)
+    assert np.array_equal(ctx.minhash_bulk((a, b), hv, off, 0, 800), want)
+    ctx.set_option("minhash.share", 1)
+    try:
+        assert np.array_equal(ctx.minhash_bulk((a, b), hv, off, 0, 800), want)
+    finally:
+        ctx.set_option("minhash.share", 0)
+    # repeats in most sets: after a call or two the first launch is the tie-tolerant one (Three records, merged across groups)
+    n, t = 5000, 256
+    rep = rng.randint(0, 2**32, size=(n, t), dtype=np.uint64)
+    m = n * t // 50
+    rows, dst, src = rng.randint(0, n, m), rng.randint(0, t, m), rng.randint(0, t, m)
+    rep[rows, dst] = rep[rows, src]
+    want = O2.c_minhash_bulk_dense(rep, a, b)
+    for _ in range(4):
+        assert np.array_equal(ctx.minhash_bulk((a, b), rep.reshape(-1), None, t, n), want)
+    roff = np.arange(0, (n + 1) * t, t, dtype=np.int64)
+    for _ in range(2):
+        assert np.array_equal(ctx.minhash_bulk((a, b), rep.reshape(-1), roff, 0, n), want)
+    clean = rng.randint(0, 2**32, size=(n, t), dtype=np.uint64)
+    want = O2.c_minhash_bulk_dense(clean, a, b)
+    for _ in range(2):  # and back
+        assert np.array_equal(ctx.minhash_bulk((a, b), clean.reshape(-1), None, t, n), want)

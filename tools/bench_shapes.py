@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--cases", default="k48,k64,k96,k128,k200,k256,ragged100,ragged480")
     ap.add_argument("--packed", default="0,1,2")
     ap.add_argument("--p3", default="0", help="settings of minhash.p3 to run (0 auto: three permutations per lane for 129 .. 192; 1: four)")
+    ap.add_argument("--share", default="0", help="settings of minhash.share to run (0 auto: lane groups share a last slot of <= 32 permutations; 1: off)")
     ap.add_argument("--reps", type=int, default=5)
     args = ap.parse_args()
     from datasketch_amd import MinHash, _native
@@ -42,9 +43,10 @@ def main():
         d_hv, d_off, d_out = ctx.to_device(hv), ctx.to_device(off), ctx.alloc(n * k * 8)
         dense = lo == hi
         first = None
-        for packed, p3 in [(int(x), int(y)) for x in args.packed.split(",") for y in args.p3.split(",")]:
+        for packed, p3, share in [(int(x), int(y), int(z)) for x in args.packed.split(",") for y in args.p3.split(",") for z in args.share.split(",")]:
             ctx.set_option("minhash.packed", packed)
             ctx.set_option("minhash.p3", p3)
+            ctx.set_option("minhash.share", share)
 
             def run():
                 ctx.minhash_bulk_dev((a, b), d_hv.ptr, _native.MHX_U64, None if dense else d_off.ptr, lo if dense else 0, n, hv.size, None, 0,
@@ -60,7 +62,7 @@ def main():
             ctx.synchronize()
             ms = min(evs[i].elapsed_ms(evs[i + 1]) for i in range(args.reps))
             got = d_out.download((n, k), np.uint64)
-            rec = {"case": case, "num_perm": k, "sets": n, "tokens": int(hv.size), "minhash.packed": packed, "minhash.p3": p3, "ms": round(ms, 4),
+            rec = {"case": case, "num_perm": k, "sets": n, "tokens": int(hv.size), "minhash.packed": packed, "minhash.p3": p3, "minhash.share": share, "ms": round(ms, 4),
                    "pairs_per_s": hv.size * k / (ms * 1e-3)}
             if first is None:
                 first = got
@@ -71,6 +73,7 @@ def main():
             print(json.dumps(rec), flush=True)
         ctx.set_option("minhash.packed", 0)
         ctx.set_option("minhash.p3", 0)
+        ctx.set_option("minhash.share", 0)
         for d in (d_hv, d_off, d_out):
             d.free()
 
