@@ -23,6 +23,7 @@ sys.path.insert(0, ROOT)
 
 from datasketch_amd import MinHash, WeightedMinHashGenerator, _native, prehashed  # noqa: E402
 from datasketch_amd import lsh_bulk as LB  # noqa: E402
+from tools._warm import warm  # noqa: E402
 from datasketch_amd.b_bit_minhash import pack_matrix  # noqa: E402
 
 
@@ -30,6 +31,7 @@ def timed(ctx, fn, reps=5, warmup=1):
     for _ in range(warmup):
         fn()
     ctx.synchronize()
+    warm(fn, ctx.synchronize, 0.25)  # GPU clocks (tools/_warm.py)
     evs = [ctx.event() for _ in range(reps + 1)]
     evs[0].record()
     for i in range(reps):

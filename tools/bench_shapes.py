@@ -24,9 +24,11 @@ def main():
     ap.add_argument("--p3", default="0", help="settings of minhash.p3 to run (0 auto: three permutations per lane for 129 .. 192; 1: four)")
     ap.add_argument("--share", default="0", help="settings of minhash.share to run (0 auto: lane groups share a last slot of <= 32 permutations; 1: off)")
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--ramp", type=float, default=0.3, help="seconds of untimed launches in front of the timed ones (GPU clocks)")
     args = ap.parse_args()
     from datasketch_amd import MinHash, _native
     from datasketch_amd.hashfunc import prehashed
+    from tools._warm import warm
 
     ctx = _native.context()
     rng = np.random.RandomState(7)
@@ -54,6 +56,7 @@ def main():
 
             run()
             ctx.synchronize()
+            warm(run, ctx.synchronize, args.ramp)  # GPU clocks (tools/_warm.py)
             evs = [ctx.event() for _ in range(args.reps + 1)]
             evs[0].record()
             for i in range(args.reps):

@@ -9,6 +9,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tools._warm import warm  # noqa: E402
 
 
 def main():
@@ -26,6 +27,7 @@ def main():
         run = lambda: _native.check(ctx.lib.mhx_lsh_sort_bands_dev_typed(ctx.handle, d_sig.ptr, _native.MHX_U32, n, k, b, r, d_dig.ptr, d_rows.ptr))
         run()
         ctx.synchronize()
+        warm(run, ctx.synchronize, 0.3)  # GPU clocks (tools/_warm.py)
         ms = []
         for _ in range(5):
             e0, e1 = ctx.event(), ctx.event()

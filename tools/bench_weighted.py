@@ -18,6 +18,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+from tools._warm import warm  # noqa: E402
 
 
 def main():
@@ -27,6 +28,7 @@ def main():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--check", type=int, default=2048)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--ramp", type=float, default=0.3, help="seconds of untimed calls in front of the timed ones (GPU clocks)")
     ap.add_argument("--density", type=float, default=1.0, help="fraction of stored entries (the rest are zeros)")
     ap.add_argument("--dist", default="uniform", help="uniform | lognormal | sorted (columns by increasing weight)")
     ap.add_argument("--variants", default="path=0;path=2")
@@ -90,6 +92,7 @@ def main():
 
         call()
         ctx.synchronize()
+        warm(call, ctx.synchronize, args.ramp)  # GPU clocks (tools/_warm.py)
         times = []
         for _ in range(args.reps):
             e0, e1 = ctx.event(), ctx.event()

@@ -1,6 +1,7 @@
 import sys, json, numpy as np
 sys.path.insert(0, '.')
 from datasketch_amd import MinHash, _native
+from tools._warm import warm
 ctx = _native.context()
 rng = np.random.RandomState(7)
 for case, (n, lo, hi) in {"ragged100": (1_000_000, 1, 100), "ragged480": (500_000, 32, 480), "k128": (1_000_000, 256, 256)}.items():
@@ -14,10 +15,11 @@ for case, (n, lo, hi) in {"ragged100": (1_000_000, 1, 100), "ragged480": (500_00
         def run():
             ctx.minhash_bulk_dev((a, b), d_hv.ptr, _native.MHX_U64, d_off.ptr, 0, n, hv.size, None, 0, d_out.ptr, _native.MHX_U64)
         run(); ctx.synchronize()
-        evs = [ctx.event() for _ in range(6)]
+        warm(run, ctx.synchronize, 0.3)
+        evs = [ctx.event() for _ in range(21)]
         evs[0].record()
-        for i in range(5):
+        for i in range(20):
             run(); evs[i + 1].record()
         ctx.synchronize()
-        print(case, "prefetch", pf, round(min(evs[i].elapsed_ms(evs[i + 1]) for i in range(5)), 4), flush=True)
+        print(case, "prefetch", pf, round(min(evs[i].elapsed_ms(evs[i + 1]) for i in range(20)), 4), round(sum(evs[i].elapsed_ms(evs[i + 1]) for i in range(20)) / 20, 4), flush=True)
     ctx.set_option("minhash.prefetch", 1)
