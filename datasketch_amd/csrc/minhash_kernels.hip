@@ -1512,7 +1512,11 @@ unsigned resident_grid(mhx_ctx *ctx, const void *kernel, int64_t items) {
 template <int P, typename TokT, typename OutT, int PF = P>
 int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_t total_tokens, bool split) {
     const int kchunks = (args.num_perm + kWave * P - 1) / (kWave * P);
-    const int blocks_per_cu = ctx->opt_blocks_per_cu > 0 ? (int)ctx->opt_blocks_per_cu : 64;  // >> residency: dispatcher evens out the tail (16: 2.40 ms, 32: 2.29, 64: 2.23)
+    // >> residency: the dispatcher evens out the tail.  Re-measured at steady clocks in round 4 (tools/experiments/
+    // r04_steady_clock_revalidation.py): K = 128 dense 1.99 ms for 16 .. 128, 2.09 at 512; sets of 1..100 tokens 0.913 at 64,
+    // 0.925 at 32, 0.929 at 128, 0.960 at 16; K = 256 (four permutations per lane: fewer waves resident, longer sets)
+    // 3.89 at 64, 3.79 at 128, 3.81 at 256, 3.95 at 1024; K = 192 2.99 / 2.98 / 2.97 at 64 / 128 / 256
+    const int blocks_per_cu = ctx->opt_blocks_per_cu > 0 ? (int)ctx->opt_blocks_per_cu : (P >= 3 ? 128 : 64);
     const int64_t max_blocks = (int64_t)ctx->num_cus * blocks_per_cu;
     if (!split) {
         const int64_t want = (args.n_sets + 3) / 4;
