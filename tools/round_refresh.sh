@@ -31,6 +31,6 @@ timeout 200 python tools/bench_sort.py > "${OUT}/bench_sort.txt" 2>&1; echo "sor
   timeout 200 python tools/bench_weighted.py --check 2048 --reps 5 --variants "kernel=0;kernel=2;kernel=1;rescue=-1;plan=1;path=2";
   echo "## config 4, values in (the device takes numpy's log)"; timeout 200 python tools/bench_weighted.py --values --check 0 --reps 5 --variants "kernel=0;kernel=1";
   echo "## lognormal weights, 20k rows"; timeout 200 python tools/bench_weighted.py --rows 20000 --dist lognormal --check 2048 --reps 4 --variants "kernel=0;rescue=-1;kernel=1"; } > "${OUT}/bench_weighted.txt" 2>&1; echo "weighted rc=$?"
-timeout 300 python tools/bench_shapes.py --cases k128,k136,k150,k160,k192,k200,k256 --packed 0 --p3 0,1 --reps 4 > "${OUT}/bench_kshapes.jsonl" 2> "${OUT}/bench_kshapes.err"; echo "kshapes rc=$?"
+timeout 400 python tools/bench_shapes.py --cases k128,k136,k150,k160,k176,k192,k200,k216,k240,k256 --packed 0 --p3 0,1 --share 0,1 --reps 10 > "${OUT}/bench_kshapes.jsonl" 2> "${OUT}/bench_kshapes.err"; echo "kshapes rc=$?"
 # the rocprofv3 databases are hundreds of MB; what is judged are the summaries made from them above
 find gpurun_out -name "*.db" -delete 2>/dev/null; find gpurun_out -type f -size +8M -delete 2>/dev/null; du -sh gpurun_out | tail -1
