@@ -74,7 +74,7 @@ struct mhx_ctx {
     int64_t opt_minhash_ties = 0;   // 0 auto (the second launch tries the tie-tolerant sieve before the dedup pass), 1 dedup pass only
     int64_t opt_minhash_split = 0;  // 0 auto, 1 force wave-per-set, 2 force split-sets (atomic combine)
     int64_t opt_blocks_per_cu = 0;  // 0 auto
-    int64_t opt_minhash_prefetch = 1; // warm L2 with the next set's tokens (vector load per set)
+    int64_t opt_minhash_prefetch = 1; // warm L2 with the next set's tokens (vector load per set): 1 auto (CSR, or fixed length < 256), 0 never, 2 always
     int64_t opt_minhash_alias = -1; // profiling only: >= 0 makes set i read the tokens of set (i & mask)
     int64_t opt_weighted_path = 0;  // 0 auto (dense rows: bound-ordered walk; CSR: reciprocal-multiply quotient + row blocks), 1 IEEE division for every element, 2 every element evaluated (dense rows compacted to CSR: the round-2 path)
     int64_t opt_weighted_rescue = 0; // dense walk, one wave per row: a walk's last lanes get the whole wave each (walk_rescue) when at most this many are left; 0 auto (4), < 0 never

@@ -1672,7 +1672,12 @@ int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const in
     args.alias_mask = ctx->opt_minhash_alias;
     args.pair_count = nullptr;
     args.pair_list = nullptr;
-    args.prefetch = ctx->opt_minhash_prefetch != 0;
+    // the one-set-ahead warm-up load: 1 (default) = where it pays -- CSR sets and fixed-length sets shorter than 256 tokens (3-6 % at
+    // steady clocks: 64 / 100 / 128-token sets 1.72 -> 1.63 / 1.21 -> 1.15 / 1.27 -> 1.24 ms, ragged 32..480 1.276 -> 1.230); on dense
+    // sets of 256 tokens and more it buys nothing (2.09 against 2.13 ms on the box of that sweep, 512 tokens 2.016 against 2.017) and
+    // reads a third of the corpus twice (lines evicted from the 4 MB L2 before use: 1.23x the algorithmic bytes, round 2-4 profiles).
+    // 0 = never, 2 = always.
+    args.prefetch = ctx->opt_minhash_prefetch == 2 || (ctx->opt_minhash_prefetch == 1 && (d_offsets != nullptr || fixed_len < 256));
     args.ties = ctx->opt_minhash_ties != 1;
     args.share_last = ctx->opt_minhash_share != 1;
     args.init = d_init;

@@ -75,7 +75,7 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * 1 = exact fold for every pair, 2 = fast fold with exact redo), ("minhash.split", 0 auto,
  * 1 wave per set, 2 split sets over waves), ("minhash.packed", 0 auto: several sets per wave when
  * num_perm <= 96, 1 = always one set per wave, 2 = several sets per wave up to num_perm 128), ("minhash.ties", 0 auto: the second launch tries the
- * tie-tolerant sieve before the dedup pass, 1 = dedup pass only), ("blocks_per_cu", n), ("minhash.prefetch", 0/1),
+ * tie-tolerant sieve before the dedup pass, 1 = dedup pass only), ("blocks_per_cu", n), ("minhash.prefetch", 0/1/2: never / auto / always),
  * ("minhash.alias", profiling only: >= 0 makes set i read the tokens of set i & mask),
  * ("weighted.path", 0 auto: dense rows through the bound-ordered walk, CSR rows through the row-block kernels,
  * 1 IEEE division for every element, 2 = every element evaluated: dense rows compacted to CSR first),

@@ -30,12 +30,14 @@ def main():
     ctx = _native.context()
     rng = np.random.RandomState(7)
     cases = {"k128_dense": (1_000_000, 256, 256, 128), "ragged100": (1_000_000, 1, 100, 128), "k256_dense": (1_000_000, 256, 256, 256),
-             "k192_dense": (1_000_000, 256, 256, 192), "k64_dense": (1_000_000, 256, 256, 64), "ragged480": (500_000, 32, 480, 128)}
+             "k192_dense": (1_000_000, 256, 256, 192), "t64_dense": (2_000_000, 64, 64, 128), "t128_dense": (1_000_000, 128, 128, 128),
+             "t512_dense": (500_000, 512, 512, 128), "t100_dense": (1_000_000, 100, 100, 128), "k64_dense": (1_000_000, 256, 256, 64), "ragged480": (500_000, 32, 480, 128)}
     if len(sys.argv) > 1:
         cases = {c: cases[c] for c in sys.argv[1].split(",")}
     sweeps = (("blocks_per_cu", (64, 32, 128, 16, 64, 32, 128, 16)), ("minhash.prefetch", (1, 0, 1, 0)), ("minhash.adapt", (0, 1, 0, 1)))
     if len(sys.argv) > 2:
-        sweeps = (("blocks_per_cu", tuple(int(x) for x in sys.argv[2].split(","))),)
+        key, _, vals = sys.argv[2].partition("=")
+        sweeps = ((key if vals else "blocks_per_cu", tuple(int(x) for x in (vals or key).split(","))),)
     for case, (n, lo, hi, k) in cases.items():
         lens = rng.randint(lo, hi + 1, size=n).astype(np.int64)
         off = np.zeros(n + 1, dtype=np.int64)

@@ -46,8 +46,9 @@ def main():
         return 64 * n64 + 32 * (n - n64)
 
     is_merge = lambda k: "minhash_merge_kernel" in k
-    is_sieve = lambda k: "minhash_bulk_kernel<2, unsigned long, unsigned long, 0, 3>" in k   # headline launch
-    is_alias = lambda k: "minhash_bulk_kernel<2, unsigned long, unsigned long, 0, 0>" in k   # the same with minhash.alias
+    # (the template argument lists grew a trailing ", false" in round 4: match up to the shape)
+    is_sieve = lambda k: "minhash_bulk_kernel<2, unsigned long, unsigned long, 0, 3" in k   # headline launch
+    is_alias = lambda k: "minhash_bulk_kernel<2, unsigned long, unsigned long, 0, 0" in k   # the same with minhash.alias
     cal_r, cal_w = read_bytes(pick(rd, is_merge, 3)), write_bytes(pick(wr, is_merge, 3))
     r, w = read_bytes(pick(rd, is_sieve, 4)), write_bytes(pick(wr, is_sieve, 4))
     ra = read_bytes(pick(rd, is_alias, 3))
@@ -77,12 +78,13 @@ def main():
         "ratio_to_algorithmic": (r + w) / (alg_r + alg_w),
         **issue,
         "reads_with_token_working_set_of_8MB": ra,
-        "note": "reads exceed the 2.048 GB of tokens by the lines that the one-set-ahead warm-up load brought into the XCD's 4 MB L2 "
-                "and that were evicted again before the scalar / tile loads used them; the second fetch is served over the fabric "
-                "(Infinity Cache counts as fabric here), not necessarily by HBM.  With option minhash.alias = 4095 (all scalar and "
-                "tile reads inside an 8 MB working set) the warm-up loads alone remain: one pass over the corpus.  Issuing the "
-                "warm-up load halfway through the set instead cut the reads to 2.37 GB but cost 1-10 % of time on this VALU-bound "
-                "kernel (profiles/r02_ab_late_warm_prefetch.txt): not kept.",
+        "prefetch": "minhash.prefetch = 1 (auto): no one-set-ahead warm-up load on dense sets of >= 256 tokens since round 4",
+        "note": "Rounds 2-4 (profiles/r02..r04 first refresh) measured 1.23x the algorithmic bytes here: the one-set-ahead warm-up "
+                "load brought lines into the XCD's 4 MB L2 that were evicted again before the scalar / tile loads used them.  At "
+                "steady clocks that load buys nothing on dense sets of 256 tokens and more (tools/experiments/"
+                "r04_steady_clock_revalidation.py), so it is now issued only for CSR sets and fixed lengths below 256, where it "
+                "is worth 3-6 %.  reads_with_token_working_set_of_8MB: the same launch with option minhash.alias = 4095 (all "
+                "token reads inside an 8 MB working set).",
     }, indent=1))
 
 
