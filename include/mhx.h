@@ -77,6 +77,13 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * num_perm <= 96, 1 = always one set per wave, 2 = several sets per wave up to num_perm 128), ("minhash.ties", 0 auto: the second launch tries the
  * tie-tolerant sieve before the dedup pass, 1 = dedup pass only), ("blocks_per_cu", n), ("minhash.prefetch", 0/1/2: never / auto / always),
  * ("minhash.alias", profiling only: >= 0 makes set i read the tokens of set i & mask),
+ * ("minhash.p3", 0 auto: three permutations per lane for 129 <= num_perm <= 192, 1 = four), ("minhash.share", 0 auto: with three or four
+ * permutations per lane, lane groups share a last slot that holds at most 32 permutations -- num_perm 129..160, 193..224 --, 1 = off),
+ * ("minhash.adapt", 0 auto: the context remembers on the device whether the last call's sets mostly defeated the one-candidate proof and
+ * starts the next call with the tie-tolerant one, 1 = off),
+ * ("weighted.kernel", 0 auto: dense rows of 1024..4096 columns through the one-wave-per-row kernel, 1 = the workgroup-per-row kernel, 2 = one wave
+ * per row, sample chunks one after the other), ("weighted.plan", 1 = plan and tables in two launches), ("weighted.rescue", n: a walk's last n lanes
+ * are taken over by the whole wave, 0 auto = 4, < 0 never),
  * ("weighted.path", 0 auto: dense rows through the bound-ordered walk, CSR rows through the row-block kernels,
  * 1 IEEE division for every element, 2 = every element evaluated: dense rows compacted to CSR first),
  * ("weighted.direct", n: a dense row with at most n stored elements per 1000 columns is evaluated element by element
