@@ -1893,7 +1893,7 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
         else if (nv == 8) MHX_WALK_WAVE(LOGS, 8, PAIRS_); \
         else MHX_WALK_WAVE(LOGS, 16, PAIRS_);             \
     } while (0)
-            const int32_t rescue_lanes = ctx->opt_weighted_rescue < 0 ? 0 : ctx->opt_weighted_rescue > 0 ? (int32_t)ctx->opt_weighted_rescue : 4;
+            const int32_t rescue_lanes = ctx->opt_weighted_rescue < 0 ? 0 : ctx->opt_weighted_rescue > 0 ? (int32_t)ctx->opt_weighted_rescue : 8;  // (lognormal rows at steady clocks: 2: 0.557, 4: 0.535, 8: 0.529, 16: 0.563, 32: 0.68 ms per 20k; config 4 the same for all)
             const bool pairs = ctx->opt_weighted_kernel != 2;  // two chunks of samples as one stream (0.424 -> 0.405 ms on config 4); 2 = chunk after chunk
             if (values_are_logs) {
                 if (pairs) MHX_WALK_WAVE_NV(true, true);

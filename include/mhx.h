@@ -83,7 +83,7 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * starts the next call with the tie-tolerant one, 1 = off),
  * ("weighted.kernel", 0 auto: dense rows of 1024..4096 columns through the one-wave-per-row kernel, 1 = the workgroup-per-row kernel, 2 = one wave
  * per row, sample chunks one after the other), ("weighted.plan", 1 = plan and tables in two launches), ("weighted.rescue", n: a walk's last n lanes
- * are taken over by the whole wave, 0 auto = 4, < 0 never),
+ * are taken over by the whole wave, 0 auto = 8, < 0 never),
  * ("weighted.path", 0 auto: dense rows through the bound-ordered walk, CSR rows through the row-block kernels,
  * 1 IEEE division for every element, 2 = every element evaluated: dense rows compacted to CSR first),
  * ("weighted.direct", n: a dense row with at most n stored elements per 1000 columns is evaluated element by element

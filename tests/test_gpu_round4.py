@@ -280,7 +280,7 @@ def test_a_walks_last_lanes_taken_by_the_whole_wave(ctx, kind):
     want, wn = _oracle_rows(g, sp.csr_matrix(x), rows)
     wctx, _ = g._device_handle()
     outs = []
-    for lanes in (-1, 1, 0, 64):
+    for lanes in (-1, 1, 0, 4, 64):
         wctx.set_option("weighted.rescue", lanes)
         try:
             out, ne = g.minhash_many_arrays(x)
