@@ -1,3 +1,14 @@
+#!/usr/bin/env python3
+"""Round 4 experiment (profiles/r04_ab_short_ragged_sets.txt (d), profiles/r04_clock_ramp.txt): how much of the first launch is its stores?
+
+NOT runnable against the committed library: setting 3 of option minhash.prefetch was a two-line hack in minhash_bulk_kernel that existed
+only for this measurement --
+    first run:  `if (kSieve && args.prefetch == 3) continue;` in front of `out[...] = v` (and no flag byte): no stores at all;
+    second run: `__builtin_nontemporal_store(v, &out[...])` under the same condition: streaming stores.
+With the committed library both settings run the same kernel (3 counts as "on").  Kept because its FIRST form (no clock warm-up,
+the settings alternating 1, 3, 1, 3) is what exposed the GPU's clock ramp: every later group was faster than the one before it,
+whatever its setting.  The form below (tools/_warm.py in front of every group) is the one that measured "no difference".
+"""
 import sys, json, numpy as np
 sys.path.insert(0, '.')
 from datasketch_amd import MinHash, _native
