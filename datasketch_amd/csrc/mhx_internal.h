@@ -70,7 +70,7 @@ struct mhx_ctx {
     int64_t opt_minhash_packed = 0; // 0 auto (several sets per wave when num_perm <= 96), 1 always one set per wave, 2 several sets per wave up to 128
     int64_t opt_minhash_adapt = 0;  // 0 auto (the first launch is the tie-tolerant one when the previous call's sets mostly defeated the one-candidate proof), 1 = never
     int64_t opt_minhash_share = 0;  // 0 auto (lane groups share the rows of a last slot with <= 32 permutations: K = 129..160, 193..224), 1 = off
-    int64_t opt_minhash_p3 = 0;     // 0 auto (129 .. 192 permutations: three per lane in the sieve launch), 1 = four per lane as before
+    int64_t opt_minhash_p3 = 0;     // 0 auto (three per lane in the sieve launch where that walks the fewest slots: 129 .. 192, 257 .. 384, 513 .. 576), 1 = never three
     int64_t opt_minhash_ties = 0;   // 0 auto (the second launch tries the tie-tolerant sieve before the dedup pass), 1 dedup pass only
     int64_t opt_minhash_split = 0;  // 0 auto, 1 force wave-per-set, 2 force split-sets (atomic combine)
     int64_t opt_blocks_per_cu = 0;  // 0 auto

@@ -1630,18 +1630,22 @@ int launch_typed(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_
 
 template <typename TokT, typename OutT>
 int launch_p(mhx_ctx *ctx, const BulkArgs &args, int64_t first_token, int64_t total_tokens, bool split) {
-    // P permutations per lane: 1 for K <= 64, 2 up to 128; beyond that the sieve launch takes 4 (a set's
-    // tokens are walked ceil(K/256) times instead of ceil(K/128): 4.00 -> 3.90 ms per 1M sets at K = 256,
-    // 122 VGPRs) while the full launch stays at 2 (with 4 it would need 220 VGPRs)
+    // P permutations per lane: 1 for K <= 64
     if (args.num_perm <= 64) return launch_typed<1, TokT, OutT>(ctx, args, first_token, total_tokens, split);
-    const int slots4 = (args.num_perm + 255) / 256 * 256, slots2 = (args.num_perm + 127) / 128 * 128;  // lanes x P x passes
-    // (uint64 tokens only: with uint32 tokens -- a row per chunk, two rows per loop body -- four permutations need 207 VGPRs)
-    // 129 .. 192 permutations: three per lane, one pass with every lane busy up to 192 (four per lane left a quarter of the
-    // lanes idle there: K = 150 ran 0.59 of them); option minhash.p3 = 1 switches it off (A/B)
-    if (args.num_perm > 128 && args.num_perm <= 192 && !split && ctx->opt_minhash_p3 != 1)  // (uint32 tokens too: 121 VGPRs, where four per lane need 207)
-        return launch_typed<3, TokT, OutT, 2>(ctx, args, first_token, total_tokens, split);
-    if (args.num_perm > 128 && !split && slots4 <= slots2 && sizeof(TokT) == 8)
-        return launch_typed<4, TokT, OutT, 2>(ctx, args, first_token, total_tokens, split);
+    // Beyond 64: 2, 3 or 4 permutations per lane in the sieve launch -- whichever walks the fewest 64-permutation slots over its
+    // ceil(K / 64P) passes (a pass costs its P slots whether they are full or not; the passes re-read the set from L2).  Ties go to the
+    // larger P (fewer passes: K = 256 4.00 -> 3.90 ms with four per lane).  K = 129..192: three (one pass, every lane busy up to 192;
+    // four per lane left a quarter of the lanes idle there); 193..256: four; 257..384: three, twice (round 4; until then two per lane in three
+    // passes: the same 6 slots, one more pass over the set); 385..512: four, twice; 513..576: three, three times.  The full launch stays at two (with four
+    // it would need 220 VGPRs).  Four per lane for uint64 tokens only (uint32: a row per chunk, two rows per loop body: 207 VGPRs;
+    // three: 121).  Option minhash.p3 = 1 takes the three-per-lane kernels out (A/B).
+    const auto slots = [&](int p) { return (args.num_perm + kWave * p - 1) / (kWave * p) * p; };
+    const bool may3 = !split && ctx->opt_minhash_p3 != 1, may4 = !split && sizeof(TokT) == 8;
+    int best = 2;
+    if (may3 && slots(3) <= slots(best)) best = 3;
+    if (may4 && slots(4) <= slots(best)) best = 4;
+    if (best == 3) return launch_typed<3, TokT, OutT, 2>(ctx, args, first_token, total_tokens, split);
+    if (best == 4) return launch_typed<4, TokT, OutT, 2>(ctx, args, first_token, total_tokens, split);
     return launch_typed<2, TokT, OutT>(ctx, args, first_token, total_tokens, split);
 }
 

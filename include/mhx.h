@@ -77,7 +77,7 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * num_perm <= 96, 1 = always one set per wave, 2 = several sets per wave up to num_perm 128), ("minhash.ties", 0 auto: the second launch tries the
  * tie-tolerant sieve before the dedup pass, 1 = dedup pass only), ("blocks_per_cu", n), ("minhash.prefetch", 0/1/2: never / auto / always),
  * ("minhash.alias", profiling only: >= 0 makes set i read the tokens of set i & mask),
- * ("minhash.p3", 0 auto: three permutations per lane for 129 <= num_perm <= 192, 1 = four), ("minhash.share", 0 auto: with three or four
+ * ("minhash.p3", 0 auto: three permutations per lane where that walks the fewest slots -- num_perm 129..192, 257..384, 513..576 --, 1 = never three), ("minhash.share", 0 auto: with three or four
  * permutations per lane, lane groups share a last slot that holds at most 32 permutations -- num_perm 129..160, 193..224 --, 1 = off),
  * ("minhash.adapt", 0 auto: the context remembers on the device whether the last call's sets mostly defeated the one-candidate proof and
  * starts the next call with the tie-tolerant one, 1 = off),

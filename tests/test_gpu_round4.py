@@ -204,12 +204,13 @@ def test_device_log_equals_numpy_log_for_every_float32(ctx):
     assert bad == 0
 
 
-@pytest.mark.parametrize("k", list(range(129, 257, 7)) + [192, 193, 255, 256])
+@pytest.mark.parametrize("k", list(range(129, 257, 7)) + [192, 193, 255, 256, 257, 300, 320, 384, 385, 448, 512, 513, 576, 600])
 def test_num_perm_sweep_129_to_256(ctx, k):
     """Every shape class of 129 <= num_perm <= 256 (ref: datasketch/minhash.py:113-132 allows any num_perm): three
     permutations per lane up to 192 (round 4), four beyond; dense rows of whole 16-token rows, dense rows with a tail, ragged
     sets with empty ones and 64-bit tokens, uint32 tokens, an initial state -- against the C oracle, and the three-per-lane
-    launch against the four-per-lane one."""
+    launch against the four-per-lane one.  Beyond 256 (appended to the sweep): several passes over the permutations with the number of
+    permutations per lane that walks the fewest slots -- 257..384 three per lane twice, 385..512 four twice, 513..576 three three times."""
     from oracle import oracle as O2
 
     rng = np.random.RandomState(k)
@@ -219,7 +220,7 @@ def test_num_perm_sweep_129_to_256(ctx, k):
         want = O2.c_minhash_bulk_dense(tok, a, b)
         assert np.array_equal(ctx.minhash_bulk((a, b), tok.reshape(-1), None, t, n), want)
         assert np.array_equal(ctx.minhash_bulk((a, b), tok.reshape(-1).astype(np.uint32), None, t, n, out_dtype=np.uint32), want.astype(np.uint32))
-        if k <= 192:
+        if k <= 192 or 256 < k <= 384 or 512 < k <= 576:
             ctx.set_option("minhash.p3", 1)
             try:
                 assert np.array_equal(ctx.minhash_bulk((a, b), tok.reshape(-1), None, t, n), want)
