@@ -181,7 +181,13 @@ def main():
     # below is what a long-running job sees, and the number of those extra steps is reported in the JSON line.
     clock_steps = 0
     t_ramp = time.perf_counter()
-    while args.clock_warmup > 0 and time.perf_counter() - t_ramp < args.clock_warmup:
+    if gather is not None and args.clock_warmup > 0:
+        # (a step with the all-gather inside is a collective: every rank must run the same number of them, so not by the clock)
+        clock_steps = 96
+        for _ in range(clock_steps):
+            step()
+        sync()
+    while gather is None and args.clock_warmup > 0 and time.perf_counter() - t_ramp < args.clock_warmup:
         for _ in range(8):
             step()
         clock_steps += 8
