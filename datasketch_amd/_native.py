@@ -103,6 +103,7 @@ _PROTOTYPES = {
     "mhx_comm_destroy": [_vp],
     "mhx_comm_info": [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)],
     "mhx_comm_allgather_dev": [_vp, _vp, _vp, _sz],
+    "mhx_comm_allgatherv_dev": [_vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)],
 }
 _RESTYPE = {"mhx_last_error": ctypes.c_char_p, "mhx_version": ctypes.c_char_p}
 
@@ -289,6 +290,15 @@ class DeviceBuffer:
 
     def download(self, shape, dtype, offset: int = 0) -> np.ndarray:
         out = np.empty(shape, dtype=dtype)
+        if offset + out.nbytes > self.nbytes:
+            raise ValueError("download exceeds the device buffer")
+        check(self.ctx.lib.mhx_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr + offset, out.nbytes))
+        return out
+
+    def download_into(self, out: np.ndarray, offset: int = 0) -> np.ndarray:
+        """Device -> an existing contiguous host array (a shared-memory view, a slice of a larger result)."""
+        if not out.flags.c_contiguous or not out.flags.writeable:
+            raise ValueError("download_into needs a writable C-contiguous array")
         if offset + out.nbytes > self.nbytes:
             raise ValueError("download exceeds the device buffer")
         check(self.ctx.lib.mhx_memcpy_d2h(self.ctx.handle, out.ctypes.data, self.ptr + offset, out.nbytes))
@@ -779,6 +789,15 @@ class Communicator:
     def allgather_dev(self, d_send: int, d_recv: int, bytes_per_rank: int) -> None:
         """Enqueue the all-gather on the context's stream (device pointers; d_recv holds world*bytes)."""
         check(self.ctx.lib.mhx_comm_allgather_dev(self.handle, _vp(d_send), _vp(d_recv), int(bytes_per_rank)))
+
+    def allgatherv_dev(self, d_send: int, d_recv: int, offsets, sizes) -> None:
+        """Unequal shards in place (one grouped launch of broadcasts): rank q's sizes[q] bytes land at d_recv + offsets[q]."""
+        n = self.world_size
+        if len(offsets) != n or len(sizes) != n:
+            raise ValueError("offsets and sizes have one entry per rank")
+        off = (ctypes.c_uint64 * n)(*[int(v) for v in offsets])
+        siz = (ctypes.c_uint64 * n)(*[int(v) for v in sizes])
+        check(self.ctx.lib.mhx_comm_allgatherv_dev(self.handle, _vp(d_send), _vp(d_recv), off, siz))
 
     def close(self) -> None:
         if getattr(self, "handle", None):

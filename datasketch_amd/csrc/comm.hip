@@ -23,6 +23,9 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
     ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
@@ -51,6 +54,9 @@ Rccl &rccl() {
         MHX_SYM(CommInitRank, "ncclCommInitRank")
         MHX_SYM(CommDestroy, "ncclCommDestroy")
         MHX_SYM(AllGather, "ncclAllGather")
+        MHX_SYM(Broadcast, "ncclBroadcast")
+        MHX_SYM(GroupStart, "ncclGroupStart")
+        MHX_SYM(GroupEnd, "ncclGroupEnd")
         MHX_SYM(GetErrorString, "ncclGetErrorString")
         MHX_SYM(CommCount, "ncclCommCount")
         MHX_SYM(CommUserRank, "ncclCommUserRank")
@@ -151,6 +157,34 @@ int mhx_comm_allgather_dev(mhx_comm *comm, const void *d_send, void *d_recv, siz
     MHX_GUARD(comm->ctx);
     if (int rc = comm->ctx->activate()) return rc;
     MHX_RCCL_CHECK(rccl().AllGather(d_send, d_recv, bytes_per_rank, ncclUint8, comm->comm, comm->ctx->stream));
+    return MHX_OK;
+}
+
+// Unequal shards, written in place: rank q's recv_bytes[q] bytes land at d_recv + recv_offsets[q] on every rank.  RCCL has
+// no all-gather-v; the documented equivalent is one ncclBroadcast per root inside a group call, which RCCL fuses into one
+// launch -- no padded staging buffer, no squeeze copies, no host synchronisation.
+int mhx_comm_allgatherv_dev(mhx_comm *comm, const void *d_send, void *d_recv, const uint64_t *recv_offsets,
+                            const uint64_t *recv_bytes) {
+    if (!comm) return mhx::fail(MHX_ERR_INVALID, "comm is NULL");
+    MHX_REQUIRE(recv_offsets && recv_bytes, "NULL offsets / sizes");
+    uint64_t total = 0;
+    for (int q = 0; q < comm->world; ++q) total += recv_bytes[q];
+    if (total == 0) return MHX_OK;
+    MHX_REQUIRE(d_recv && (d_send || recv_bytes[comm->rank] == 0), "NULL device pointer");
+    MHX_GUARD(comm->ctx);
+    if (int rc = comm->ctx->activate()) return rc;
+    MHX_RCCL_CHECK(rccl().GroupStart());
+    ncclResult_t first = ncclSuccess;
+    for (int q = 0; q < comm->world; ++q) {
+        if (recv_bytes[q] == 0) continue;  // (the same on every rank: counts are common knowledge)
+        char *dst = static_cast<char *>(d_recv) + recv_offsets[q];
+        const ncclResult_t r = rccl().Broadcast(q == comm->rank ? d_send : dst, dst, recv_bytes[q], ncclUint8, q, comm->comm,
+                                                comm->ctx->stream);
+        if (r != ncclSuccess && first == ncclSuccess) first = r;
+    }
+    const ncclResult_t end = rccl().GroupEnd();  // always closed: an open group would swallow the next call
+    if (first != ncclSuccess) return mhx::fail(MHX_ERR_COMM, "ncclBroadcast failed: %s", rccl().GetErrorString(first));
+    if (end != ncclSuccess) return mhx::fail(MHX_ERR_COMM, "ncclGroupEnd failed: %s", rccl().GetErrorString(end));
     return MHX_OK;
 }
 

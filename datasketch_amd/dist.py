@@ -19,7 +19,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
-import weakref
+import os
+import secrets
 
 import numpy as np
 
@@ -110,10 +111,11 @@ def communicator(ctx, group):
 class GatheredSignatures:
     """The all-gathered signature matrix, resident on this rank's GPU: ``buffer`` holds ``[rows, k]`` uint32
     (row-major, rank order).  Feed ``buffer.ptr`` to the ``*_dev`` entry points that take ``sig_dtype =
-    MHX_U32`` (b-bit packing, band digests, LSH sort), or :meth:`to_host` for a numpy matrix."""
+    MHX_U32`` (b-bit packing, band digests, LSH sort), or :meth:`to_host` for a numpy matrix.
+    ``transport`` names how the shards travelled: ``"rccl"``, ``"host-shm"``, ``"host-tcp"`` or ``"none"`` (one rank)."""
 
-    def __init__(self, ctx, buffer, rows: int, k: int):
-        self.ctx, self.buffer, self.rows, self.k = ctx, buffer, int(rows), int(k)
+    def __init__(self, ctx, buffer, rows: int, k: int, transport: str = "none"):
+        self.ctx, self.buffer, self.rows, self.k, self.transport = ctx, buffer, int(rows), int(k), transport
 
     def to_host(self, dtype=np.uint64) -> np.ndarray:
         self.ctx.synchronize()
@@ -121,33 +123,138 @@ class GatheredSignatures:
         return m if np.dtype(dtype) == np.uint32 else m.astype(dtype)
 
 
-def allgather_signatures_dev(ctx, d_local, rows: int, k: int, counts: Sequence[int], group) -> GatheredSignatures:
+TRANSPORTS = ("rccl", "host")
+
+
+def allgather_transport(transport: Optional[str] = None) -> str:
+    """``"rccl"`` (the default: RCCL over xGMI, one GPU per rank) or ``"host"`` -- an explicit opt-in, by argument or
+    ``MHX_ALLGATHER_TRANSPORT=host``, never chosen silently: the shards are staged through host memory (D2H, shared
+    memory or the TCP rendezvous, H2D), which is the one transport that lets several ranks share a GPU (RCCL refuses
+    two ranks on one device) and so lets a 1-GPU box run every line of the N > 1 path."""
+    t = (transport or os.environ.get("MHX_ALLGATHER_TRANSPORT") or "rccl").strip().lower()
+    if t not in TRANSPORTS:
+        raise ValueError(f"all-gather transport {t!r}: one of {TRANSPORTS}")
+    return t
+
+
+_HOST_PIECE = 256 << 20  # bytes per rank and TCP frame of the host transport (frames are bounded: rendezvous.MAX_FRAME)
+_FORCE_TCP = False        # tests: take the socket path although every rank is on this node
+
+
+def _node_identity() -> bytes:
+    boot = ""
+    try:
+        with open("/proc/sys/kernel/random/boot_id") as f:
+            boot = f.read().strip()
+    except OSError:
+        pass
+    import socket
+
+    return f"{socket.gethostname()}|{boot}|{os.stat('/dev/shm').st_dev if os.path.isdir('/dev/shm') else -1}".encode()
+
+
+def _allgather_host(ctx, d_local, d_all, counts: Sequence[int], row_bytes: int, group) -> str:
+    """The host-staged exchange: this rank's shard leaves the device once (into a /dev/shm file when every rank is on
+    this node, else over the rendezvous sockets in bounded pieces) and every other rank's shard is uploaded straight
+    to its place in ``d_all`` -- unequal shards need no padding.  Blocking; returns ``"host-shm"`` or ``"host-tcp"``."""
+    import mmap
+
+    world, rank = group.world, group.rank
+    offs = np.concatenate([[0], np.cumsum([int(c) * row_bytes for c in counts])]).astype(np.int64)
+    mine = int(counts[rank]) * row_bytes
+    ctx.synchronize()  # the shard is complete before it is read
+    same_node = len(set(group.allgather(_node_identity()))) == 1 and os.path.isdir("/dev/shm") and not _FORCE_TCP
+    if mine:
+        ctx.copy_dev(d_all.ptr + int(offs[rank]), d_local.ptr, mine)
+    if same_node:
+        path, fd, mem = b"", -1, None
+        err = b""
+        try:
+            if mine:
+                name = f"/dev/shm/mhx_gather_{os.getuid()}_{os.getpid()}_{secrets.token_hex(8)}"
+                fd = os.open(name, os.O_RDWR | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
+                path = name.encode()
+                os.ftruncate(fd, mine)
+                mem = mmap.mmap(fd, mine)
+                d_local.download_into(np.frombuffer(mem, dtype=np.uint8))
+        except OSError as e:
+            err = repr(e).encode()
+        try:
+            names = group.allgather(b"E" + err if err else b"P" + path)  # (also the barrier: every file is complete)
+            bad = [n[1:].decode("utf-8", "replace") for n in names if n[:1] == b"E"]
+            if bad:
+                raise OSError(f"host all-gather: a rank could not stage its shard in /dev/shm: {bad}")
+            for q in range(world):
+                size = int(counts[q]) * row_bytes
+                if q == rank or size == 0:
+                    continue
+                qfd = os.open(names[q][1:].decode(), os.O_RDONLY | getattr(os, "O_NOFOLLOW", 0))
+                try:
+                    with mmap.mmap(qfd, size, prot=mmap.PROT_READ) as view:
+                        d_all.upload(np.frombuffer(view, dtype=np.uint8), offset=int(offs[q]))
+                finally:
+                    os.close(qfd)
+            ctx.synchronize()
+            group.barrier()  # every rank has read every file
+        finally:
+            if mem is not None:
+                mem.close()
+            if fd >= 0:
+                os.close(fd)
+            if path:
+                try:
+                    os.unlink(path.decode())
+                except OSError:
+                    pass
+        return "host-shm"
+    sizes = [int(c) * row_bytes for c in counts]
+    step = max(1, min(_HOST_PIECE, (rendezvous.MAX_FRAME // 2) // world))  # rank 0 answers with all the pieces in one frame
+    for lo in range(0, max(sizes), step):
+        n_mine = max(0, min(step, mine - lo))
+        piece = d_local.download((n_mine,), np.uint8, offset=lo).tobytes() if n_mine else b""
+        parts = group.allgather(piece)
+        for q in range(world):
+            if q != rank and parts[q]:
+                d_all.upload(np.frombuffer(parts[q], dtype=np.uint8), offset=int(offs[q]) + lo)
+    ctx.synchronize()
+    return "host-tcp"
+
+
+def allgather_signatures_dev(ctx, d_local, rows: int, k: int, counts: Sequence[int], group,
+                             transport: Optional[str] = None) -> GatheredSignatures:
     """Device path of :func:`allgather_signatures`: ``d_local`` is a DeviceBuffer holding this rank's
-    ``[rows, k]`` **uint32** shard (the compact output type of ``mhx_minhash_bulk_dev``) with capacity
-    for ``max(counts)`` rows.  One RCCL all-gather of the padded shards; when the shards are unequal the
-    padding is squeezed out with ``world`` device-to-device copies.  Nothing comes back to the host."""
+    ``[rows, k]`` **uint32** shard (the compact output type of ``mhx_minhash_bulk_dev``).  The result is the
+    ``[sum(counts), k]`` matrix in rank order on this rank's GPU; nothing comes back to the host.
+
+    ``transport="rccl"`` (default): one ``ncclAllGather`` when the shards are equal, else one grouped launch of
+    per-root broadcasts (``mhx_comm_allgatherv_dev``) that writes every shard at its final place -- no padded
+    buffer, no squeeze copies, no host synchronisation; enqueued on the context's stream.
+    ``transport="host"``: see :func:`allgather_transport` (explicit opt-in; blocking)."""
     world = len(counts)
-    width = max(counts)
+    counts = [int(c) for c in counts]
     total = int(sum(counts))
+    if world != group.world:
+        raise ValueError("counts has one entry per rank")
     if rows != counts[group.rank]:
         raise ValueError("rows differs from this rank's entry of counts")
-    comm = communicator(ctx, group)
+    transport = allgather_transport(transport)
     row_bytes = k * 4
-    d_all = ctx.alloc(max(1, world * width * row_bytes))
-    comm.allgather_dev(d_local.ptr, d_all.ptr, width * row_bytes)
-    if all(c == width for c in counts):
-        return GatheredSignatures(ctx, d_all, total, k)
-    d_packed = ctx.alloc(max(1, total * row_bytes))
-    pos = 0
-    for r in range(world):
-        ctx.copy_dev(d_packed.ptr + pos * row_bytes, d_all.ptr + r * width * row_bytes, counts[r] * row_bytes)
-        pos += counts[r]
-    ctx.synchronize()  # d_all is released on return: the copies must have read it
-    return GatheredSignatures(ctx, d_packed, total, k)
+    d_all = ctx.alloc(max(1, total * row_bytes))
+    if transport == "host":
+        used = _allgather_host(ctx, d_local, d_all, counts, row_bytes, group)
+        return GatheredSignatures(ctx, d_all, total, k, used)
+    comm = communicator(ctx, group)
+    if all(c == counts[0] for c in counts):
+        comm.allgather_dev(d_local.ptr, d_all.ptr, counts[0] * row_bytes)
+    else:
+        sizes = [c * row_bytes for c in counts]
+        comm.allgatherv_dev(d_local.ptr, d_all.ptr, [sum(sizes[:q]) for q in range(world)], sizes)
+    return GatheredSignatures(ctx, d_all, total, k, "rccl")
 
 
 def bulk_signatures_sharded(local_tokens, *, num_perm: int, seed: int = 1, gpu_mode: str = "always", group=None,
-                            counts: Optional[Sequence[int]] = None, keep_on_device: bool = False):
+                            counts: Optional[Sequence[int]] = None, keep_on_device: bool = False,
+                            transport: Optional[str] = None):
     """Config-3 shape: every rank hashes ITS OWN rows -- ``local_tokens`` is this rank's dense ``[n_r, T]``
     array of pre-hashed tokens (uint32 or uint64), or a callable returning it (so that a rank only ever
     materialises its own shard) -- and the shards are all-gathered; every rank gets the full ``[N, K]``
@@ -155,7 +262,8 @@ def bulk_signatures_sharded(local_tokens, *, num_perm: int, seed: int = 1, gpu_m
 
     With a GPU the shard stays on the device from the kernel to the RCCL all-gather (uint32 on the wire).
     ``keep_on_device=True`` returns a :class:`GatheredSignatures` (for the pack / digest / sort chain) instead
-    of a host uint64 matrix.  ``gpu_mode='disable'`` is the numpy path with the host stand-in collective."""
+    of a host uint64 matrix.  ``transport``: see :func:`allgather_transport` (``"host"`` is the explicit opt-in
+    that lets several ranks share one GPU).  ``gpu_mode='disable'`` is the numpy path with the host stand-in collective."""
     from datasketch_amd import _native
     from datasketch_amd.hashfunc import prehashed
     from datasketch_amd.minhash import MinHash
@@ -184,10 +292,10 @@ def bulk_signatures_sharded(local_tokens, *, num_perm: int, seed: int = 1, gpu_m
     tok_code = _native.MHX_U32 if shard.dtype == np.uint32 else _native.MHX_U64
     n_local, t = shard.shape
     d_tok = ctx.to_device(shard)
-    d_out = ctx.alloc(max(1, max(counts) * num_perm * 4))
+    d_out = ctx.alloc(max(1, n_local * num_perm * 4))
     ctx.minhash_bulk_dev(proto.permutations, d_tok.ptr, tok_code, None, t, n_local, shard.size, None, 0, d_out.ptr, _native.MHX_U32)
     if g.world == 1:
         gathered = GatheredSignatures(ctx, d_out, n_local, num_perm)
     else:
-        gathered = allgather_signatures_dev(ctx, d_out, n_local, num_perm, counts, g)
+        gathered = allgather_signatures_dev(ctx, d_out, n_local, num_perm, counts, g, transport=transport)
     return gathered if keep_on_device else gathered.to_host(np.uint64)

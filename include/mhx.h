@@ -407,6 +407,12 @@ MHX_API int mhx_comm_info(mhx_comm *comm, int *rank, int *world_size, int *devic
  * d_recv receives world_size*bytes_per_rank bytes in rank order.  Enqueued on the ctx stream. */
 MHX_API int mhx_comm_allgather_dev(mhx_comm *comm, const void *d_send, void *d_recv,
                                    size_t bytes_per_rank);
+/* All-gather of UNEQUAL row shards, in place: rank q contributes recv_bytes[q] bytes (its own entry from d_send),
+ * and every rank receives them at d_recv + recv_offsets[q].  recv_offsets / recv_bytes: host arrays of world_size
+ * entries, identical on every rank (shard sizes are common knowledge: SURVEY.md section 8e "AllGatherv-style with
+ * per-rank counts").  One grouped launch of ncclBroadcast per root; enqueued on the ctx stream, no host sync. */
+MHX_API int mhx_comm_allgatherv_dev(mhx_comm *comm, const void *d_send, void *d_recv,
+                                    const uint64_t *recv_offsets, const uint64_t *recv_bytes);
 
 #ifdef __cplusplus
 }

@@ -316,3 +316,96 @@ def test_rendezvous_frame_cap_and_cleanup_on_failure(tmp_path, monkeypatch):
     os.chmod(d, 0o755)
     with pytest.raises(PermissionError):
         rendezvous._publish_dir()
+
+
+# ---- the host-staged all-gather transport (dist._allgather_host) on stand-in device buffers ----------------------
+class _FakeBuffer:
+    """The four members of _native.DeviceBuffer the transport uses, over one bytearray 'device memory' per context."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        self.ptr = len(ctx.mem)
+        ctx.mem.extend(b"\xEE" * self.nbytes)
+
+    def upload(self, arr, offset=0):
+        raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+        assert offset + raw.size <= self.nbytes
+        self.ctx.mem[self.ptr + offset: self.ptr + offset + raw.size] = raw.tobytes()
+        return self
+
+    def download(self, shape, dtype, offset=0):
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        assert offset + n <= self.nbytes
+        return np.frombuffer(bytes(self.ctx.mem[self.ptr + offset: self.ptr + offset + n]), dtype=dtype).reshape(shape).copy()
+
+    def download_into(self, out, offset=0):
+        out[...] = self.download(out.shape, out.dtype, offset)
+        return out
+
+
+class _FakeContext:
+    def __init__(self):
+        self.mem = bytearray()
+
+    def alloc(self, nbytes):
+        return _FakeBuffer(self, nbytes)
+
+    def copy_dev(self, dst, src, nbytes):
+        self.mem[dst: dst + nbytes] = self.mem[src: src + nbytes]
+
+    def synchronize(self):
+        pass
+
+
+@pytest.mark.parametrize("force_tcp", [False, True])
+@pytest.mark.parametrize("counts", [[5, 5, 5], [7, 0, 3], [1, 9, 4]])
+def test_host_staged_allgather_places_every_shard(force_tcp, counts, monkeypatch):
+    """Three ranks (threads), equal and unequal shards (one empty), over /dev/shm files and over the sockets in pieces
+    smaller than a shard: every rank ends up with the [sum(counts), k] uint32 matrix in rank order, and no staging
+    file is left behind."""
+    import glob
+    import threading
+
+    from datasketch_amd import dist, rendezvous
+
+    monkeypatch.setattr(dist, "_FORCE_TCP", force_tcp)
+    monkeypatch.setattr(dist, "_HOST_PIECE", 64)  # several pieces per shard on the socket path
+    k, world, port = 6, 3, _free_port()
+    shards = [np.random.RandomState(90 + r).randint(0, 2**32, (counts[r], k), dtype=np.uint64).astype(np.uint32) for r in range(world)]
+    want = np.concatenate(shards)
+    before = set(glob.glob("/dev/shm/mhx_gather_*"))
+    res, errors = {}, []
+
+    def run(rank):
+        try:
+            with rendezvous.Group(rank, world, "127.0.0.1", port, timeout=30) as g:
+                ctx = _FakeContext()
+                d_local = ctx.alloc(max(1, shards[rank].nbytes)).upload(shards[rank])
+                got = dist.allgather_signatures_dev(ctx, d_local, counts[rank], k, counts, g, transport="host")
+                res[rank] = (got.transport, got.to_host(np.uint32))
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    assert not errors, errors
+    for r in range(world):
+        transport, m = res[r]
+        assert transport == ("host-tcp" if force_tcp else "host-shm")
+        assert np.array_equal(m, want)
+    assert set(glob.glob("/dev/shm/mhx_gather_*")) == before
+
+
+def test_allgather_transport_is_an_explicit_choice(monkeypatch):
+    from datasketch_amd import dist
+
+    monkeypatch.delenv("MHX_ALLGATHER_TRANSPORT", raising=False)
+    assert dist.allgather_transport() == "rccl"            # never host by default
+    monkeypatch.setenv("MHX_ALLGATHER_TRANSPORT", "host")
+    assert dist.allgather_transport() == "host"
+    assert dist.allgather_transport("rccl") == "rccl"      # the argument wins
+    with pytest.raises(ValueError):
+        dist.allgather_transport("carrier-pigeon")
