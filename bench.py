@@ -63,6 +63,13 @@ def parse_args(argv=None):
     ap.add_argument("--no-e2e", action="store_true", help="skip the PCIe-inclusive host->host measurement")
     ap.add_argument("--no-extra", action="store_true", help="skip the config 3/4/5 entries (N=1 only anyway)")
     ap.add_argument("--extra-only", default="", help="comma list out of c3,c4,c5 (default: all)")
+    ap.add_argument("--full-only", action="store_true", help="N=1: only configs 3 and 5 at their stated size (10M x 256, num_perm=256) with every check, one JSON line")
+    ap.add_argument("--full-rows", type=int, default=10_000_000, help="rows of the full-size configs 3 / 5 (tests shrink it)")
+    ap.add_argument("--allgather-transport", default=None, choices=["rccl", "host"],
+                    help="N > 1: how the uint32 shards travel (default rccl over xGMI; host = staged through host memory, the explicit opt-in "
+                         "that lets ranks share one GPU -- labelled in the JSON line, never chosen silently)")
+    ap.add_argument("--no-c3-sharded", action="store_true", help="N > 1: skip extra.c3_sharded (config 3 end to end across the ranks)")
+    ap.add_argument("--c3-rows", type=int, default=1_250_000, help="N > 1: rows per rank of extra.c3_sharded")
     ap.add_argument("--u32", action="store_true", help="compact variant: uint32 tokens in, uint32 signatures out")
     ap.add_argument("--share-devices", action="store_true", help="testing only: let several ranks use one GPU (no RCCL then)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="libmhx tuning knob (mhx_ctx_set_option), e.g. blocks_per_cu=4")
@@ -128,6 +135,14 @@ def main():
     def sync():
         ctx.synchronize()
 
+    if args.full_only:
+        if world != 1:
+            raise SystemExit("--full-only is a single-GPU run")
+        res = extra_full(ctx, args.full_rows, args.seed, checks="all")
+        print(json.dumps({"metric": "configs 3 and 5 at their stated size on one GPU (every check)", "n_gpus": 1, "data": "synthetic",
+                          "guard_alloc": os.environ.get("MHX_GUARD_ALLOC"), "extra": res}), flush=True)
+        return
+
     n, t, k = args.sets, args.tokens, args.num_perm
     proto = MinHash(num_perm=k, seed=args.seed, hashfunc=lambda x: x)
     perms = proto.permutations
@@ -162,9 +177,12 @@ def main():
 
     gather = None
     gather_error = None
+    from datasketch_amd import dist as _dist
+
+    transport = _dist.allgather_transport(args.allgather_transport)
     if args.allgather and world > 1:
         try:
-            gather = AllGather(ctx, group, n, k)
+            gather = AllGather(ctx, group, n, k, transport)
         except Exception as e:  # noqa: BLE001 -- RCCL trouble must not take the compute numbers down with it
             gather_error = repr(e)
         if any(group.allgather(b"\x01" if gather is None else b"\x00")[r] == b"\x01" for r in range(world)):
@@ -260,6 +278,7 @@ def main():
             "token_dtype": "uint32" if args.u32 else "uint64",
             "signature_dtype": "uint32" if args.u32 else "uint64",
             "parallelism": f"shard{world}" + ("+allgather" if gather is not None else ""),
+            "allgather_transport": transport if world > 1 else None,
             "launcher": "torch.distributed.run env" if "TORCHELASTIC_RUN_ID" in os.environ else ("self-spawned ranks" if world > 1 else "single process"),
             "rendezvous": "datasketch_amd.rendezvous (TCP, no PyTorch)",
             "parity_rows_checked": int(check),
@@ -301,7 +320,9 @@ def main():
 
         def give_up():
             if rank == 0:
-                out["allgather"] = {"error": f"RCCL all-gather probe did not finish within {args.probe_timeout:.0f} s"}
+                out.setdefault("allgather", {"error": f"the all-gather probe did not finish within {args.probe_timeout:.0f} s"})
+                if "allgather" in out and "error" not in out["allgather"]:
+                    out.setdefault("extra", {})["c3_sharded"] = {"error": f"did not finish within {args.probe_timeout:.0f} s"}
                 print(json.dumps(out), flush=True)
             os._exit(0)
 
@@ -309,8 +330,15 @@ def main():
         dog.daemon = True
         dog.start()
         try:
-            out["allgather"] = allgather_probe(ctx, group, gather, perms, d_tok, tok_dtype, n, t, k)
+            out["allgather"] = allgather_probe(ctx, group, gather, perms, d_tok, tok_dtype, n, t, k, transport=transport)
             out["per_rank"]["rccl_ranks_seen"] = out["allgather"].get("rccl_ranks_seen")  # ncclCommCount as every rank reports it
+            if not args.no_c3_sharded and not args.u32 and "error" not in out["allgather"]:
+                dog.cancel()
+                dog = threading.Timer(args.probe_timeout, give_up)  # a fresh allowance for the second collective phase
+                dog.daemon = True
+                dog.start()
+                d_out.free()
+                out.setdefault("extra", {})["c3_sharded"] = c3_sharded(ctx, group, args, d_tok, n, t, check_rows_idx, check_tokens)
         except (ConnectionError, TimeoutError, OSError) as e:  # a peer left (its own watchdog, or a crash inside RCCL)
             out["allgather"] = {"error": repr(e)}
             if rank == 0:
@@ -344,8 +372,13 @@ def main():
             out["cpu_baseline"] = cpu_baseline(tokens, a, b, min(args.cpu_sample, n), k, t, sig_head, seed=args.seed)
         if not args.no_extra:
             d_out.free()
-            only = [x for x in args.extra_only.split(",") if x] or ["c3", "c5", "c4"]
+            only = [x for x in args.extra_only.split(",") if x] or ["c3", "c5", "c4", "full"]
             out["extra"] = extra_configs(ctx, tokens, d_tok, args.seed, only)
+            if "full" in only:  # configs 3 and 5 at their stated size (10M rows) on this one GPU
+                d_tok.free()
+                del tokens
+                ctx.release_scratch()
+                out["extra"].update(extra_full(ctx, args.full_rows, args.seed, checks="sample"))
     group.barrier()
     group.close()
     if rank == 0:
@@ -369,30 +402,36 @@ def measured_traffic(n, t, k, args, field="traffic_bytes_per_launch"):
 
 # ------------------------------------------------------------------------------------------------
 class AllGather:
-    """RCCL all-gather of this rank's uint32 [n, k] signature shard into a [world, n, k] device buffer, through
-    libmhx's own binding (mhx_comm_*): enqueued on the kernel's stream.  The 128-byte RCCL id travels over the
-    rendezvous group."""
+    """All-gather of this rank's uint32 [n, k] signature shard into a [world, n, k] device buffer.  transport "rccl": RCCL
+    through libmhx's own binding (mhx_comm_*), enqueued on the kernel's stream, the 128-byte id travelling over the
+    rendezvous group; "host": the explicit host-staged stand-in (datasketch_amd.dist.allgather_transport), blocking."""
 
-    def __init__(self, ctx, group, n, k):
+    def __init__(self, ctx, group, n, k, transport="rccl"):
         from datasketch_amd import dist
 
-        self.ctx, self.group, self.n, self.k = ctx, group, n, k
-        self.comm = dist.communicator(ctx, group)
+        self.ctx, self.group, self.n, self.k, self.transport = ctx, group, n, k, transport
+        self.comm = dist.communicator(ctx, group) if transport == "rccl" else None
         self.shard_bytes = n * k * 4
         self.d_shard = ctx.alloc(self.shard_bytes)
         self.d_all = ctx.alloc(self.shard_bytes * group.world)
+        self.used = transport
 
     def step(self, perms, d_tok, tok_dtype, t):
         from datasketch_amd import _native
 
         self.ctx.minhash_bulk_dev(perms, d_tok.ptr, tok_dtype, None, t, self.n, self.n * t, None, 0, self.d_shard.ptr, _native.MHX_U32)
-        self.comm.allgather_dev(self.d_shard.ptr, self.d_all.ptr, self.shard_bytes)
+        self.gather_only()
 
     def gather_only(self):
-        self.comm.allgather_dev(self.d_shard.ptr, self.d_all.ptr, self.shard_bytes)
+        if self.comm is not None:
+            self.comm.allgather_dev(self.d_shard.ptr, self.d_all.ptr, self.shard_bytes)
+        else:
+            from datasketch_amd import dist
+
+            self.used = dist._allgather_host(self.ctx, self.d_shard, self.d_all, [self.n] * self.group.world, self.k * 4, self.group)
 
 
-def allgather_probe(ctx, group, gather, perms, d_tok, tok_dtype, n, t, k, reps=5):
+def allgather_probe(ctx, group, gather, perms, d_tok, tok_dtype, n, t, k, reps=5, transport="rccl"):
     """The exchange step alone: every rank's uint32 shard to every rank.  Reports what RCCL itself says about the
     communicator and checks the gathered matrix: row 0 of every rank's block must be that rank's row 0."""
     from datasketch_amd import _native
@@ -401,7 +440,7 @@ def allgather_probe(ctx, group, gather, perms, d_tok, tok_dtype, n, t, k, reps=5
     err = None
     try:
         if gather is None:
-            gather = AllGather(ctx, group, n, k)
+            gather = AllGather(ctx, group, n, k, transport)
         ctx.minhash_bulk_dev(perms, d_tok.ptr, tok_dtype, None, t, n, n * t, None, 0, gather.d_shard.ptr, _native.MHX_U32)
         gather.gather_only()  # warm-up (RCCL builds its rings / channels on first use)
         ctx.synchronize()
@@ -420,7 +459,9 @@ def allgather_probe(ctx, group, gather, perms, d_tok, tok_dtype, n, t, k, reps=5
     ctx.synchronize()
     ms = [evs[i].elapsed_ms(evs[i + 1]) for i in range(reps)]
     all_ms = [float(np.frombuffer(p, dtype=np.float64)[0]) for p in group.allgather(np.float64(np.mean(ms)).tobytes())]
-    info = gather.comm.info()
+    res["transport"] = gather.used
+    # what RCCL itself says about the communicator; the host-staged stand-in has none: its ranks are the rendezvous group's
+    info = gather.comm.info() if gather.comm is not None else {"ranks_seen": -1, "rank": group.rank, "device": ctx.device, "rccl_version": None}
     seen = group.allgather_ints([info["ranks_seen"], info["rank"], info["device"]])
     my_row0 = gather.d_shard.download((k,), np.uint32)
     rows0 = [np.frombuffer(p, dtype=np.uint32) for p in group.allgather(my_row0.tobytes())]
@@ -435,10 +476,11 @@ def allgather_probe(ctx, group, gather, perms, d_tok, tok_dtype, n, t, k, reps=5
     res.update({
         "ms": worst,
         "ms_per_rank": all_ms,
-        "rccl_ranks_seen": [s[0] for s in seen],
+        "rccl_ranks_seen": [s[0] for s in seen] if gather.comm is not None else None,
         "rccl_rank_device": [[s[1], s[2]] for s in seen],
         "rccl_version": info["rccl_version"],
         "received_GBps_per_gpu": res["bytes_received_per_gpu"] / (worst * 1e-3) / 1e9,
+        "xgmi_bound_GBps_per_gpu": XGMI_LINKS * XGMI_GBPS_PER_LINK,
         "signatures_per_s_with_allgather_after_compute": None,
         "checked": "row 0 of every rank's block on every rank",
     })
@@ -713,15 +755,34 @@ def extra_configs(ctx, tokens, d_tok, seed, only):
         a3, b3 = st["perms3"]
         want = O.c_minhash_bulk_dense(tok, a3, b3)
         pack = d_pack.download((n3, nb), np.uint64)
+        dig = d_dig.download((n3, bands), np.uint64)
         if not np.array_equal(pack[rows], O.c_bbit_pack(want, 1)):
             raise SystemExit("PARITY FAILURE (extra.c5): b=1 blocks differ from the oracle's bBitMinHash packing")
-        del pack
+        # the same two outputs from ONE read of the matrix (bbit_digest_fused_kernel), over buffers cleared in between
+        import ctypes as _ct
+
+        for d in (d_pack, d_dig):
+            _native.check(lib.mhx_memset_dev(ctx.handle, _ct.c_void_p(d.ptr), 0, d.nbytes))
+        one_read = []
+        ms_fused = _timed(ctx, lambda: one_read.append(ctx.bbit_pack_band_digests_dev(dsig.ptr, _native.MHX_U32, n3, k3, 1, bands, r, d_pack.ptr, d_dig.ptr)))
+        if not (np.array_equal(d_pack.download((n3, nb), np.uint64), pack) and np.array_equal(d_dig.download((n3, bands), np.uint64), dig)):
+            raise SystemExit("PARITY FAILURE (extra.c5): the fused kernel's blocks / digests differ from the two kernels'")
+        keys = O.c_band_keys(want[:64], bands, r)
+        for i in range(64):
+            for j in range(bands):
+                if int(dig[rows[i], j]) != _fnv1a64(keys[i, j * r:(j + 1) * r].tobytes()):
+                    raise SystemExit("PARITY FAILURE (extra.c5): band digest differs from FNV-1a-64 of the reference's key bytes")
+        del pack, dig
         res["c5"] = {
             "workload": f"config 5 per-GPU shard: b=1 packing of {n3} x {k3} signatures (uint32, as all-gathered) + LSH band hashing ({bands} x {r})",
+            "fused": dict(_roof(n3 * (4 * k3 + k3 // 8 + 8 * bands), ms_fused), one_read=bool(one_read and all(one_read)),
+                          kernel="bbit_digest_fused_kernel: blocks and digests from one read of the matrix (algorithmic bytes: 4K in, K/8 + 8*bands out)"),
             "bbit_pack_b1": _roof(n3 * (4 * k3 + k3 // 8), ms_pack),
             "band_digests": _roof(n3 * (4 * k3 + 8 * bands), ms_dig),
-            "pipeline_ms": ms_pack + ms_dig,
-            "parity": f"{len(rows)} packed rows vs the C oracle (b_bit_minhash.py:82-101 bit order)",
+            "pipeline_ms": ms_fused,
+            "pipeline_ms_two_kernels": ms_pack + ms_dig,
+            "parity": f"{len(rows)} packed rows vs the C oracle (b_bit_minhash.py:82-101 bit order), 64 x {bands} digests vs FNV-1a-64 of the reference's key "
+                      f"bytes, and the fused kernel's outputs equal to the two kernels' on all {n3} rows",
         }
         d_pack.free()
         d_dig.free()
@@ -734,6 +795,257 @@ def extra_configs(ctx, tokens, d_tok, seed, only):
     if "c4" in only:
         res["c4"] = extra_c4(ctx)
     return res
+
+
+# ------------------------------------------------------------------------------------------------
+XGMI_LINKS, XGMI_GBPS_PER_LINK = 7, 153.0  # 7 point-to-point links per GPU
+
+
+def full_corpus(ctx, n, t, shards=8, piece=50_000, sample=4096):
+    """Config 3's corpus, resident in HBM: shard q = RandomState(42 + q).randint(0, 2**32, (rows_q, t), uint64) (SURVEY.md
+    section 8d), drawn by one host thread per shard (numpy releases the GIL inside the draw) in pieces of 50k sets that
+    go up as they are made -- 20.5 GB on the device, 100 MB per thread on the host.  Returns the device buffer, `sample`
+    row numbers spread over the whole corpus and their tokens (what the oracle will be given)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from datasketch_amd.dist import shard_rows
+
+    d_tok = ctx.alloc(n * t * 8)
+    rows = np.unique(np.concatenate([np.linspace(0, n - 1, sample).astype(np.int64), [0, n - 1]]))
+
+    def make(q):
+        b, e = shard_rows(n, shards, q)
+        rng = np.random.RandomState(42 + q)
+        kept = []
+        for lo in range(b, e, piece):
+            m = min(piece, e - lo)
+            part = rng.randint(0, 2**32, size=(m, t), dtype=np.uint64)
+            sel = rows[(rows >= lo) & (rows < lo + m)]
+            kept.append(part[sel - lo].copy())
+            d_tok.upload(part, offset=lo * t * 8)
+        return np.concatenate(kept) if kept else np.empty((0, t), dtype=np.uint64)
+
+    with ThreadPoolExecutor(max(1, min(shards, _usable_cores()))) as pool:
+        sample_tokens = np.concatenate(list(pool.map(make, range(shards))))
+    return d_tok, rows, sample_tokens
+
+
+def _download_rows(buf, rows, width, dtype):
+    """The given rows of a row-major device matrix (one small copy per row: a few thousand rows of a 10 GB matrix)."""
+    item = np.dtype(dtype).itemsize
+    return np.stack([buf.download((width,), dtype, offset=int(r) * width * item) for r in rows]) if len(rows) else np.empty((0, width), dtype)
+
+
+def extra_full(ctx, n, seed, checks="sample", t=256, k=256, bands=32, r=8):
+    """BASELINE.json configs[2] and [4] at their STATED size on one GPU (an 8-GPU job holds exactly this on every GPU after
+    the all-gather): n = 10M sets x 256 tokens (2.56e9 tokens: past 2^31 elements in every kernel), num_perm = 256 ->
+    uint32 signatures (10.2 GB) -> band digests (32 x 8) -> bucketing of 320M (band, digest) keys; b = 1 blocks + band
+    digests of the same matrix from one read.  checks = "sample": the spread sample rows against the C oracle at every
+    stage, four bands of the sorted output in full; "all": every band, the fused outputs against the two kernels'
+    everywhere, the bucketing against the stable radix sort everywhere."""
+    from datasketch_amd import _native, lsh_bulk
+    from datasketch_amd.minhash import MinHash
+    from oracle import oracle as O
+
+    lib = ctx.lib
+    t0 = time.perf_counter()
+    d_tok, rows, tok = full_corpus(ctx, n, t)
+    gen_s = time.perf_counter() - t0
+    perms = MinHash(num_perm=k, seed=seed, hashfunc=lambda x: x).permutations
+    nb = k // 64
+    d_sig = ctx.alloc(n * k * 4)
+    ms_sig = _timed(ctx, lambda: ctx.minhash_bulk_dev(perms, d_tok.ptr, _native.MHX_U64, None, t, n, n * t, None, 0, d_sig.ptr, _native.MHX_U32), reps=2, ramp=0.1)
+    d_tok.free()
+    d_dig, d_sd, d_sr = ctx.alloc(n * bands * 8), ctx.alloc(n * bands * 8), ctx.alloc(n * bands * 4)
+    ms_dig = _timed(ctx, lambda: _native.check(lib.mhx_band_digests_dev_typed(ctx.handle, d_sig.ptr, _native.MHX_U32, n, k, bands, r, d_dig.ptr)), reps=3, ramp=0.1)
+    sort_dig = lambda: _native.check(lib.mhx_lsh_sort_digests_dev(ctx.handle, d_dig.ptr, n, bands, d_sd.ptr, d_sr.ptr))
+    ms_sort = _timed(ctx, sort_dig, reps=3, ramp=0.1)
+    # ---- parity, config 3
+    a, b = perms
+    want = O.c_minhash_bulk_dense(tok, a, b)
+    if not np.array_equal(_download_rows(d_sig, rows, k, np.uint32).astype(np.uint64), want):
+        raise SystemExit("PARITY FAILURE (extra.c3_full): signatures differ from the oracle")
+    want_dig = lsh_bulk.band_digests(want, bands, r, gpu_mode="disable")  # FNV-1a-64 of the reference's key bytes (lsh.py:537-538), numpy
+    for i in range(8):
+        keys = O.c_band_keys(want[i: i + 1], bands, r)
+        if int(want_dig[i, bands - 1]) != _fnv1a64(keys[0, (bands - 1) * r:].tobytes()):
+            raise SystemExit("PARITY FAILURE (extra.c3_full): the numpy digests differ from FNV-1a-64 of the key bytes")
+    if not np.array_equal(_download_rows(d_dig, rows, bands, np.uint64), want_dig):
+        raise SystemExit("PARITY FAILURE (extra.c3_full): band digests differ from FNV-1a-64 of the reference's key bytes")
+    dig = d_dig.download((n, bands), np.uint64)
+    check_bands = list(range(bands)) if checks == "all" else sorted({0, bands // 3, 2 * bands // 3, bands - 1})
+    for j in check_bands:
+        sd = d_sd.download((n,), np.uint64, offset=j * n * 8)
+        sr = d_sr.download((n,), np.uint32, offset=j * n * 4)
+        col = dig[:, j]
+        if np.any(sd[1:] < sd[:-1]) or not np.array_equal(col[sr.astype(np.int64)], sd):
+            raise SystemExit(f"PARITY FAILURE (extra.c3_full): band {j} is not the band's digests in ascending order")
+        tie = sd[1:] == sd[:-1]
+        if np.any(sr[1:][tie] <= sr[:-1][tie]) or np.unique(sr).size != n:
+            raise SystemExit(f"PARITY FAILURE (extra.c3_full): band {j}: rows not ascending inside a bucket, or not a permutation")
+    radix = None
+    if checks == "all":  # the whole output against the stable radix sort (the fallback path), every band
+        sd_all, sr_all = d_sd.download((bands, n), np.uint64), d_sr.download((bands, n), np.uint32)
+        ctx.set_option("lsh.sort", 1)
+        try:
+            radix = _timed(ctx, sort_dig, reps=1, ramp=0.0)
+            same = np.array_equal(d_sd.download((bands, n), np.uint64), sd_all) and np.array_equal(d_sr.download((bands, n), np.uint32), sr_all)
+        finally:
+            ctx.set_option("lsh.sort", 0)
+        del sd_all, sr_all
+        if not same:
+            raise SystemExit("PARITY FAILURE (extra.c3_full): the bucketing passes and the stable radix sort disagree")
+    for d in (d_sd, d_sr):
+        d.free()
+    ctx.release_scratch()
+    c3 = {
+        "workload": f"config 3 at its stated size on one GPU: {n} sets x {t} tokens ({n * t:.3e} tokens), num_perm={k} (uint64 tokens in, uint32 signatures out), "
+                    f"band digests ({bands} x {r}), bucketing of {n * bands} (band, digest) keys",
+        "signatures": dict(_roof(n * (8 * t + 4 * k), ms_sig), signatures_per_s=n / (ms_sig * 1e-3)),
+        "band_digests": _roof(n * (4 * k + 8 * bands), ms_dig),
+        "lsh_sort_digests": dict(_roof(n * (8 * bands + 12 * bands), ms_sort), keys_per_s=n * bands / (ms_sort * 1e-3)),
+        "pipeline_ms": ms_sig + ms_dig + ms_sort,
+        "corpus_seconds_on_host": gen_s,
+        "parity": f"{len(rows)} rows spread over the corpus: signatures vs the C oracle, {bands} digests each vs FNV-1a-64 of the reference's key bytes; "
+                  f"sorted bands {check_bands if checks != 'all' else 'all'}: ascending, equal to the digest column gathered by the sorted rows, rows ascending "
+                  f"inside every bucket, a permutation" + ("; all bands equal to the stable radix sort's" if radix is not None else ""),
+    }
+    if radix is not None:
+        c3["lsh_sort_digests_radix_ms"] = radix
+    # ---- config 5: b = 1 blocks + band digests of the same 10M x 256 matrix
+    d_blk, d_dig2 = ctx.alloc(n * nb * 8), ctx.alloc(n * bands * 8)
+    fused_flag = []
+    fused = lambda: fused_flag.append(ctx.bbit_pack_band_digests_dev(d_sig.ptr, _native.MHX_U32, n, k, 1, bands, r, d_blk.ptr, d_dig2.ptr))
+    ms_fused = _timed(ctx, fused, reps=3, ramp=0.1)
+    blk_rows = _download_rows(d_blk, rows, nb, np.uint64)
+    if not (np.array_equal(blk_rows, O.c_bbit_pack(want, 1)) and np.array_equal(_download_rows(d_dig2, rows, bands, np.uint64), want_dig)):
+        raise SystemExit("PARITY FAILURE (extra.c5_full): fused b=1 blocks / digests differ from the oracle")
+    if not np.array_equal(d_dig2.download((n, bands), np.uint64), dig):
+        raise SystemExit("PARITY FAILURE (extra.c5_full): the fused kernel's digests differ from band_digest_kernel's")
+    del dig
+    ms_pack = _timed(ctx, lambda: _native.check(lib.mhx_bbit_pack_dev_typed(ctx.handle, d_sig.ptr, _native.MHX_U32, n, k, 1, d_dig.ptr)), reps=3, ramp=0.1)  # (into d_dig: free by now)
+    if checks == "all" and not np.array_equal(d_dig.download((n, nb), np.uint64), d_blk.download((n, nb), np.uint64)):
+        raise SystemExit("PARITY FAILURE (extra.c5_full): the fused kernel's blocks differ from bbit1_wide_kernel's")
+    c5 = {
+        "workload": f"config 5 at its stated size on one GPU: b=1 packing of {n} x {k} signatures (uint32) + LSH band hashing ({bands} x {r})",
+        "fused": dict(_roof(n * (4 * k + k // 8 + 8 * bands), ms_fused), one_read=bool(fused_flag and all(fused_flag)),
+                      kernel="bbit_digest_fused_kernel: blocks and digests from one read of the matrix"),
+        "two_kernels_ms": ms_pack + ms_dig,
+        "bbit_pack_b1_ms": ms_pack,
+        "band_digests_ms": ms_dig,
+        "pipeline_ms": ms_fused,
+        "parity": f"{len(rows)} spread rows: blocks vs the C oracle (b_bit_minhash.py:82-101), digests vs FNV-1a-64 of the key bytes; all {n} x {bands} "
+                  f"digests equal to band_digest_kernel's" + (f"; all {n} x {nb} blocks equal to bbit1_wide_kernel's" if checks == "all" else ""),
+    }
+    for d in (d_sig, d_dig, d_blk, d_dig2):
+        d.free()
+    return {"c3_full": c3, "c5_full": c5}
+
+
+def c3_sharded(ctx, group, args, d_tok, n_head, t, check_rows_idx, check_tokens, k=256, bands=32, r=8):
+    """BASELINE.json configs[2] end to end across the ranks: every rank hashes ITS shard (num_perm = 256, uint32 out), the
+    shards are all-gathered (RCCL over xGMI; `--allgather-transport host` is the labelled stand-in that lets ranks share
+    a GPU), and the LSH index is built PARTITIONED BY BAND -- the reference keeps one independent hashtable per band
+    (lsh.py:199,326-347), so rank q digests and buckets bands [q*bands/world, (q+1)*bands/world) of ALL rows.  Per-stage
+    HIP-event / wall times on every rank; parity on every rank: its own rows of the gathered matrix and row 0 of every
+    other rank's block against the numpy path, its bands' digests of those rows, its first band's order."""
+    from datasketch_amd import _native, dist, lsh_bulk
+    from datasketch_amd.hashfunc import prehashed
+    from datasketch_amd.minhash import MinHash
+
+    lib, world, rank = ctx.lib, group.world, group.rank
+    n3 = args.c3_rows
+    res = {"workload": f"config 3 sharded: {world} ranks x {n3} sets x {t} tokens, num_perm={k} -> all-gather (uint32) -> band-partitioned LSH bucketing ({bands} x {r})"}
+    perms = MinHash(num_perm=k, seed=args.seed, hashfunc=lambda x: x).permutations
+    if n3 > n_head:  # the headline's corpus + more rows of the same kind
+        d3 = ctx.alloc(n3 * t * 8)
+        ctx.copy_dev(d3.ptr, d_tok.ptr, n_head * t * 8)
+        rng = np.random.RandomState(4242 + rank)
+        for lo in range(n_head, n3, 50_000):
+            d3.upload(rng.randint(0, 2**32, size=(min(50_000, n3 - lo), t), dtype=np.uint64), offset=lo * t * 8)
+    else:
+        d3 = d_tok
+    d_shard = ctx.alloc(n3 * k * 4)
+    sig_call = lambda: ctx.minhash_bulk_dev(perms, d3.ptr, _native.MHX_U64, None, t, n3, n3 * t, None, 0, d_shard.ptr, _native.MHX_U32)
+    ms_sig = _timed(ctx, sig_call, reps=3, ramp=0.1)
+    counts = [n3] * world
+    transport = dist.allgather_transport(args.allgather_transport)
+    err = b""
+    gathered = None
+    try:
+        gathered = dist.allgather_signatures_dev(ctx, d_shard, n3, k, counts, group, transport=transport)  # warm-up: communicator, rings
+        ctx.synchronize()
+    except Exception as e:  # noqa: BLE001 -- e.g. RCCL refusing ranks that share a device
+        err = repr(e).encode()
+    flags = group.allgather(err)
+    if any(flags):
+        res["error"] = [f.decode("utf-8", "replace") for f in flags]
+        return res
+    del gathered
+    group.barrier()
+    w0 = time.perf_counter()
+    gathered = dist.allgather_signatures_dev(ctx, d_shard, n3, k, counts, group, transport=transport)
+    ctx.synchronize()
+    ms_gather = 1e3 * (time.perf_counter() - w0)
+    total = world * n3
+    lo_band = rank * bands // world
+    hi_band = (rank + 1) * bands // world
+    nbl = hi_band - lo_band
+    ms_dig = ms_sort = 0.0
+    if nbl > 0:
+        d_dig, d_sd, d_sr = ctx.alloc(total * nbl * 8), ctx.alloc(total * nbl * 8), ctx.alloc(total * nbl * 4)
+        sig_at = gathered.buffer.ptr + lo_band * r * 4  # the band subset: same rows, same stride, first band of this rank
+        ms_dig = _timed(ctx, lambda: _native.check(lib.mhx_band_digests_dev_typed(ctx.handle, sig_at, _native.MHX_U32, total, k, nbl, r, d_dig.ptr)), reps=3, ramp=0.05)
+        ms_sort = _timed(ctx, lambda: _native.check(lib.mhx_lsh_sort_digests_dev(ctx.handle, d_dig.ptr, total, nbl, d_sd.ptr, d_sr.ptr)), reps=3, ramp=0.05)
+    # ---- parity on every rank
+    ok, why = True, ""
+    sel = check_rows_idx[check_rows_idx < min(n3, n_head)][:512]
+    tok = check_tokens[: len(sel)]
+    want = MinHash.bulk_signatures(tok, num_perm=k, seed=args.seed, hashfunc=prehashed, gpu_mode="disable")
+    mine = _download_rows(gathered.buffer, rank * n3 + sel, k, np.uint32).astype(np.uint64)
+    if not np.array_equal(mine, want):
+        ok, why = False, "own rows of the gathered matrix differ from the numpy path"
+    row0 = group.allgather(want[0].astype(np.uint32).tobytes() if len(sel) and sel[0] == 0 else b"")
+    for q in range(world):
+        if row0[q] and not np.array_equal(gathered.buffer.download((k,), np.uint32, offset=q * n3 * k * 4), np.frombuffer(row0[q], dtype=np.uint32)):
+            ok, why = False, f"row 0 of rank {q}'s block is not that rank's row 0"
+    if nbl > 0 and ok:
+        wd = lsh_bulk.band_digests(want, bands, r, gpu_mode="disable")[:, lo_band:hi_band]
+        if not np.array_equal(_download_rows(d_dig, rank * n3 + sel, nbl, np.uint64), wd):
+            ok, why = False, "band digests differ from FNV-1a-64 of the reference's key bytes"
+        sd, sr = d_sd.download((total,), np.uint64), d_sr.download((total,), np.uint32)
+        col = d_dig.download((total, nbl), np.uint64)[:, 0]
+        tie = sd[1:] == sd[:-1]
+        if np.any(sd[1:] < sd[:-1]) or not np.array_equal(col[sr.astype(np.int64)], sd) or np.any(sr[1:][tie] <= sr[:-1][tie]):
+            ok, why = False, "the rank's first band is not in (digest, row) order"
+    oks = group.allgather(b"" if ok else why.encode())
+    if any(oks):
+        raise SystemExit("PARITY FAILURE (extra.c3_sharded): " + "; ".join(f"rank {q}: {o.decode()}" for q, o in enumerate(oks) if o))
+    stages = {"signatures": ms_sig, "allgather": ms_gather, "band_digests": ms_dig, "bucketing": ms_sort}
+    per_rank = {name: [float(np.frombuffer(p, dtype=np.float64)[0]) for p in group.allgather(np.float64(v).tobytes())] for name, v in stages.items()}
+    worst = {name: max(v) for name, v in per_rank.items()}
+    received = (world - 1) * n3 * k * 4
+    ag = {"transport": gathered.transport, "wire_dtype": "uint32", "bytes_received_per_gpu": received, "ms": worst["allgather"],
+          "GBps_per_gpu": received / (worst["allgather"] * 1e-3) / 1e9,
+          "xgmi_bound_GBps_per_gpu": XGMI_LINKS * XGMI_GBPS_PER_LINK,
+          "note": "received bytes / slowest rank's wall time (one blocking gather after a warm-up one); the bound is 7 links x 153 GB/s into every GPU "
+                  "(SURVEY.md section 5); a host-staged transport crosses PCIe twice and says nothing about xGMI"}
+    if gathered.transport == "rccl":
+        info = dist.communicator(ctx, group).info()
+        ag["rccl_ranks_seen"] = [s[0] for s in group.allgather_ints([info["ranks_seen"]])]
+    res.update({
+        "rows_total": total,
+        "bands_per_rank": [(q + 1) * bands // world - q * bands // world for q in range(world)],
+        "per_rank_ms": per_rank,
+        "ms": worst,
+        "pipeline_ms": sum(worst.values()),
+        "signatures_per_s_end_to_end": total / (sum(worst.values()) * 1e-3),
+        "allgather": ag,
+        "parity": "every rank: up to 512 of its own rows of the gathered matrix and row 0 of every other rank's block vs the numpy path; its bands' digests of "
+                  "those rows vs FNV-1a-64 of the reference's key bytes; its first band ascending, equal to the gathered digest column, rows ascending inside buckets",
+    })
+    return res
+
 
 
 def _fnv1a64(data: bytes) -> int:

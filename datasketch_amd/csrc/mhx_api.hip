@@ -372,6 +372,9 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "lsh.sort_bits")) ctx->opt_lsh_sort_bits = value;
     else if (!strcmp(key, "lsh.gather")) ctx->opt_lsh_gather = value;
     else if (!strcmp(key, "lsh.sort")) ctx->opt_lsh_sort = value;
+    else if (!strcmp(key, "lsh.place")) ctx->opt_lsh_place = value;
+    else if (!strcmp(key, "pack.fused")) ctx->opt_pack_fused = value;
+    else if (!strcmp(key, "weighted.refill")) ctx->opt_weighted_refill = value;
     else return fail(MHX_ERR_INVALID, "unknown option '%s'", key);
     return MHX_OK;
 }
@@ -1031,6 +1034,28 @@ int mhx_band_digests_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dtype, i
     MHX_REQUIRE(d_sig && d_out, "NULL device pointer");
     if (int rc = ctx->activate()) return rc;
     return mhx::launch_band_digests(ctx, d_sig, sig_dtype, n, k, bands, r, d_out);
+}
+
+// b-bit blocks and band digests of the same matrix: one read when the shape allows the fused kernel, the two kernels otherwise
+int mhx_bbit_pack_band_digests_dev(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t b,
+                                   int32_t bands, int32_t r, uint64_t *d_blocks, uint64_t *d_digests, int *fused) {
+    if (fused) *fused = 0;
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    MHX_REQUIRE(sig_dtype == MHX_U64 || sig_dtype == MHX_U32, "bad sig_dtype %d", sig_dtype);
+    MHX_REQUIRE(b >= 1 && b <= 32, "b must be in [1, 32]");
+    MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
+    MHX_REQUIRE(n >= 0 && k > 0, "bad shape");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(d_sig && d_blocks && d_digests, "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    bool done = false;
+    if (ctx->opt_pack_fused != 1)
+        if (int rc = mhx::launch_bbit_digest_fused(ctx, d_sig, sig_dtype, n, k, b, bands, r, d_blocks, d_digests, &done)) return rc;
+    if (fused) *fused = done ? 1 : 0;
+    if (done) return MHX_OK;
+    if (int rc = mhx::launch_bbit_pack(ctx, d_sig, sig_dtype, n, k, b, d_blocks)) return rc;
+    return mhx::launch_band_digests(ctx, d_sig, sig_dtype, n, k, bands, r, d_digests);
 }
 
 int mhx_lsh_sort_bands_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t bands,

@@ -222,16 +222,127 @@ __global__ __launch_bounds__(256) void lean_serialize_kernel(const uint64_t *__r
 // uses as that band's dictionary key (ref: datasketch/lsh.py:199,344,537-538: the r hashvalues of the
 // band, each as 8 big-endian bytes).  It is what MinHashLSH(hashfunc=fnv1a_64) would store
 // (ref: lsh.py:540-543), in a form a device-side sort can group by.  One lane per (row, band).
-// (LOG2 >= 0: bands is that power of two -- the 64-bit division of idx by a run-time divisor was 60 of the kernel's ~290
-// VALU instructions per element)
-template <typename SigT, int LOG2>
+// (shift >= 0: bands is that power of two -- the 64-bit division of idx by a run-time divisor was 60 of the kernel's ~290
+// VALU instructions per element; a run-time shift costs what a compile-time one does)
+template <typename SigT>
 __global__ __launch_bounds__(256) void band_digest_kernel(const SigT *__restrict__ sig, int64_t n, int32_t k,
-                                                          int32_t bands, int32_t r, uint64_t *__restrict__ out) {
+                                                          int32_t bands, int32_t r, int shift, uint64_t *__restrict__ out) {
     const int64_t total = n * (int64_t)bands;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = LOG2 >= 0 ? idx >> LOG2 : idx / bands;
+        const int64_t row = shift >= 0 ? idx >> shift : idx / bands;
         out[idx] = band_digest_of<SigT>(sig, row, (int)(idx - row * bands), k, r);
+    }
+}
+
+// ---- b-bit packing AND band digests from ONE read of the matrix (config 5) ---------------------------------------
+// ref: datasketch/b_bit_minhash.py:78-101 (blocks) and lsh.py:199,344,537-543 (band keys, hashed).  Config 5 wants both of
+// a 10M x 256 matrix; as two kernels the 1 KB rows cross the HBM bus twice (2.9 GB of traffic for 1.64 GB of algorithmic
+// bytes per 1.25M rows).  Here one lane owns one (row, band): it loads the band's R values once (R * sizeof(SigT)
+// contiguous bytes, 16-byte loads), hashes them (FNV-1a-64 of the reference's key bytes, as band_digest_of) and turns the
+// same registers into its part of the row's b-bit blocks:
+//   * R >= 64 / slot: the lane's values fill R * slot / 64 whole blocks, stored directly;
+//   * R <  64 / slot: G = 64 / (slot * R) neighbouring lanes (bands) share a block; each shifts its R * slot bits into
+//     place and the group ORs the words with DPP steps (shuffles for G = 32, 64), the group's first lane stores.
+// Shapes: bands a power of two (<= 64: a wave holds whole rows), R in {4, 8, 16}, bands * R == num_perm (every value of the
+// row belongs to a band, so the blocks are complete), bands % G == 0, 16-byte aligned rows.  launch_bbit_digest_fused says
+// whether a shape qualifies; the caller runs the two kernels otherwise.
+__device__ __forceinline__ void fnv_absorb(uint64_t &h, uint32_t hi, uint32_t lo) {
+    constexpr uint64_t kPrime = 0x100000001b3ull;
+    constexpr uint64_t kPrime4 = kPrime * kPrime * kPrime * kPrime;  // four zero bytes: h ^= 0 leaves h
+    if (hi == 0) {
+        h *= kPrime4;
+    } else {
+#pragma unroll
+        for (int byte = 3; byte >= 0; --byte) {
+            h ^= (hi >> (8 * byte)) & 0xFFu;
+            h *= kPrime;
+        }
+    }
+#pragma unroll
+    for (int byte = 3; byte >= 0; --byte) {  // big-endian byte order of the key
+        h ^= (lo >> (8 * byte)) & 0xFFu;
+        h *= kPrime;
+    }
+}
+
+template <int G>
+__device__ __forceinline__ uint32_t or_lanes(uint32_t x) {  // OR over aligned groups of G lanes, in every lane
+    if constexpr (G <= 16) {
+        return or_group<G>(x);
+    } else {
+        x = or_group<16>(x);
+        x |= (uint32_t)__shfl_xor((int)x, 16);
+        if constexpr (G == 64) x |= (uint32_t)__shfl_xor((int)x, 32);
+        return x;
+    }
+}
+
+template <typename SigT, int SLOT, int R>
+__global__ __launch_bounds__(256) void bbit_digest_fused_kernel(const SigT *__restrict__ sig, int64_t n, int32_t k, int32_t b,
+                                                                int band_shift, uint64_t *__restrict__ blocks,
+                                                                uint64_t *__restrict__ digests) {
+    constexpr int PER = 64 / SLOT;               // values per block
+    constexpr int G = PER > R ? PER / R : 1;     // lanes per block
+    constexpr int Q = R >= PER ? R / PER : 1;    // blocks per lane
+    constexpr bool kWide = sizeof(SigT) == 8;
+    const int bands = 1 << band_shift;
+    const int64_t total = n << band_shift;
+    const uint32_t mask = b >= 32 ? 0xFFFFFFFFu : ((1u << b) - 1u);
+    const int nb = k / PER;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < total; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t idx = base + threadIdx.x;
+        const bool live = idx < total;           // (total is a multiple of G: a group is live or not as a whole)
+        const int64_t row = idx >> band_shift;
+        const int band = (int)(idx & (bands - 1));
+        uint32_t lo[R], hi[R];
+        if (live) {
+            const SigT *src = sig + row * k + (int64_t)band * R;
+            if constexpr (kWide) {
+                const ulonglong2 *s2 = reinterpret_cast<const ulonglong2 *>(src);
+#pragma unroll
+                for (int c = 0; c < R / 2; ++c) {
+                    const ulonglong2 v = s2[c];
+                    lo[2 * c] = (uint32_t)v.x, hi[2 * c] = (uint32_t)(v.x >> 32);
+                    lo[2 * c + 1] = (uint32_t)v.y, hi[2 * c + 1] = (uint32_t)(v.y >> 32);
+                }
+            } else {
+                const uint4 *s4 = reinterpret_cast<const uint4 *>(src);
+#pragma unroll
+                for (int c = 0; c < R / 4; ++c) {
+                    const uint4 v = s4[c];
+                    lo[4 * c] = v.x, lo[4 * c + 1] = v.y, lo[4 * c + 2] = v.z, lo[4 * c + 3] = v.w;
+                }
+#pragma unroll
+                for (int i = 0; i < R; ++i) hi[i] = 0;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < R; ++i) lo[i] = 0, hi[i] = 0;
+        }
+        // the digest of the band's key
+        uint64_t h = 0xcbf29ce484222325ull;
+#pragma unroll
+        for (int i = 0; i < R; ++i) fnv_absorb(h, kWide ? hi[i] : 0u, lo[i]);
+        if (live) digests[idx] = h;
+        // the band's part of the row's blocks (value j of a block sits at bit (PER - 1 - j) * SLOT)
+        if constexpr (G > 1) {
+            uint64_t chunk = 0;  // the lane's R values, first highest: R * SLOT < 64 bits
+#pragma unroll
+            for (int i = 0; i < R; ++i) chunk |= (uint64_t)(lo[i] & mask) << ((R - 1 - i) * SLOT);
+            const int g = band & (G - 1);
+            const uint64_t word = chunk << ((G - 1 - g) * (R * SLOT));
+            const uint32_t whi = or_lanes<G>((uint32_t)(word >> 32)), wlo = or_lanes<G>((uint32_t)word);
+            if (live && g == 0) blocks[row * nb + (band / G)] = ((uint64_t)whi << 32) | wlo;
+        } else {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                uint64_t word = 0;
+#pragma unroll
+                for (int i = 0; i < PER; ++i) word |= (uint64_t)(lo[q * PER + i] & mask) << ((PER - 1 - i) * SLOT);
+                if (live) blocks[row * nb + (int64_t)band * Q + q] = word;
+            }
+        }
     }
 }
 
@@ -332,6 +443,49 @@ int launch_bbit_pack(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, 
     return MHX_OK;
 }
 
+// One pass for both (see bbit_digest_fused_kernel); *done = false when the shape does not qualify (nothing launched).
+int launch_bbit_digest_fused(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t b, int32_t bands,
+                             int32_t r, uint64_t *d_blocks, uint64_t *d_digests, bool *done) {
+    *done = false;
+    const int slot = bbit_slot_size(b);
+    const int per = 64 / slot;
+    const int esize = sig_dtype == MHX_U32 ? 4 : 8;
+    if (!(r == 4 || r == 8 || r == 16) || bands > 64 || (bands & (bands - 1)) != 0 || (int64_t)bands * r != k) return MHX_OK;
+    const int g = per > r ? per / r : 1;
+    if (bands % g != 0 || k % per != 0 || (r * esize) % 16 != 0) return MHX_OK;
+    if ((((uintptr_t)d_sig) & 15) != 0 || (((int64_t)k * esize) & 15) != 0) return MHX_OK;
+    int shift = 0;
+    while ((1 << shift) < bands) ++shift;
+    const int64_t want = (n * bands + 255) / 256;
+    dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * 16)));
+#define MHX_FUSED(T, S, RR) hipLaunchKernelGGL((bbit_digest_fused_kernel<T, S, RR>), grid, dim3(256), 0, ctx->stream, (const T *)d_sig, n, k, b, shift, d_blocks, d_digests)
+#define MHX_FUSED_R(T, S)                                                              \
+    do {                                                                               \
+        if (r == 4) MHX_FUSED(T, S, 4); else if (r == 8) MHX_FUSED(T, S, 8); else MHX_FUSED(T, S, 16); \
+    } while (0)
+#define MHX_FUSED_S(T)                                                                 \
+    do {                                                                               \
+        switch (slot) {                                                                \
+            case 1: MHX_FUSED_R(T, 1); break;                                          \
+            case 2: MHX_FUSED_R(T, 2); break;                                          \
+            case 4: MHX_FUSED_R(T, 4); break;                                          \
+            case 8: MHX_FUSED_R(T, 8); break;                                          \
+            case 16: MHX_FUSED_R(T, 16); break;                                        \
+            default: MHX_FUSED_R(T, 32); break;                                        \
+        }                                                                              \
+    } while (0)
+    if (sig_dtype == MHX_U32)
+        MHX_FUSED_S(uint32_t);
+    else
+        MHX_FUSED_S(uint64_t);
+#undef MHX_FUSED_S
+#undef MHX_FUSED_R
+#undef MHX_FUSED
+    MHX_HIP_CHECK(hipGetLastError());
+    *done = true;
+    return MHX_OK;
+}
+
 int launch_band_keys(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,
                      uint64_t *d_out) {
     const int w = bands * r;
@@ -354,18 +508,11 @@ int launch_band_digests(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t 
                         uint64_t *d_out) {
     const int64_t want = (n * bands + 255) / 256;
     dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * 16)));
-#define MHX_DIGEST(T, L) hipLaunchKernelGGL((band_digest_kernel<T, L>), grid, dim3(256), 0, ctx->stream, (const T *)d_sig, n, k, bands, r, d_out)
-#define MHX_DIGEST_T(T)                                                                                                    \
-    do {                                                                                                                   \
-        if (bands == 16) MHX_DIGEST(T, 4); else if (bands == 32) MHX_DIGEST(T, 5); else if (bands == 64) MHX_DIGEST(T, 6);  \
-        else if (bands == 128) MHX_DIGEST(T, 7); else MHX_DIGEST(T, -1);                                                    \
-    } while (0)
+    const int shift = (bands & (bands - 1)) == 0 ? __builtin_ctz((unsigned)bands) : -1;
     if (sig_dtype == MHX_U32)
-        MHX_DIGEST_T(uint32_t);
+        hipLaunchKernelGGL(band_digest_kernel<uint32_t>, grid, dim3(256), 0, ctx->stream, (const uint32_t *)d_sig, n, k, bands, r, shift, d_out);
     else
-        MHX_DIGEST_T(uint64_t);
-#undef MHX_DIGEST_T
-#undef MHX_DIGEST
+        hipLaunchKernelGGL(band_digest_kernel<uint64_t>, grid, dim3(256), 0, ctx->stream, (const uint64_t *)d_sig, n, k, bands, r, shift, d_out);
     MHX_HIP_CHECK(hipGetLastError());
     return MHX_OK;
 }

@@ -1435,7 +1435,8 @@ __global__ __launch_bounds__(256, 4) void weighted_walk_dense_kernel(const float
 // and the row's stream (16 x 1-KB loads per row and wave) overlaps with the walks of the seven other waves.
 // Same arithmetic, same rules, same helper (walk_row) as the kernel above; rows it does not take (dim > 4096 or not a
 // multiple of 4, fewer than two stripes fitting the LDS) stay with that kernel.
-template <bool LOGS, int NV, bool PAIRS>  // NV: 16-byte loads per lane that hold a row (dim <= 256 NV); PAIRS: two chunks of samples walked as one instruction stream
+// FETCH (A/B, option weighted.refill): bit 0 = the next row's loads go out right after staging instead of behind the walk, bit 1 = non-temporal loads
+template <bool LOGS, int NV, bool PAIRS, int FETCH = 0>  // NV: 16-byte loads per lane that hold a row (dim <= 256 NV); PAIRS: two chunks of samples walked as one instruction stream
 __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__restrict__ x, int64_t n_rows, int32_t dim,
                                                                  const WalkPlan *__restrict__ plan, const float4 *__restrict__ walk_a,
                                                                  const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos,
@@ -1474,7 +1475,13 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int c = (u * kWave + lane) * 4;
-            pre[u] = *reinterpret_cast<const float4 *>(src + (c < dim ? c : dim - 4));
+            if constexpr ((FETCH & 2) != 0) {
+                typedef float f4 __attribute__((ext_vector_type(4)));
+                const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(src + (c < dim ? c : dim - 4)));
+                pre[u] = make_float4(v.x, v.y, v.z, v.w);
+            } else {
+                pre[u] = *reinterpret_cast<const float4 *>(src + (c < dim ? c : dim - 4));
+            }
         }
     };
     const auto one_row = [&](float4 (&pre)[NV], int64_t d) {
@@ -1500,6 +1507,9 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
             }
             if (in) *reinterpret_cast<float4 *>(row + c) = make_float4(l[0], l[1], l[2], l[3]);
         }
+        // (FETCH bit 0) the refill goes out as soon as the registers are free: two rows per wave are in flight for the whole
+        // of the scan and the walk, at the price of the walk's first table load waiting behind it
+        if constexpr ((FETCH & 1) != 0) fetch(pre, d + 2 * stride);
         const bool any_above = __any(lane_above), any_odd = __any(lane_odd);
         int n_stored = dim, n_out = 0;
         bool has_nan = false;
@@ -1608,7 +1618,7 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
         if (lane == 0) nonempty[d] = n_stored > 0 ? 1 : 0;
         // the refill goes out behind the walk (vector loads complete in order: a walk's own table load must not sit out
         // the HBM latency of a row that is not needed for two rows)
-        fetch(pre, d + 2 * stride);
+        if constexpr ((FETCH & 1) == 0) fetch(pre, d + 2 * stride);
     };
     float4 pre0[NV], pre1[NV];
     const int64_t d0 = (int64_t)blockIdx.x * n_waves + wave;
@@ -1883,16 +1893,20 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
             const int64_t per_cu = ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu : std::max<int64_t>(1, (int64_t)ctx->lds_per_block / (int64_t)(lds + 64));
             const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, per_cu * ctx->num_cus));
             const int nv = dim <= 1024 ? 4 : dim <= 2048 ? 8 : 16;
-#define MHX_WALK_WAVE(LOGS, NV_, PAIRS_)                                                                                                  \
-    hipLaunchKernelGGL((weighted_walk_wave_kernel<LOGS, NV_, PAIRS_>), dim3(blocks), dim3(64 * waves), lds, ctx->stream, d_x, n_rows, dim, plan, walk_a, \
+#define MHX_WALK_WAVE(LOGS, NV_, ...)                                                                                                  \
+    hipLaunchKernelGGL((weighted_walk_wave_kernel<LOGS, NV_, __VA_ARGS__>), dim3(blocks), dim3(64 * waves), lds, ctx->stream, d_x, n_rows, dim, plan, walk_a, \
                        gen->d_walk_c, reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, list_cap_w, direct_permille_w,  \
                        (int32_t)(stripe_bytes / 4), rescue_lanes, d_out, d_nonempty)
 #define MHX_WALK_WAVE_NV(LOGS, PAIRS_)            \
     do {                                          \
         if (nv == 4) MHX_WALK_WAVE(LOGS, 4, PAIRS_);      \
         else if (nv == 8) MHX_WALK_WAVE(LOGS, 8, PAIRS_); \
+        else if (fetch_mode == 1) MHX_WALK_WAVE(LOGS, 16, PAIRS_, 1); \
+        else if (fetch_mode == 2) MHX_WALK_WAVE(LOGS, 16, PAIRS_, 2); \
+        else if (fetch_mode == 3) MHX_WALK_WAVE(LOGS, 16, PAIRS_, 3); \
         else MHX_WALK_WAVE(LOGS, 16, PAIRS_);             \
     } while (0)
+            const int fetch_mode = (int)(ctx->opt_weighted_refill & 3);
             const int32_t rescue_lanes = ctx->opt_weighted_rescue < 0 ? 0 : ctx->opt_weighted_rescue > 0 ? (int32_t)ctx->opt_weighted_rescue : 8;  // (lognormal rows at steady clocks: 2: 0.557, 4: 0.535, 8: 0.529, 16: 0.563, 32: 0.68 ms per 20k; config 4 the same for all)
             const bool pairs = ctx->opt_weighted_kernel != 2;  // two chunks of samples as one stream (0.424 -> 0.405 ms on config 4); 2 = chunk after chunk
             if (values_are_logs) {

@@ -174,7 +174,7 @@ def _allgather_host(ctx, d_local, d_all, counts: Sequence[int], row_bytes: int, 
                 name = f"/dev/shm/mhx_gather_{os.getuid()}_{os.getpid()}_{secrets.token_hex(8)}"
                 fd = os.open(name, os.O_RDWR | os.O_CREAT | os.O_EXCL | getattr(os, "O_NOFOLLOW", 0), 0o600)
                 path = name.encode()
-                os.ftruncate(fd, mine)
+                os.posix_fallocate(fd, 0, mine)  # reserves the pages: a full tmpfs fails HERE (ENOSPC), not with SIGBUS in the copy
                 mem = mmap.mmap(fd, mine)
                 d_local.download_into(np.frombuffer(mem, dtype=np.uint8))
         except OSError as e:

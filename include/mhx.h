@@ -379,6 +379,14 @@ MHX_API int mhx_bbit_pack_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dty
                                     int32_t num_perm, int32_t b, uint64_t *d_out);
 MHX_API int mhx_band_digests_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n_sigs,
                                        int32_t num_perm, int32_t bands, int32_t r, uint64_t *d_out);
+/* Config 5 in one call: the b-bit blocks (mhx_bbit_pack*: ref datasketch/b_bit_minhash.py:78-101) AND the band digests
+ * (mhx_band_digests*: ref datasketch/lsh.py:199,344,537-543) of the same [n, num_perm] matrix.  When bands is a power of
+ * two <= 64, r is 4, 8 or 16, bands * r == num_perm and rows are 16-byte aligned, ONE kernel reads the matrix once and
+ * writes both outputs (*fused = 1); any other shape runs the two kernels one after the other (*fused = 0).  Results are
+ * those of the two separate calls, bit for bit.  d_blocks: uint64[n, num_blocks], d_digests: uint64[n, bands]. */
+MHX_API int mhx_bbit_pack_band_digests_dev(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n_sigs,
+                                           int32_t num_perm, int32_t b, int32_t bands, int32_t r,
+                                           uint64_t *d_blocks, uint64_t *d_digests, int *fused);
 MHX_API int mhx_lsh_sort_bands_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n_sigs,
                                          int32_t num_perm, int32_t bands, int32_t r,
                                          uint64_t *d_sorted_digests, uint32_t *d_sorted_rows);

@@ -83,6 +83,7 @@ def main():
         ctx.set_option("weighted.kernel", int(opts.get("kernel", 0)))
         ctx.set_option("weighted.plan", int(opts.get("plan", 0)))
         ctx.set_option("weighted.rescue", int(opts.get("rescue", 0)))
+        ctx.set_option("weighted.refill", int(opts.get("refill", 0)))
 
         def call():
             if args.csr:
@@ -128,6 +129,7 @@ def main():
     ctx.set_option("weighted.direct", 0)
     ctx.set_option("weighted.debug", 0)
     ctx.set_option("weighted.kernel", 0)
+    ctx.set_option("weighted.refill", 0)
     ctx.set_option("weighted.plan", 0)
     ctx.set_option("weighted.rescue", 0)
 
