@@ -190,16 +190,35 @@ def device_count() -> int:
 
 
 def gpu_available() -> bool:
-    """Counterpart of the reference's ``_gpu_available`` (datasketch/minhash.py:38-48).
-
-    False on a host without an AMD GPU.  On a GPU host a missing/unloadable libmhx.so raises:
-    the HIP path must never be skipped silently where it could have run.
-    """
+    """Counterpart of the reference's ``_gpu_available`` (datasketch/minhash.py:38-48), strict: False on a host
+    without an AMD GPU; on a GPU host a missing / unloadable libmhx.so RAISES.  This is what ``gpu_mode='always'``
+    asks (the HIP path must never be skipped silently where it was demanded); ``'detect'`` asks :func:`gpu_detected`."""
     try:
         return device_count() > 0
     except MhxError:
         if gpu_node_present():
             raise
+        return False
+
+
+_detect_warned = False
+
+
+def gpu_detected() -> bool:
+    """``gpu_mode='detect'``: the reference's semantics (datasketch/minhash.py:272-279) -- use the device when there is
+    one, else fall back to the numpy path without failing.  The one addition: on a host that HAS an AMD GPU
+    (``/dev/kfd``) a library that does not load is a broken installation, so the fallback is announced with a
+    ``RuntimeWarning`` naming the load error (once per process) instead of passing in silence."""
+    global _detect_warned
+    try:
+        return device_count() > 0
+    except MhxError as e:
+        if gpu_node_present() and not _detect_warned:
+            _detect_warned = True
+            import warnings
+
+            warnings.warn(f"datasketch_amd: this host has an AMD GPU but the HIP path is unavailable ({e}); gpu_mode='detect' falls back to "
+                          "the numpy path.  gpu_mode='always' makes this an error.", RuntimeWarning, stacklevel=3)
         return False
 
 

@@ -138,7 +138,7 @@ def pack_matrix(signatures: np.ndarray, b: int, gpu_mode: str = "always") -> np.
     if b > 32 or b < 0:
         raise ValueError("b must be an integer in [0, 32]")
     signatures = np.ascontiguousarray(signatures, dtype=np.uint64)
-    if gpu_mode != "disable" and (gpu_mode == "always" or _native.gpu_available()):
+    if gpu_mode != "disable" and (gpu_mode == "always" or _native.gpu_detected()):
         return _native.context().bbit_pack(signatures, b)
     masked = np.bitwise_and(signatures, np.uint64((1 << b) - 1))
     return _pack_rows(masked, _slot_size(b))
@@ -162,7 +162,7 @@ def jaccard_pairs(blocks: np.ndarray, pairs, num_perm: int, b: int, r: float = 0
     nb = -(-int(num_perm) // (64 // slot))
     if blocks.ndim != 2 or blocks.shape[1] != nb:
         raise ValueError("blocks must be [n, %d] for num_perm=%d, b=%d" % (nb, num_perm, b))
-    if gpu_mode != "disable" and (gpu_mode == "always" or _native.gpu_available()):
+    if gpu_mode != "disable" and (gpu_mode == "always" or _native.gpu_detected()):
         same = _native.context().bbit_jaccard_pairs(blocks, num_perm, b, pairs)
     else:
         vals = _unpack_rows(blocks, slot, num_perm)

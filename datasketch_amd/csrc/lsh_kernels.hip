@@ -100,7 +100,7 @@ __device__ __forceinline__ uint32_t bin_of(uint64_t digest, int bin_bits) { retu
 // stream: 1.04 ms for the pass instead of 0.5).
 template <typename SigT>
 __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__restrict__ sig, int32_t k, int32_t r, int64_t n, int32_t bands,
-                                                               int bin_bits, int band_share, uint32_t *__restrict__ cursor,
+                                                               int bin_bits, int band_share, int line_share, uint32_t *__restrict__ cursor,
                                                                uint64_t *__restrict__ slab_dig, uint32_t *__restrict__ slab_row,
                                                                uint32_t *__restrict__ overflow) {
     constexpr int kChunk = 256 * kScatterRows;
@@ -113,9 +113,27 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
     uint32_t *scan_tmp = reinterpret_cast<uint32_t *>(st_row + kChunk);
     const int64_t chunks = (n + kChunk - 1) / kChunk;
     const int groups = bands / band_share;
-    for (int64_t item = blockIdx.x; item < chunks * groups; item += gridDim.x) {
-        const int band = (int)(item % groups) * band_share + team;
-        const int64_t row0 = item / groups * kChunk;
+    // Which workgroup takes which (chunk of rows, band group).  Workgroups go round the 8 XCDs (blockIdx % 8), each XCD with its
+    // own L2.  line_share > 0: that many band groups read the same 128-byte lines of the rows (a digest matrix: 4 teams x 8 B = 32 B
+    // of a line per workgroup) -- they go to the SAME XCD, one after the other, so that the line crosses the fabric once (each
+    // group on its own XCD fetched it four times: 1.30 GB of reads for a 320 MB matrix, and the pass was HBM-bound at 4.4 TB/s of
+    // real traffic, profiles/r05_pmc_sort_and_fused_before.txt).  The groups/line_share sets of groups are dealt to the XCDs (x %
+    // sets), the chunks among the XCDs that serve a set -- a band's slabs are still written by few XCDs, whose L2 merges the
+    // short runs of a bin into whole lines.  line_share == 0: item = band group fastest (band group x on XCD x when groups == 8).
+    const int sets = line_share > 0 ? groups / line_share : 1, xcd = (int)(blockIdx.x & 7), serving = line_share > 0 ? 8 / sets : 1;
+    for (int64_t it = line_share > 0 ? blockIdx.x >> 3 : blockIdx.x;; it += line_share > 0 ? gridDim.x >> 3 : gridDim.x) {
+        int64_t chunk;
+        int group;
+        if (line_share > 0) {
+            chunk = it / line_share * serving + xcd / sets;
+            group = (xcd % sets) * line_share + (int)(it % line_share);
+        } else {
+            chunk = it / groups;
+            group = (int)(it % groups);
+        }
+        if (chunk >= chunks) break;  // (workgroup-uniform)
+        const int band = group * band_share + team;
+        const int64_t row0 = chunk * kChunk;
         for (int t = tid; t < nb; t += 256) hist[t] = 0;
         __syncthreads();
         uint64_t dg[kScatterRows];
@@ -182,39 +200,68 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
 
 __device__ __forceinline__ bool pair_less(uint64_t da, uint32_t ra, uint64_t db, uint32_t rb) { return da < db || (da == db && ra < rb); }
 
-__global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32_t *__restrict__ cursor, const uint64_t *__restrict__ slab_dig,
-                                                           const uint32_t *__restrict__ slab_row, int64_t n, int32_t bands, int bin_bits,
-                                                           int scattered, uint64_t *__restrict__ out_dig, uint32_t *__restrict__ out_row) {
+// where every bin's elements go in the output: the sizes of the band's bins before it (one workgroup per band; a bin holds at
+// most kBinCap elements).  Computed once here: lsh_bin_sort_kernel used to sum the band's cursors in every workgroup -- a
+// 512-thread tree reduction, nine barriers per bin.
+__global__ __launch_bounds__(256) void lsh_bin_offsets_kernel(const uint32_t *__restrict__ cursor, int bin_bits, uint32_t *__restrict__ bin_start) {
+    __shared__ uint32_t scan_tmp[4];
+    const int nb = 1 << bin_bits, tid = threadIdx.x;
+    const uint32_t *cur = cursor + (int64_t)blockIdx.x * nb;
+    uint32_t *dst = bin_start + (int64_t)blockIdx.x * nb;
+    const int per = (nb + 255) / 256;
+    uint32_t sum = 0;
+    for (int j = 0; j < per; ++j) {
+        const int t = tid * per + j;
+        if (t < nb) sum += min(cur[t], (uint32_t)kBinCap);
+    }
+    uint32_t at = block_inclusive_scan(sum, scan_tmp, tid) - sum;
+    for (int j = 0; j < per; ++j) {
+        const int t = tid * per + j;
+        if (t < nb) {
+            dst[t] = at;
+            at += min(cur[t], (uint32_t)kBinCap);
+        }
+    }
+}
+
+// One workgroup per (band, bin).  The slab is read ONCE, into registers (at most kBinCap / kSortThreads = 6 elements per thread);
+// bucket sizes are counted from the registers, the elements placed into their buckets in LDS from the registers, ranked inside
+// the bucket and stored to their place in the output.  53 KB of LDS: three workgroups per CU.  (Round 3 read the slab twice --
+// the second time from L2, but each read is a full memory latency in a workgroup that has nothing else to do -- summed the
+// band's cursors itself and, with 2 KB more LDS, fitted twice per CU: 0.44 ms for 40M keys at 2.2 TB/s of traffic,
+// profiles/r05_pmc_sort_and_fused_before.txt.  Measured and dropped in round 5: placing every element in LDS first and
+// streaming the bin out in order -- the scattered stores of a bin merge in the L2 as it is, EA write requests = 64 B x
+// output size; the extra LDS pass cost 4 %.)
+__global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ bin_start,
+                                                           const uint64_t *__restrict__ slab_dig, const uint32_t *__restrict__ slab_row, int64_t n,
+                                                           int32_t bands, int bin_bits, uint64_t *__restrict__ out_dig, uint32_t *__restrict__ out_row) {
     __shared__ uint64_t dig[kBinCap];
     __shared__ uint32_t row[kBinCap];
     __shared__ uint32_t cnt[1 << kSubBits], start[1 << kSubBits];
-    __shared__ uint32_t part[kSortThreads];
     __shared__ uint32_t scan_tmp[kSortThreads / 64];
     const int nb = 1 << bin_bits, tid = threadIdx.x;
-    constexpr int kSub = 1 << kSubBits, kPer = kSub / kSortThreads;
+    constexpr int kSub = 1 << kSubBits, kPer = kSub / kSortThreads, kMine = (kBinCap + kSortThreads - 1) / kSortThreads;
     for (int64_t item = blockIdx.x; item < (int64_t)bands * nb; item += gridDim.x) {
         const int64_t band = item >> bin_bits;
-        const int bin = (int)(item & (nb - 1));
-        const uint32_t *cur = cursor + band * nb;
-        const uint32_t count = min(cur[bin], (uint32_t)kBinCap);
-        // where the bin goes: behind the band's bins before it
-        uint32_t before = 0;
-        for (int t = tid; t < bin; t += kSortThreads) before += min(cur[t], (uint32_t)kBinCap);
-        part[tid] = before;
-        for (int t = tid; t < kSub; t += kSortThreads) cnt[t] = 0;
-        __syncthreads();
-        for (int o = kSortThreads / 2; o > 0; o >>= 1) {
-            if (tid < o) part[tid] += part[tid + o];
-            __syncthreads();
-        }
-        const int64_t out_base = band * n + part[0];
+        const uint32_t count = min(cursor[item], (uint32_t)kBinCap);
+        const int64_t out_base = band * n + bin_start[item];
         const int64_t slab = item * kBinCap;
         const auto sub_of = [&](uint64_t d) { return (uint32_t)((bin_bits ? d << bin_bits : d) >> (64 - kSubBits)); };
-        // the slab is read twice (the second time from the L2): bucket sizes first, then every element to its bucket's range
-        // in LDS -- one LDS copy of the bin, three workgroups per CU
-        for (uint32_t i = tid; i < count; i += kSortThreads) atomicAdd(&cnt[sub_of(slab_dig[slab + i])], 1u);
+        uint64_t my_d[kMine];
+        uint32_t my_r[kMine];
+#pragma unroll
+        for (int u = 0; u < kMine; ++u) {  // (all loads in flight together)
+            const uint32_t i = tid + u * kSortThreads;
+            if (i < count) my_d[u] = slab_dig[slab + i], my_r[u] = slab_row[slab + i];
+        }
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) cnt[tid * kPer + j] = 0;
         __syncthreads();
-        // exclusive scan of the 2048 bucket sizes: a thread's 8 buckets, then the threads' sums
+#pragma unroll
+        for (int u = 0; u < kMine; ++u)
+            if (tid + u * kSortThreads < count) atomicAdd(&cnt[sub_of(my_d[u])], 1u);
+        __syncthreads();
+        // exclusive scan of the 2048 bucket sizes: a thread's buckets, then the threads' sums
         uint32_t mine[kPer], sum = 0;
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
@@ -230,58 +277,30 @@ __global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32
             at += mine[j];
         }
         __syncthreads();
-        for (uint32_t i = tid; i < count; i += kSortThreads) {
-            const uint64_t d = slab_dig[slab + i];
-            const uint32_t b = sub_of(d);
-            const uint32_t p = start[b] + atomicAdd(&cnt[b], 1u);
-            dig[p] = d;
-            row[p] = slab_row[slab + i];
+#pragma unroll
+        for (int u = 0; u < kMine; ++u) {
+            if (tid + u * kSortThreads < count) {
+                const uint32_t b = sub_of(my_d[u]);
+                const uint32_t p = start[b] + atomicAdd(&cnt[b], 1u);
+                dig[p] = my_d[u];
+                row[p] = my_r[u];
+            }
         }
         __syncthreads();
         // every element finds its place inside its bucket by counting the bucket's smaller (digest, row) pairs -- one or two
         // comparisons for uniform digests, the bucket's size for a cluster of equal ones (spread over the whole workgroup:
-        // an element is a thread's, whatever its bucket).
-        if (scattered) {  // (round 3, kept for A/B: lsh.place = 1) ... and goes straight to its position in the output
-            for (uint32_t i = tid; i < count; i += kSortThreads) {
-                const uint64_t d = dig[i];
-                const uint32_t rw = row[i];
+        // an element is a thread's, whatever its bucket) -- and goes straight to its position in the output
+#pragma unroll
+        for (int u = 0; u < kMine; ++u) {
+            if (tid + u * kSortThreads < count) {
+                const uint64_t d = my_d[u];
+                const uint32_t rw = my_r[u];
                 const uint32_t b = sub_of(d), lo = start[b], hi = lo + cnt[b];
                 uint32_t rank = 0;
                 for (uint32_t j = lo; j < hi; ++j) rank += pair_less(dig[j], row[j], d, rw) ? 1u : 0u;
                 out_dig[out_base + lo + rank] = d;
                 out_row[out_base + lo + rank] = rw;
             }
-            __syncthreads();
-            continue;
-        }
-        // A thread's elements wait in registers while all ranks are taken from LDS, then every element is written to its
-        // sorted place IN LDS and the bin streams out in order: consecutive lanes store consecutive addresses.  (Stored
-        // straight from the ranking loop, a wave's 64 stores went to 64 different lines of the bin's 30 KB of output: the
-        // pass was bound by the address coalescer, 0.41 ms for 40M keys -- 2.4 TB/s of algorithmic traffic.)
-        constexpr int kMine = (kBinCap + kSortThreads - 1) / kSortThreads;
-        uint64_t my_d[kMine];
-        uint32_t my_r[kMine], my_p[kMine];
-#pragma unroll
-        for (int u = 0; u < kMine; ++u) {
-            const uint32_t i = tid + u * kSortThreads;
-            my_p[u] = 0xFFFFFFFFu;
-            if (i < count) {
-                const uint64_t d = dig[i];
-                const uint32_t rw = row[i];
-                const uint32_t b = sub_of(d), lo = start[b], hi = lo + cnt[b];
-                uint32_t rank = 0;
-                for (uint32_t j = lo; j < hi; ++j) rank += pair_less(dig[j], row[j], d, rw) ? 1u : 0u;
-                my_d[u] = d, my_r[u] = rw, my_p[u] = lo + rank;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < kMine; ++u)
-            if (my_p[u] != 0xFFFFFFFFu) dig[my_p[u]] = my_d[u], row[my_p[u]] = my_r[u];
-        __syncthreads();
-        for (uint32_t i = tid; i < count; i += kSortThreads) {
-            out_dig[out_base + i] = dig[i];
-            out_row[out_base + i] = row[i];
         }
         __syncthreads();
     }
@@ -585,7 +604,7 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     while (bin_bits < kMaxBinBits && (n >> bin_bits) > 2500) ++bin_bits;  // about 1250 .. 2500 elements per bin (kBinCap: 3072)
     if ((n >> bin_bits) > 2500) return MHX_OK;                            // more than 12 million rows: the radix sort
     const int64_t nb = (int64_t)1 << bin_bits, bins = nb * bands;
-    const size_t cur_bytes = ((sizeof(uint32_t) * (size_t)(bins + 1)) + 255) & ~(size_t)255;
+    const size_t cur_bytes = ((sizeof(uint32_t) * (size_t)(2 * bins + 1)) + 255) & ~(size_t)255;  // cursor[bins] | overflow | bin_start[bins]
     const size_t dig_bytes = sizeof(uint64_t) * (size_t)bins * kBinCap, row_bytes = sizeof(uint32_t) * (size_t)bins * kBinCap;
     if (cur_bytes + dig_bytes + row_bytes > (size_t)ctx->hbm_bytes / 4) return MHX_OK;
     // bands whose r values of a row share a 128-byte line go to one workgroup (at most four) -- as far as the teams'
@@ -601,29 +620,37 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     if (ctx->ensure_scratch(3, cur_bytes + dig_bytes + row_bytes + 256) != MHX_OK) return MHX_OK;
     uint32_t *d_cursor = (uint32_t *)ctx->scratch[3];
     uint32_t *d_overflow = d_cursor + bins;
+    uint32_t *d_bin_start = d_overflow + 1;
     uint64_t *d_slab_dig = (uint64_t *)((char *)ctx->scratch[3] + cur_bytes);
     uint32_t *d_slab_row = (uint32_t *)((char *)ctx->scratch[3] + cur_bytes + dig_bytes);
     MHX_HIP_CHECK(hipMemsetAsync(d_cursor, 0, sizeof(uint32_t) * (size_t)(bins + 1), ctx->stream));
     const int64_t items = (n + 256 * kScatterRows - 1) / (256 * kScatterRows) * (bands / band_share);
     const size_t lds1 = team_bytes * band_share;
     const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(32 / (4 * band_share), (int64_t)((size_t)ctx->lds_per_block / (lds1 + 64))));
-    const unsigned grid1 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, (int64_t)ctx->num_cus * per_cu * 2));
+    unsigned grid1 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, (int64_t)ctx->num_cus * per_cu * 2));
+    // band groups that read the same 128-byte lines go to one XCD (see the kernel); option lsh.place = 1: round 3's order
+    const int groups = bands / band_share, group_bytes = piece * band_share;
+    int line_share = group_bytes < 128 && 128 % group_bytes == 0 ? 128 / group_bytes : 0;
+    while (line_share > 1 && groups % line_share) line_share >>= 1;
+    if (line_share <= 1 || 8 % (groups / line_share) != 0 || grid1 < 8 || ctx->opt_lsh_place == 1) line_share = 0;
+    if (line_share > 0) grid1 &= ~7u;
     if (sig_dtype == kSigDigests)
         hipLaunchKernelGGL(lsh_bin_scatter_kernel<Digest64>, dim3(grid1), dim3(256 * band_share), lds1, ctx->stream, (const Digest64 *)d_sig, k, r, n, bands,
-                           bin_bits, band_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
+                           bin_bits, band_share, line_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
     else if (sig_dtype == MHX_U32)
         hipLaunchKernelGGL(lsh_bin_scatter_kernel<uint32_t>, dim3(grid1), dim3(256 * band_share), lds1, ctx->stream, (const uint32_t *)d_sig, k, r, n, bands,
-                           bin_bits, band_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
+                           bin_bits, band_share, line_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
     else
         hipLaunchKernelGGL(lsh_bin_scatter_kernel<uint64_t>, dim3(grid1), dim3(256 * band_share), lds1, ctx->stream, (const uint64_t *)d_sig, k, r, n, bands,
-                           bin_bits, band_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
+                           bin_bits, band_share, line_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
     if (hipGetLastError() != hipSuccess) return MHX_OK;  // (a launch the device refuses: nothing has run, the radix sort takes over)
     uint32_t overflow = 0;
     MHX_HIP_CHECK(hipMemcpyAsync(&overflow, d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (overflow) return MHX_OK;
-    hipLaunchKernelGGL(lsh_bin_sort_kernel, dim3((unsigned)std::min<int64_t>(bins, (int64_t)ctx->num_cus * 64)), dim3(kSortThreads), 0, ctx->stream, d_cursor,
-                       d_slab_dig, d_slab_row, n, bands, bin_bits, ctx->opt_lsh_place == 1 ? 1 : 0, d_sorted_digests, d_sorted_rows);
+    hipLaunchKernelGGL(lsh_bin_offsets_kernel, dim3((unsigned)bands), dim3(256), 0, ctx->stream, d_cursor, bin_bits, d_bin_start);
+    hipLaunchKernelGGL(lsh_bin_sort_kernel, dim3((unsigned)std::min<int64_t>(bins, (int64_t)ctx->num_cus * 96)), dim3(kSortThreads), 0, ctx->stream, d_cursor,
+                       d_bin_start, d_slab_dig, d_slab_row, n, bands, bin_bits, d_sorted_digests, d_sorted_rows);
     MHX_HIP_CHECK(hipGetLastError());
     *done = true;
     return MHX_OK;

@@ -87,7 +87,7 @@ struct mhx_ctx {
     int64_t opt_lsh_sort = 0;       // mhx_lsh_sort_bands: 0 auto (two-pass bucketing, radix sort when a bin would overflow), 1 radix sort
     int64_t opt_lsh_gather = 0;     // mhx_lsh_sort_bands: 1 = gather the full digests after the sort (the fallback path) even when they could ride along
     int64_t opt_lsh_sort_bits = 0;  // mhx_lsh_sort_bands: bits of (band, digest) the radix sort orders by; 0 = from n
-    int64_t opt_lsh_place = 0;      // lsh_bin_sort_kernel: 0 = elements take their sorted places in LDS and stream out coalesced, 1 = round 3's scattered stores
+    int64_t opt_lsh_place = 0;      // lsh_bin_scatter_kernel: 0 = band groups that share 128-byte lines of the input run on one XCD, 1 = round 3's order (band group x on XCD x)
     int64_t opt_pack_fused = 0;     // mhx_bbit_pack_band_digests_dev: 0 auto (one read of the matrix where the shape allows), 1 = always the two kernels
     int64_t opt_weighted_refill = 0; // one-wave-per-row walk: 0 = the next row's loads go out behind the walk, 1 = right after staging (A/B)
     int64_t opt_host_chunk_bytes = 0;  // mhx_minhash_bulk: bytes per pipelined piece; 0 auto (96 MiB, inputs > 256 MiB), < 0 never pipeline

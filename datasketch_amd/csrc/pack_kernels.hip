@@ -247,25 +247,6 @@ __global__ __launch_bounds__(256) void band_digest_kernel(const SigT *__restrict
 // Shapes: bands a power of two (<= 64: a wave holds whole rows), R in {4, 8, 16}, bands * R == num_perm (every value of the
 // row belongs to a band, so the blocks are complete), bands % G == 0, 16-byte aligned rows.  launch_bbit_digest_fused says
 // whether a shape qualifies; the caller runs the two kernels otherwise.
-__device__ __forceinline__ void fnv_absorb(uint64_t &h, uint32_t hi, uint32_t lo) {
-    constexpr uint64_t kPrime = 0x100000001b3ull;
-    constexpr uint64_t kPrime4 = kPrime * kPrime * kPrime * kPrime;  // four zero bytes: h ^= 0 leaves h
-    if (hi == 0) {
-        h *= kPrime4;
-    } else {
-#pragma unroll
-        for (int byte = 3; byte >= 0; --byte) {
-            h ^= (hi >> (8 * byte)) & 0xFFu;
-            h *= kPrime;
-        }
-    }
-#pragma unroll
-    for (int byte = 3; byte >= 0; --byte) {  // big-endian byte order of the key
-        h ^= (lo >> (8 * byte)) & 0xFFu;
-        h *= kPrime;
-    }
-}
-
 template <int G>
 __device__ __forceinline__ uint32_t or_lanes(uint32_t x) {  // OR over aligned groups of G lanes, in every lane
     if constexpr (G <= 16) {
@@ -279,25 +260,23 @@ __device__ __forceinline__ uint32_t or_lanes(uint32_t x) {  // OR over aligned g
 }
 
 template <typename SigT, int SLOT, int R>
-__global__ __launch_bounds__(256) void bbit_digest_fused_kernel(const SigT *__restrict__ sig, int64_t n, int32_t k, int32_t b,
-                                                                int band_shift, uint64_t *__restrict__ blocks,
-                                                                uint64_t *__restrict__ digests) {
+__global__ __launch_bounds__(256) void bbit_digest_fused_kernel(const SigT *__restrict__ sig, int64_t n, int32_t b, int band_shift,
+                                                                uint64_t *__restrict__ blocks, uint64_t *__restrict__ digests) {
     constexpr int PER = 64 / SLOT;               // values per block
     constexpr int G = PER > R ? PER / R : 1;     // lanes per block
     constexpr int Q = R >= PER ? R / PER : 1;    // blocks per lane
     constexpr bool kWide = sizeof(SigT) == 8;
-    const int bands = 1 << band_shift;
+    // bands * R == num_perm (the launcher sees to it), so with idx = row * bands + band:
+    //   the band's values start at sig + idx * R, its digest goes to digests[idx], and -- a row holding bands / G (or
+    //   bands * Q) blocks -- its block is blocks[idx / G] (or blocks[idx * Q + q]): no row / band arithmetic at all
     const int64_t total = n << band_shift;
     const uint32_t mask = b >= 32 ? 0xFFFFFFFFu : ((1u << b) - 1u);
-    const int nb = k / PER;
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < total; base += (int64_t)gridDim.x * blockDim.x) {
         const int64_t idx = base + threadIdx.x;
         const bool live = idx < total;           // (total is a multiple of G: a group is live or not as a whole)
-        const int64_t row = idx >> band_shift;
-        const int band = (int)(idx & (bands - 1));
         uint32_t lo[R], hi[R];
         if (live) {
-            const SigT *src = sig + row * k + (int64_t)band * R;
+            const SigT *src = sig + idx * R;
             if constexpr (kWide) {
                 const ulonglong2 *s2 = reinterpret_cast<const ulonglong2 *>(src);
 #pragma unroll
@@ -321,26 +300,47 @@ __global__ __launch_bounds__(256) void bbit_digest_fused_kernel(const SigT *__re
             for (int i = 0; i < R; ++i) lo[i] = 0, hi[i] = 0;
         }
         // the digest of the band's key
-        uint64_t h = 0xcbf29ce484222325ull;
+        uint32_t h_hi = 0xcbf29ce4u, h_lo = 0x84222325u;
 #pragma unroll
-        for (int i = 0; i < R; ++i) fnv_absorb(h, kWide ? hi[i] : 0u, lo[i]);
-        if (live) digests[idx] = h;
+        for (int i = 0; i < R; ++i) fnv_absorb_value(h_hi, h_lo, kWide ? hi[i] : 0u, lo[i]);
+        if (live) digests[idx] = ((uint64_t)h_hi << 32) | h_lo;
         // the band's part of the row's blocks (value j of a block sits at bit (PER - 1 - j) * SLOT)
         if constexpr (G > 1) {
-            uint64_t chunk = 0;  // the lane's R values, first highest: R * SLOT < 64 bits
+            constexpr int kBits = R * SLOT;      // the lane's R values, first highest: < 64 bits
+            const int g = (int)idx & (G - 1);    // (= band % G: bands is a multiple of G)
+            const int sh = (G - 1 - g) * kBits;  // where the lane's bits sit in the block
+            uint32_t whi, wlo;
+            if constexpr (SLOT == 1) {
+                // b = 1: a funnel shift per value (v_alignbit_b32: acc = {value, acc} >> 1 moves the value's low bit in at
+                // the top), last value first -- the lane's R bits end up top-aligned, first value highest; one 64-bit
+                // shift puts them at bit 63 - g * R of the block
+                uint32_t acc = 0;
 #pragma unroll
-            for (int i = 0; i < R; ++i) chunk |= (uint64_t)(lo[i] & mask) << ((R - 1 - i) * SLOT);
-            const int g = band & (G - 1);
-            const uint64_t word = chunk << ((G - 1 - g) * (R * SLOT));
-            const uint32_t whi = or_lanes<G>((uint32_t)(word >> 32)), wlo = or_lanes<G>((uint32_t)word);
-            if (live && g == 0) blocks[row * nb + (band / G)] = ((uint64_t)whi << 32) | wlo;
+                for (int i = R - 1; i >= 0; --i) acc = __builtin_amdgcn_alignbit(lo[i], acc, 1);
+                const uint64_t word = ((uint64_t)acc << 32) >> (g * R);
+                whi = (uint32_t)(word >> 32), wlo = (uint32_t)word;
+            } else if constexpr (kBits <= 32) {  // 32-bit arithmetic: the chunk lands in one half of the block
+                uint32_t chunk = 0;
+#pragma unroll
+                for (int i = 0; i < R; ++i) chunk |= (lo[i] & mask) << ((R - 1 - i) * SLOT);
+                whi = sh >= 32 ? chunk << (sh - 32) : 0u;
+                wlo = sh >= 32 ? 0u : chunk << sh;
+            } else {
+                uint64_t chunk = 0;
+#pragma unroll
+                for (int i = 0; i < R; ++i) chunk |= (uint64_t)(lo[i] & mask) << ((R - 1 - i) * SLOT);
+                const uint64_t word = chunk << sh;
+                whi = (uint32_t)(word >> 32), wlo = (uint32_t)word;
+            }
+            whi = or_lanes<G>(whi), wlo = or_lanes<G>(wlo);
+            if (live && g == 0) blocks[idx / G] = ((uint64_t)whi << 32) | wlo;
         } else {
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 uint64_t word = 0;
 #pragma unroll
                 for (int i = 0; i < PER; ++i) word |= (uint64_t)(lo[q * PER + i] & mask) << ((PER - 1 - i) * SLOT);
-                if (live) blocks[row * nb + (int64_t)band * Q + q] = word;
+                if (live) blocks[idx * Q + q] = word;
             }
         }
     }
@@ -458,7 +458,7 @@ int launch_bbit_digest_fused(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int
     while ((1 << shift) < bands) ++shift;
     const int64_t want = (n * bands + 255) / 256;
     dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * 16)));
-#define MHX_FUSED(T, S, RR) hipLaunchKernelGGL((bbit_digest_fused_kernel<T, S, RR>), grid, dim3(256), 0, ctx->stream, (const T *)d_sig, n, k, b, shift, d_blocks, d_digests)
+#define MHX_FUSED(T, S, RR) hipLaunchKernelGGL((bbit_digest_fused_kernel<T, S, RR>), grid, dim3(256), 0, ctx->stream, (const T *)d_sig, n, b, shift, d_blocks, d_digests)
 #define MHX_FUSED_R(T, S)                                                              \
     do {                                                                               \
         if (r == 4) MHX_FUSED(T, S, 4); else if (r == 8) MHX_FUSED(T, S, 8); else MHX_FUSED(T, S, 16); \

@@ -278,7 +278,7 @@ def bulk_signatures_sharded(local_tokens, *, num_perm: int, seed: int = 1, gpu_m
     counts = [int(c) for c in counts]
     if counts[g.rank] != shard.shape[0]:
         raise ValueError("counts[rank] differs from the number of local rows")
-    use_gpu = gpu_mode == "always" or (gpu_mode == "detect" and _native.gpu_available())
+    use_gpu = gpu_mode == "always" or (gpu_mode == "detect" and _native.gpu_detected())
     if not use_gpu:
         if keep_on_device:
             raise ValueError("keep_on_device needs the GPU path")

@@ -46,7 +46,7 @@ def sha1_hash_many(tokens, bits: int = 32, gpu_mode: str = "detect"):
     if bits not in (32, 64):
         raise ValueError("bits must be 32 or 64")
     tokens = tokens if isinstance(tokens, (list, tuple)) else list(tokens)
-    use_gpu = gpu_mode == "always" or (gpu_mode == "detect" and _native.gpu_available())
+    use_gpu = gpu_mode == "always" or (gpu_mode == "detect" and _native.gpu_detected())
     if gpu_mode == "always" and not _native.gpu_available():
         raise RuntimeError("GPU mode 'always' requested but no MI355X / libmhx.so is available.")
     if not use_gpu:

@@ -127,7 +127,7 @@ def serialize_matrix(signatures: np.ndarray, seed: int, gpu_mode: str = "always"
     signatures = np.ascontiguousarray(signatures, dtype=np.uint64)
     if signatures.size and int(signatures.max()) > 0xFFFFFFFF:
         raise struct.error("'I' format requires 0 <= number <= 4294967295")
-    if gpu_mode != "disable" and (gpu_mode == "always" or _native.gpu_available()):
+    if gpu_mode != "disable" and (gpu_mode == "always" or _native.gpu_detected()):
         return _native.context().lean_serialize(signatures, seed)
     n, k = signatures.shape
     out = np.zeros((n, 12 + 4 * k), dtype=np.uint8)

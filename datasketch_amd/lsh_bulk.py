@@ -51,7 +51,7 @@ def _use_gpu(gpu_mode: str) -> bool:
         if not _native.gpu_available():
             raise RuntimeError("GPU mode 'always' requested but no MI355X / libmhx.so is available.")
         return True
-    return gpu_mode == "detect" and _native.gpu_available()
+    return gpu_mode == "detect" and _native.gpu_detected()
 
 
 def _matrix(signatures) -> np.ndarray:

@@ -139,8 +139,8 @@ class MinHash:
             if not ok:
                 raise _no_device_error()
             return True
-        if mode == "detect":
-            return _gpu_available()
+        if mode == "detect":  # the reference's fallback (minhash.py:276-277); a GPU host with a broken library is announced once
+            return _native.gpu_detected()
         return False
 
     # ------------------------------------------------------------------ updates

@@ -90,7 +90,7 @@ class WeightedMinHashGenerator:
                 raise RuntimeError("GPU mode 'always' requested but no HIP device (or libmhx.so) is available.")
             return True
         if self._gpu_mode == "detect":
-            return _native.gpu_available()
+            return _native.gpu_detected()
         return False
 
     def _log_on_device(self, ctx) -> bool:

@@ -7,7 +7,7 @@
 * configs 3 and 5 at their stated size on one GPU: 10M x 256 tokens, num_perm = 256 (2.56e9 tokens: the first pass above
   2^31 elements through every kernel), band digests, the bucketing of 320M keys, b = 1 packing;
 * the fused pack + band-digest kernel against the two oracles, every slot size, uint32 and uint64;
-* the bucketing pass that places elements through LDS against round 3's scattered stores.
+* the rewritten bucketing passes against numpy's stable order, round 3's work order and the radix sort.
 Everything goes through the C ABI.
 """
 import json
@@ -71,7 +71,7 @@ def test_fused_pack_and_digests_against_both_oracles(ctx, k, bands, r, dtype):
         assert not fused2 and np.array_equal(blocks2, blocks) and np.array_equal(dig2, dig), b
 
 
-@pytest.mark.parametrize("k,bands,r", [(100, 10, 10), (256, 32, 4), (96, 12, 8), (256, 25, 10), (8, 2, 4)])
+@pytest.mark.parametrize("k,bands,r", [(100, 10, 10), (256, 32, 4), (96, 12, 8), (256, 25, 10), (24, 3, 8), (256, 128, 2)])
 def test_fused_entry_point_on_shapes_the_fused_kernel_does_not_take(ctx, k, bands, r):
     """bands * r < num_perm, bands not a power of two, r not 4 / 8 / 16: the same entry point runs the two kernels."""
     rng = np.random.RandomState(k)
@@ -85,23 +85,25 @@ def test_fused_entry_point_on_shapes_the_fused_kernel_does_not_take(ctx, k, band
     assert blocks.shape[0] == 0 and dig.shape == (0, bands)
 
 
-# ------------------------------------------------------------------ bucketing: elements placed through LDS
+# ------------------------------------------------------------------ bucketing: the round-5 passes
 @pytest.mark.parametrize("n", [1, 63, 2500, 2501, 70_001, 400_000])
-def test_bucketing_through_lds_equals_scattered_stores_and_the_radix_sort(ctx, n):
-    """lsh_bin_sort_kernel writes every element to its sorted place in LDS and streams the bin out (lsh.place = 0); round
-    3's straight-to-global stores (lsh.place = 1) and the stable radix sort (lsh.sort = 1) must give the same
-    (band, digest, row) order -- on uniform digests, on clusters of equal digests and with rows shared by many bands."""
+def test_bucketing_passes_equal_round_3s_order_and_the_radix_sort(ctx, n):
+    """Round 5 rewrote both bucketing passes (the scatter pass deals band groups that share input lines to one XCD -- lsh.place
+    = 1 keeps round 3's order for A/B --, the bin pass reads its slab once and takes the bins' places from a prefix kernel):
+    the (band, digest, row) order must be numpy's stable order and the stable radix sort's (lsh.sort = 1) -- on uniform
+    digests, on clusters of equal digests and with rows shared by many bands."""
     rng = np.random.RandomState(n)
     bands = 16
     dig = rng.randint(0, 2**63, (n, bands), dtype=np.uint64) * np.uint64(2) + rng.randint(0, 2, (n, bands)).astype(np.uint64)
     if n > 100:
-        dig[rng.randint(0, n, n // 7), 3] = dig[0, 3]            # one big bucket in band 3
+        dig[rng.randint(0, n, min(n // 7, 600)), 3] = dig[0, 3]  # one big bucket in band 3 (within a bin's capacity: the two passes run)
+        dig[rng.randint(0, n, n // 7), 7] = dig[1, 7]            # ... and one in band 7 that overflows its bin for large n: the radix fallback
         dup = rng.randint(0, n, n // 3)
         dig[dup, 5] = dig[(dup * 7) % n, 5]                       # many small ones in band 5
     d_dig = ctx.to_device(dig)
     d_sd, d_sr = ctx.alloc(max(1, n * bands * 8)), ctx.alloc(max(1, n * bands * 4))
     res = {}
-    for name, opts in (("lds", {}), ("scattered", {"lsh.place": 1}), ("radix", {"lsh.sort": 1})):
+    for name, opts in (("lds", {}), ("round3_order", {"lsh.place": 1}), ("radix", {"lsh.sort": 1})):
         for key, v in opts.items():
             ctx.set_option(key, v)
         try:
@@ -115,7 +117,7 @@ def test_bucketing_through_lds_equals_scattered_stores_and_the_radix_sort(ctx, n
         order = np.lexsort((np.arange(n), dig[:, j]))
         assert np.array_equal(res["lds"][1][j], order.astype(np.uint32)), j
         assert np.array_equal(res["lds"][0][j], dig[order, j]), j
-    for name in ("scattered", "radix"):
+    for name in ("round3_order", "radix"):
         assert np.array_equal(res[name][0], res["lds"][0]) and np.array_equal(res[name][1], res["lds"][1]), name
 
 
