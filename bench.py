@@ -694,8 +694,16 @@ def extra_configs(ctx, tokens, d_tok, seed, only):
         ms_sort = _timed(ctx, sort)
         # config 3 as a chain computes the digests once: the bucketing takes the [n, bands] digest matrix that was just written
         sort_dig = lambda: _native.check(lib.mhx_lsh_sort_digests_dev(ctx.handle, d_dig.ptr, n3, bands, d_sd.ptr, d_sr.ptr))
-        ms_sort_dig = _timed(ctx, sort_dig)
+        ms_sort_dig_rm = _timed(ctx, sort_dig)
         sd_dig, sr_dig = d_sd.download((bands, n3), np.uint64), d_sr.download((bands, n3), np.uint32)
+        # ... and the layout the chain runs on: the digests band-major ([bands, n]), read by the bucketing with unit stride
+        d_dig_bm = ctx.alloc(n3 * bands * 8)
+        ms_dig_bm = _timed(ctx, lambda: _native.check(lib.mhx_band_digests_layout_dev(ctx.handle, dsig.ptr, _native.MHX_U32, n3, k3, bands, r, _native.BAND_MAJOR, d_dig_bm.ptr)))
+        ms_sort_dig = _timed(ctx, lambda: _native.check(lib.mhx_lsh_sort_digests_layout_dev(ctx.handle, d_dig_bm.ptr, n3, bands, _native.BAND_MAJOR, d_sd.ptr, d_sr.ptr)))
+        if not (np.array_equal(d_sd.download((bands, n3), np.uint64), sd_dig) and np.array_equal(d_sr.download((bands, n3), np.uint32), sr_dig)):
+            raise SystemExit("PARITY FAILURE (extra.c3): bucketing from the band-major digests differs from bucketing from the row-major ones")
+        dig_bm = d_dig_bm.download((bands, n3), np.uint64)
+        d_dig_bm.free()
         ms_sort = _timed(ctx, sort)  # (d_sd / d_sr hold the sort-from-signatures result again for the checks below)
         # parity: signature rows against the C oracle, digests against FNV-1a of the reference's key bytes, order of the sort
         rows, tok = sample_rows()
@@ -706,6 +714,9 @@ def extra_configs(ctx, tokens, d_tok, seed, only):
             raise SystemExit("PARITY FAILURE (extra.c3): K=256 signatures differ from the oracle")
         keys = O.c_band_keys(want[:64], bands, r)
         dig = d_dig.download((n3, bands), np.uint64)
+        if not np.array_equal(dig_bm, dig.T):
+            raise SystemExit("PARITY FAILURE (extra.c3): band-major digests differ from the row-major ones")
+        del dig_bm
         for i in range(64):
             for j in range(bands):
                 if int(dig[rows[i], j]) != _fnv1a64(keys[i, j * r:(j + 1) * r].tobytes()):
@@ -724,7 +735,8 @@ def extra_configs(ctx, tokens, d_tok, seed, only):
             "workload": f"config 3 per-GPU shard: {n3} sets x {t} tokens, num_perm={k3} (uint64 tokens in, uint32 signatures out = the all-gather's wire format), then LSH band digests ({bands} bands x {r}) and the bucketing sort",
             "signatures": dict(_roof(n3 * (8 * t + 4 * k3), ms_sig), signatures_per_s=n3 / (ms_sig * 1e-3),
                                note="algorithmic bytes 8*T + 4*K per signature (uint32 out); SURVEY 8d's 4096 B/sig assumes uint64 out"),
-            "band_digests": _roof(n3 * (4 * k3 + 8 * bands), ms_dig),
+            "band_digests": dict(_roof(n3 * (4 * k3 + 8 * bands), ms_dig_bm), layout="band-major [bands, n] (MHX_BAND_MAJOR), written through an LDS tile"),
+            "band_digests_row_major": _roof(n3 * (4 * k3 + 8 * bands), ms_dig),
             "lsh_sort_bands": dict(_roof(n3 * (4 * k3 + 12 * bands), ms_sort), keys_per_s=n3 * bands / (ms_sort * 1e-3),
                                    kernels="lsh_bin_scatter_kernel + lsh_bin_sort_kernel",
                                    note="digests computed and scattered to bins by their top bits, every bin ordered in LDS: exact (band, digest, row) "
@@ -733,10 +745,13 @@ def extra_configs(ctx, tokens, d_tok, seed, only):
                                          note="lsh.sort=1: digests + the library radix sort of (band, digest prefix, row) + exact clean-up (round 2's path, "
                                               "now the fallback), same call, same box"),
             "lsh_sort_digests": dict(_roof(n3 * (8 * bands + 12 * bands), ms_sort_dig), keys_per_s=n3 * bands / (ms_sort_dig * 1e-3),
-                                     note="mhx_lsh_sort_digests_dev: the same two passes on the [n, bands] digest matrix band_digests has just written "
-                                          "(8 B read per key, no hashing); bytes = digests in, (digest, row) out"),
-            "pipeline_ms": ms_sig + ms_dig + ms_sort_dig,
-            "pipeline": "signatures -> band_digests (kept: the index's keys) -> lsh_sort_digests; digests computed once",
+                                     note="mhx_lsh_sort_digests_layout_dev on the band-major digest matrix band_digests has just written (8 B read per key with "
+                                          "unit stride, no hashing); bytes = digests in, (digest, row) out"),
+            "lsh_sort_digests_row_major": dict(_roof(n3 * (8 * bands + 12 * bands), ms_sort_dig_rm), keys_per_s=n3 * bands / (ms_sort_dig_rm * 1e-3),
+                                               note="the same from an [n, bands] matrix: every 128-byte input line is fetched by the four XCDs whose bands share it "
+                                                    "(profiles/r05_pmc_scatter_work_orders.txt)"),
+            "pipeline_ms": ms_sig + ms_dig_bm + ms_sort_dig,
+            "pipeline": "signatures -> band_digests (band-major, kept: one key array per hashtable) -> lsh_sort_digests; digests computed once",
             "pipeline_ms_digests_twice": ms_sig + ms_dig + ms_sort,
             "parity": f"{len(rows)} signature rows vs the C oracle, 64 x {bands} digests vs FNV-1a-64 of the reference's key bytes, 2 bands' order, all {bands} sorted bands equal to the stable radix sort's and to the sort from the digest matrix",
         }
@@ -772,6 +787,11 @@ def extra_configs(ctx, tokens, d_tok, seed, only):
             for j in range(bands):
                 if int(dig[rows[i], j]) != _fnv1a64(keys[i, j * r:(j + 1) * r].tobytes()):
                     raise SystemExit("PARITY FAILURE (extra.c5): band digest differs from FNV-1a-64 of the reference's key bytes")
+        for d in (d_pack, d_dig):
+            _native.check(lib.mhx_memset_dev(ctx.handle, _ct.c_void_p(d.ptr), 0, d.nbytes))
+        ms_fused_bm = _timed(ctx, lambda: one_read.append(ctx.bbit_pack_band_digests_dev(dsig.ptr, _native.MHX_U32, n3, k3, 1, bands, r, d_pack.ptr, d_dig.ptr, _native.BAND_MAJOR)))
+        if not (np.array_equal(d_pack.download((n3, nb), np.uint64), pack) and np.array_equal(d_dig.download((bands, n3), np.uint64), dig.T)):
+            raise SystemExit("PARITY FAILURE (extra.c5): the fused kernel's band-major digests / blocks differ from the two kernels'")
         del pack, dig
         res["c5"] = {
             "workload": f"config 5 per-GPU shard: b=1 packing of {n3} x {k3} signatures (uint32, as all-gathered) + LSH band hashing ({bands} x {r})",
@@ -779,7 +799,9 @@ def extra_configs(ctx, tokens, d_tok, seed, only):
                           kernel="bbit_digest_fused_kernel: blocks and digests from one read of the matrix (algorithmic bytes: 4K in, K/8 + 8*bands out)"),
             "bbit_pack_b1": _roof(n3 * (4 * k3 + k3 // 8), ms_pack),
             "band_digests": _roof(n3 * (4 * k3 + 8 * bands), ms_dig),
-            "pipeline_ms": ms_fused,
+            "fused_band_major": dict(_roof(n3 * (4 * k3 + k3 // 8 + 8 * bands), ms_fused_bm),
+                                     note="the same kernel writing the digests [bands, n] through an LDS tile: the layout the bucketing reads with unit stride"),
+            "pipeline_ms": ms_fused_bm,
             "pipeline_ms_two_kernels": ms_pack + ms_dig,
             "parity": f"{len(rows)} packed rows vs the C oracle (b_bit_minhash.py:82-101 bit order), 64 x {bands} digests vs FNV-1a-64 of the reference's key "
                       f"bytes, and the fused kernel's outputs equal to the two kernels' on all {n3} rows",
@@ -857,8 +879,9 @@ def extra_full(ctx, n, seed, checks="sample", t=256, k=256, bands=32, r=8):
     ms_sig = _timed(ctx, lambda: ctx.minhash_bulk_dev(perms, d_tok.ptr, _native.MHX_U64, None, t, n, n * t, None, 0, d_sig.ptr, _native.MHX_U32), reps=2, ramp=0.1)
     d_tok.free()
     d_dig, d_sd, d_sr = ctx.alloc(n * bands * 8), ctx.alloc(n * bands * 8), ctx.alloc(n * bands * 4)
-    ms_dig = _timed(ctx, lambda: _native.check(lib.mhx_band_digests_dev_typed(ctx.handle, d_sig.ptr, _native.MHX_U32, n, k, bands, r, d_dig.ptr)), reps=3, ramp=0.1)
-    sort_dig = lambda: _native.check(lib.mhx_lsh_sort_digests_dev(ctx.handle, d_dig.ptr, n, bands, d_sd.ptr, d_sr.ptr))
+    BM = _native.BAND_MAJOR  # the digests [bands, n]: one array per hashtable, read by the bucketing with unit stride
+    ms_dig = _timed(ctx, lambda: _native.check(lib.mhx_band_digests_layout_dev(ctx.handle, d_sig.ptr, _native.MHX_U32, n, k, bands, r, BM, d_dig.ptr)), reps=3, ramp=0.1)
+    sort_dig = lambda: _native.check(lib.mhx_lsh_sort_digests_layout_dev(ctx.handle, d_dig.ptr, n, bands, BM, d_sd.ptr, d_sr.ptr))
     ms_sort = _timed(ctx, sort_dig, reps=3, ramp=0.1)
     # ---- parity, config 3
     a, b = perms
@@ -870,14 +893,14 @@ def extra_full(ctx, n, seed, checks="sample", t=256, k=256, bands=32, r=8):
         keys = O.c_band_keys(want[i: i + 1], bands, r)
         if int(want_dig[i, bands - 1]) != _fnv1a64(keys[0, (bands - 1) * r:].tobytes()):
             raise SystemExit("PARITY FAILURE (extra.c3_full): the numpy digests differ from FNV-1a-64 of the key bytes")
-    if not np.array_equal(_download_rows(d_dig, rows, bands, np.uint64), want_dig):
+    dig = d_dig.download((bands, n), np.uint64)
+    if not np.array_equal(dig[:, rows].T, want_dig):
         raise SystemExit("PARITY FAILURE (extra.c3_full): band digests differ from FNV-1a-64 of the reference's key bytes")
-    dig = d_dig.download((n, bands), np.uint64)
     check_bands = list(range(bands)) if checks == "all" else sorted({0, bands // 3, 2 * bands // 3, bands - 1})
     for j in check_bands:
         sd = d_sd.download((n,), np.uint64, offset=j * n * 8)
         sr = d_sr.download((n,), np.uint32, offset=j * n * 4)
-        col = dig[:, j]
+        col = dig[j]
         if np.any(sd[1:] < sd[:-1]) or not np.array_equal(col[sr.astype(np.int64)], sd):
             raise SystemExit(f"PARITY FAILURE (extra.c3_full): band {j} is not the band's digests in ascending order")
         tie = sd[1:] == sd[:-1]
@@ -900,7 +923,7 @@ def extra_full(ctx, n, seed, checks="sample", t=256, k=256, bands=32, r=8):
     ctx.release_scratch()
     c3 = {
         "workload": f"config 3 at its stated size on one GPU: {n} sets x {t} tokens ({n * t:.3e} tokens), num_perm={k} (uint64 tokens in, uint32 signatures out), "
-                    f"band digests ({bands} x {r}), bucketing of {n * bands} (band, digest) keys",
+                    f"band digests ({bands} x {r}, band-major), bucketing of {n * bands} (band, digest) keys",
         "signatures": dict(_roof(n * (8 * t + 4 * k), ms_sig), signatures_per_s=n / (ms_sig * 1e-3)),
         "band_digests": _roof(n * (4 * k + 8 * bands), ms_dig),
         "lsh_sort_digests": dict(_roof(n * (8 * bands + 12 * bands), ms_sort), keys_per_s=n * bands / (ms_sort * 1e-3)),
@@ -915,12 +938,12 @@ def extra_full(ctx, n, seed, checks="sample", t=256, k=256, bands=32, r=8):
     # ---- config 5: b = 1 blocks + band digests of the same 10M x 256 matrix
     d_blk, d_dig2 = ctx.alloc(n * nb * 8), ctx.alloc(n * bands * 8)
     fused_flag = []
-    fused = lambda: fused_flag.append(ctx.bbit_pack_band_digests_dev(d_sig.ptr, _native.MHX_U32, n, k, 1, bands, r, d_blk.ptr, d_dig2.ptr))
+    fused = lambda: fused_flag.append(ctx.bbit_pack_band_digests_dev(d_sig.ptr, _native.MHX_U32, n, k, 1, bands, r, d_blk.ptr, d_dig2.ptr, BM))
     ms_fused = _timed(ctx, fused, reps=3, ramp=0.1)
     blk_rows = _download_rows(d_blk, rows, nb, np.uint64)
-    if not (np.array_equal(blk_rows, O.c_bbit_pack(want, 1)) and np.array_equal(_download_rows(d_dig2, rows, bands, np.uint64), want_dig)):
-        raise SystemExit("PARITY FAILURE (extra.c5_full): fused b=1 blocks / digests differ from the oracle")
-    if not np.array_equal(d_dig2.download((n, bands), np.uint64), dig):
+    if not np.array_equal(blk_rows, O.c_bbit_pack(want, 1)):
+        raise SystemExit("PARITY FAILURE (extra.c5_full): fused b=1 blocks differ from the oracle")
+    if not np.array_equal(d_dig2.download((bands, n), np.uint64), dig):  # (dig: checked against the oracle on the sample rows above)
         raise SystemExit("PARITY FAILURE (extra.c5_full): the fused kernel's digests differ from band_digest_kernel's")
     del dig
     ms_pack = _timed(ctx, lambda: _native.check(lib.mhx_bbit_pack_dev_typed(ctx.handle, d_sig.ptr, _native.MHX_U32, n, k, 1, d_dig.ptr)), reps=3, ramp=0.1)  # (into d_dig: free by now)
@@ -929,7 +952,7 @@ def extra_full(ctx, n, seed, checks="sample", t=256, k=256, bands=32, r=8):
     c5 = {
         "workload": f"config 5 at its stated size on one GPU: b=1 packing of {n} x {k} signatures (uint32) + LSH band hashing ({bands} x {r})",
         "fused": dict(_roof(n * (4 * k + k // 8 + 8 * bands), ms_fused), one_read=bool(fused_flag and all(fused_flag)),
-                      kernel="bbit_digest_fused_kernel: blocks and digests from one read of the matrix"),
+                      kernel="bbit_digest_fused_kernel: blocks and band-major digests from one read of the matrix"),
         "two_kernels_ms": ms_pack + ms_dig,
         "bbit_pack_b1_ms": ms_pack,
         "band_digests_ms": ms_dig,
@@ -995,8 +1018,9 @@ def c3_sharded(ctx, group, args, d_tok, n_head, t, check_rows_idx, check_tokens,
     if nbl > 0:
         d_dig, d_sd, d_sr = ctx.alloc(total * nbl * 8), ctx.alloc(total * nbl * 8), ctx.alloc(total * nbl * 4)
         sig_at = gathered.buffer.ptr + lo_band * r * 4  # the band subset: same rows, same stride, first band of this rank
-        ms_dig = _timed(ctx, lambda: _native.check(lib.mhx_band_digests_dev_typed(ctx.handle, sig_at, _native.MHX_U32, total, k, nbl, r, d_dig.ptr)), reps=3, ramp=0.05)
-        ms_sort = _timed(ctx, lambda: _native.check(lib.mhx_lsh_sort_digests_dev(ctx.handle, d_dig.ptr, total, nbl, d_sd.ptr, d_sr.ptr)), reps=3, ramp=0.05)
+        BM = _native.BAND_MAJOR
+        ms_dig = _timed(ctx, lambda: _native.check(lib.mhx_band_digests_layout_dev(ctx.handle, sig_at, _native.MHX_U32, total, k, nbl, r, BM, d_dig.ptr)), reps=3, ramp=0.05)
+        ms_sort = _timed(ctx, lambda: _native.check(lib.mhx_lsh_sort_digests_layout_dev(ctx.handle, d_dig.ptr, total, nbl, BM, d_sd.ptr, d_sr.ptr)), reps=3, ramp=0.05)
     # ---- parity on every rank
     ok, why = True, ""
     sel = check_rows_idx[check_rows_idx < min(n3, n_head)][:512]
@@ -1011,10 +1035,11 @@ def c3_sharded(ctx, group, args, d_tok, n_head, t, check_rows_idx, check_tokens,
             ok, why = False, f"row 0 of rank {q}'s block is not that rank's row 0"
     if nbl > 0 and ok:
         wd = lsh_bulk.band_digests(want, bands, r, gpu_mode="disable")[:, lo_band:hi_band]
-        if not np.array_equal(_download_rows(d_dig, rank * n3 + sel, nbl, np.uint64), wd):
+        dig_local = d_dig.download((nbl, total), np.uint64)
+        if not np.array_equal(dig_local[:, rank * n3 + sel].T, wd):
             ok, why = False, "band digests differ from FNV-1a-64 of the reference's key bytes"
         sd, sr = d_sd.download((total,), np.uint64), d_sr.download((total,), np.uint32)
-        col = d_dig.download((total, nbl), np.uint64)[:, 0]
+        col = dig_local[0]
         tie = sd[1:] == sd[:-1]
         if np.any(sd[1:] < sd[:-1]) or not np.array_equal(col[sr.astype(np.int64)], sd) or np.any(sr[1:][tie] <= sr[:-1][tie]):
             ok, why = False, "the rank's first band is not in (digest, row) order"

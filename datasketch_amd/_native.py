@@ -20,6 +20,7 @@ LIB_PATH = os.environ.get("MHX_LIBRARY") or os.path.join(_HERE, "libmhx.so")  # 
 MHX_OK, MHX_ERR_NO_DEVICE, MHX_ERR_INVALID, MHX_ERR_HIP, MHX_ERR_OOM, MHX_ERR_UNSUPPORTED, MHX_ERR_COMM = range(7)
 MHX_U64, MHX_U32 = 0, 1
 COMM_ID_BYTES = 128
+ROW_MAJOR, BAND_MAJOR = 0, 1  # layouts of a band-digest matrix on the device (include/mhx.h)
 
 _vp = ctypes.c_void_p
 _i64 = ctypes.c_int64
@@ -92,7 +93,9 @@ _PROTOTYPES = {
     "mhx_jaccard_pairs": [_vp, _vp, _i64, ctypes.c_int32, _vp, _i64, _vp],
     "mhx_bbit_pack_dev_typed": [_vp, _vp, _int, _i64, _i32, _i32, _vp],
     "mhx_band_digests_dev_typed": [_vp, _vp, _int, _i64, _i32, _i32, _i32, _vp],
-    "mhx_bbit_pack_band_digests_dev": [_vp, _vp, _int, _i64, _i32, _i32, _i32, _i32, _vp, _vp, ctypes.POINTER(_int)],
+    "mhx_bbit_pack_band_digests_dev": [_vp, _vp, _int, _i64, _i32, _i32, _i32, _i32, _int, _vp, _vp, ctypes.POINTER(_int)],
+    "mhx_band_digests_layout_dev": [_vp, _vp, _int, _i64, _i32, _i32, _i32, _int, _vp],
+    "mhx_lsh_sort_digests_layout_dev": [_vp, _vp, _i64, ctypes.c_int32, _int, _vp, _vp],
     "mhx_lsh_sort_bands_dev_typed": [_vp, _vp, _int, _i64, _i32, _i32, _i32, _vp, _vp],
     "mhx_jaccard_pairs_dev_typed": [_vp, _vp, _vp, _int, _i32, _vp, _i64, _vp],
     "mhx_bbit_jaccard_pairs_dev": [_vp, _vp, _vp, _i32, _i32, _vp, _i64, _vp],
@@ -737,16 +740,17 @@ class Context:
         return out
 
     def bbit_pack_band_digests_dev(self, d_sig: int, sig_dtype: int, n: int, k: int, b: int, bands: int, r: int,
-                                   d_blocks: int, d_digests: int) -> bool:
+                                   d_blocks: int, d_digests: int, layout: int = 0) -> bool:
         """b-bit blocks and band digests of a device-resident matrix (mhx_bbit_pack_band_digests_dev); True when the
         fused kernel ran (the matrix was read once)."""
         fused = _int(0)
         check(self.lib.mhx_bbit_pack_band_digests_dev(self.handle, _vp(d_sig), int(sig_dtype), int(n), int(k), int(b), int(bands),
-                                                      int(r), _vp(d_blocks), _vp(d_digests), ctypes.byref(fused)))
+                                                      int(r), int(layout), _vp(d_blocks), _vp(d_digests), ctypes.byref(fused)))
         return bool(fused.value)
 
-    def bbit_pack_band_digests(self, sig: np.ndarray, b: int, bands: int, r: int):
-        """(blocks [n, num_blocks] uint64, digests [n, bands] uint64, fused) of a host matrix (uint64 or uint32)."""
+    def bbit_pack_band_digests(self, sig: np.ndarray, b: int, bands: int, r: int, layout: int = 0):
+        """(blocks [n, num_blocks] uint64, digests [n, bands] uint64 -- [bands, n] with layout = BAND_MAJOR --, fused) of a
+        host matrix (uint64 or uint32)."""
         sig = np.ascontiguousarray(sig)
         if sig.dtype != np.uint32:
             sig = np.ascontiguousarray(sig, dtype=np.uint64)
@@ -755,9 +759,9 @@ class Context:
         check(self.lib.mhx_bbit_num_blocks(k, int(b), ctypes.byref(nb)))
         d_sig = self.to_device(sig)
         d_blk, d_dig = self.alloc(max(1, n * nb.value * 8)), self.alloc(max(1, n * bands * 8))
-        fused = self.bbit_pack_band_digests_dev(d_sig.ptr, MHX_U32 if sig.dtype == np.uint32 else MHX_U64, n, k, b, bands, r, d_blk.ptr, d_dig.ptr)
+        fused = self.bbit_pack_band_digests_dev(d_sig.ptr, MHX_U32 if sig.dtype == np.uint32 else MHX_U64, n, k, b, bands, r, d_blk.ptr, d_dig.ptr, layout)
         self.synchronize()
-        out = d_blk.download((n, nb.value), np.uint64), d_dig.download((n, bands), np.uint64), fused
+        out = d_blk.download((n, nb.value), np.uint64), d_dig.download((bands, n) if layout == BAND_MAJOR else (n, bands), np.uint64), fused
         for d in (d_sig, d_blk, d_dig):
             d.free()
         return out

@@ -69,11 +69,18 @@ __device__ __forceinline__ void fnv_absorb_value(uint32_t &hi, uint32_t &lo, uin
 struct Digest64 {
     uint64_t v;
 };
+// ... the same digests band-major ([bands, n]: band j's digests of all rows are contiguous) -- the layout the bucketing reads
+// with unit stride (a team takes 2048 rows of ONE band) and the per-band hashtables of the reference suggest (lsh.py:199)
+struct Digest64BM {
+    uint64_t v;
+};
 
 template <typename SigT>
-__device__ __forceinline__ uint64_t band_digest_of(const SigT *__restrict__ sig, int64_t row, int band, int32_t k, int32_t r) {
+__device__ __forceinline__ uint64_t band_digest_of(const SigT *__restrict__ sig, int64_t row, int band, int32_t k, int32_t r, int64_t n = 0) {
     if constexpr (std::is_same<SigT, Digest64>::value) {
         return sig[row * k + band].v;  // (k = bands here)
+    } else if constexpr (std::is_same<SigT, Digest64BM>::value) {
+        return sig[(int64_t)band * n + row].v;
     } else {
     const SigT *src = sig + row * k + (int64_t)band * r;
     uint32_t h_hi = 0xcbf29ce4u, h_lo = 0x84222325u;

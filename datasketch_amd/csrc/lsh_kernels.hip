@@ -36,23 +36,24 @@ __device__ __host__ __forceinline__ uint64_t prefix_key(uint64_t digest, uint32_
 // digests[n, bands] (row-major) -> (key, row) in the same order: rows ascend within every band and the
 // sort is stable, so equal keys of a band keep ascending rows
 __global__ __launch_bounds__(256) void band_keys_for_sort_kernel(const uint64_t *__restrict__ digests, int64_t n, int32_t bands,
-                                                                 int band_bits, int sort_bits, uint64_t *__restrict__ keys,
+                                                                 int band_bits, int sort_bits, int band_major, uint64_t *__restrict__ keys,
                                                                  uint32_t *__restrict__ rows) {
     const int64_t total = n * (int64_t)bands;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = idx / bands;
-        keys[idx] = prefix_key(digests[idx], (uint32_t)(idx - row * bands), band_bits, sort_bits);
+        const int64_t band = idx - row * bands;
+        keys[idx] = prefix_key(digests[band_major ? band * n + row : idx], (uint32_t)band, band_bits, sort_bits);
         rows[idx] = (uint32_t)row;
     }
 }
 
 // position p of the sorted order belongs to band p / n (every band has n entries): fetch its full digest
 __global__ __launch_bounds__(256) void gather_digests_kernel(const uint64_t *__restrict__ digests, const uint32_t *__restrict__ rows,
-                                                             int64_t n, int32_t bands, int64_t total,
+                                                             int64_t n, int32_t bands, int64_t total, int band_major,
                                                              uint64_t *__restrict__ sorted_digests) {
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x)
-        sorted_digests[p] = digests[(int64_t)rows[p] * bands + p / n];
+        sorted_digests[p] = digests[band_major ? p / n * n + rows[p] : (int64_t)rows[p] * bands + p / n];
 }
 
 // ---- the bands bucketed in two passes (round 3) ------------------------------------------------------------
@@ -72,9 +73,10 @@ __global__ __launch_bounds__(256) void gather_digests_kernel(const uint64_t *__r
 // host reads after pass 1, and the call falls back to the radix sort.
 constexpr int kBinCap = 3072;
 constexpr int kScatterRows = 8;   // rows per thread of pass 1 (2048 per workgroup: 26 KB of LDS, six workgroups per CU)
-constexpr int kSubBits = 11;
+constexpr int kSubBits = 10;  // (11 until round 5: 8 KB less LDS puts three workgroups on a CU instead of two, 0.45 -> 0.35 ms for 40M keys; 9 bits and a fourth workgroup gain nothing)
 constexpr int kSortThreads = 512;
 constexpr int kMaxBinBits = 12;
+constexpr int kMaxBinsPerThread = (1 << kMaxBinBits) / 256;
 
 // inclusive prefix sum over the threads of a workgroup: shuffles inside a wave, the wave totals through LDS
 __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t *tmp4, int tid) {
@@ -100,7 +102,7 @@ __device__ __forceinline__ uint32_t bin_of(uint64_t digest, int bin_bits) { retu
 // stream: 1.04 ms for the pass instead of 0.5).
 template <typename SigT>
 __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__restrict__ sig, int32_t k, int32_t r, int64_t n, int32_t bands,
-                                                               int bin_bits, int band_share, int line_share, uint32_t *__restrict__ cursor,
+                                                               int bin_bits, int band_share, uint32_t *__restrict__ cursor,
                                                                uint64_t *__restrict__ slab_dig, uint32_t *__restrict__ slab_row,
                                                                uint32_t *__restrict__ overflow) {
     constexpr int kChunk = 256 * kScatterRows;
@@ -113,27 +115,14 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
     uint32_t *scan_tmp = reinterpret_cast<uint32_t *>(st_row + kChunk);
     const int64_t chunks = (n + kChunk - 1) / kChunk;
     const int groups = bands / band_share;
-    // Which workgroup takes which (chunk of rows, band group).  Workgroups go round the 8 XCDs (blockIdx % 8), each XCD with its
-    // own L2.  line_share > 0: that many band groups read the same 128-byte lines of the rows (a digest matrix: 4 teams x 8 B = 32 B
-    // of a line per workgroup) -- they go to the SAME XCD, one after the other, so that the line crosses the fabric once (each
-    // group on its own XCD fetched it four times: 1.30 GB of reads for a 320 MB matrix, and the pass was HBM-bound at 4.4 TB/s of
-    // real traffic, profiles/r05_pmc_sort_and_fused_before.txt).  The groups/line_share sets of groups are dealt to the XCDs (x %
-    // sets), the chunks among the XCDs that serve a set -- a band's slabs are still written by few XCDs, whose L2 merges the
-    // short runs of a bin into whole lines.  line_share == 0: item = band group fastest (band group x on XCD x when groups == 8).
-    const int sets = line_share > 0 ? groups / line_share : 1, xcd = (int)(blockIdx.x & 7), serving = line_share > 0 ? 8 / sets : 1;
-    for (int64_t it = line_share > 0 ? blockIdx.x >> 3 : blockIdx.x;; it += line_share > 0 ? gridDim.x >> 3 : gridDim.x) {
-        int64_t chunk;
-        int group;
-        if (line_share > 0) {
-            chunk = it / line_share * serving + xcd / sets;
-            group = (xcd % sets) * line_share + (int)(it % line_share);
-        } else {
-            chunk = it / groups;
-            group = (int)(it % groups);
-        }
-        if (chunk >= chunks) break;  // (workgroup-uniform)
-        const int band = group * band_share + team;
-        const int64_t row0 = chunk * kChunk;
+    // item = band group fastest: with 8 band groups and a grid that is a multiple of 8, band group x is always on XCD x (workgroups
+    // go round the XCDs), whose L2 then merges the short runs of that band's bins into whole lines.  (Measured and dropped in round 5:
+    // dealing the band groups that share 128-byte input lines of a ROW-major digest matrix to one XCD -- reads 1.30 GB -> 0.32 GB, but
+    // 16 bands' slabs per XCD no longer merge: writes 0.62 -> 1.02 GB in 32-byte requests, 447 -> 493 us,
+    // profiles/r05_pmc_scatter_work_orders.txt.  The band-major input (Digest64BM) keeps both properties.)
+    for (int64_t item = blockIdx.x; item < chunks * groups; item += gridDim.x) {
+        const int band = (int)(item % groups) * band_share + team;
+        const int64_t row0 = item / groups * kChunk;
         for (int t = tid; t < nb; t += 256) hist[t] = 0;
         __syncthreads();
         uint64_t dg[kScatterRows];
@@ -141,7 +130,7 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
         for (int j = 0; j < kScatterRows; ++j) {
             const int64_t row = row0 + j * 256 + tid;
             if (row < n) {
-                dg[j] = band_digest_of<SigT>(sig, row, band, k, r);
+                dg[j] = band_digest_of<SigT>(sig, row, band, k, r, n);
                 atomicAdd(&hist[bin_of(dg[j], bin_bits)], 1u);
             }
         }
@@ -149,24 +138,26 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
         // per bin: a range of its slab (one global atomic) and the start of its elements in the team's staging area
         // (exclusive scan of the counts: thread t owns bins [t * per, t * per + per))
         {
-            const int per = (nb + 255) / 256;
-            uint32_t sum = 0;
-            for (int j = 0; j < per; ++j) {
+            const int per = (nb + 255) / 256;  // (<= 16: nb <= 4096)
+            uint32_t cnts[kMaxBinsPerThread], bases[kMaxBinsPerThread], sum = 0;
+#pragma unroll
+            for (int j = 0; j < kMaxBinsPerThread; ++j) {  // the thread's returning atomics go out back to back: one round trip to the L2, not `per`
                 const int t = tid * per + j;
-                if (t < nb) sum += hist[t];
+                cnts[j] = j < per && t < nb ? hist[t] : 0u;
+                bases[j] = cnts[j] ? atomicAdd(&cursor[(int64_t)band * nb + t], cnts[j]) : 0u;
+                sum += cnts[j];
             }
             const uint32_t incl = block_inclusive_scan(sum, scan_tmp, tid);
             uint32_t at = incl - sum;
-            for (int j = 0; j < per; ++j) {
+#pragma unroll
+            for (int j = 0; j < kMaxBinsPerThread; ++j) {
                 const int t = tid * per + j;
-                if (t < nb) {
-                    const uint32_t c = hist[t];
-                    const uint32_t b = c ? atomicAdd(&cursor[(int64_t)band * nb + t], c) : 0u;
-                    if (b + c > (uint32_t)kBinCap) *overflow = 1u;
-                    base[t] = b;
+                if (j < per && t < nb) {
+                    if (bases[j] + cnts[j] > (uint32_t)kBinCap) *overflow = 1u;
+                    base[t] = bases[j];
                     lstart[t] = at;
                     hist[t] = 0;
-                    at += c;
+                    at += cnts[j];
                 }
             }
         }
@@ -200,68 +191,39 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
 
 __device__ __forceinline__ bool pair_less(uint64_t da, uint32_t ra, uint64_t db, uint32_t rb) { return da < db || (da == db && ra < rb); }
 
-// where every bin's elements go in the output: the sizes of the band's bins before it (one workgroup per band; a bin holds at
-// most kBinCap elements).  Computed once here: lsh_bin_sort_kernel used to sum the band's cursors in every workgroup -- a
-// 512-thread tree reduction, nine barriers per bin.
-__global__ __launch_bounds__(256) void lsh_bin_offsets_kernel(const uint32_t *__restrict__ cursor, int bin_bits, uint32_t *__restrict__ bin_start) {
-    __shared__ uint32_t scan_tmp[4];
-    const int nb = 1 << bin_bits, tid = threadIdx.x;
-    const uint32_t *cur = cursor + (int64_t)blockIdx.x * nb;
-    uint32_t *dst = bin_start + (int64_t)blockIdx.x * nb;
-    const int per = (nb + 255) / 256;
-    uint32_t sum = 0;
-    for (int j = 0; j < per; ++j) {
-        const int t = tid * per + j;
-        if (t < nb) sum += min(cur[t], (uint32_t)kBinCap);
-    }
-    uint32_t at = block_inclusive_scan(sum, scan_tmp, tid) - sum;
-    for (int j = 0; j < per; ++j) {
-        const int t = tid * per + j;
-        if (t < nb) {
-            dst[t] = at;
-            at += min(cur[t], (uint32_t)kBinCap);
-        }
-    }
-}
-
-// One workgroup per (band, bin).  The slab is read ONCE, into registers (at most kBinCap / kSortThreads = 6 elements per thread);
-// bucket sizes are counted from the registers, the elements placed into their buckets in LDS from the registers, ranked inside
-// the bucket and stored to their place in the output.  53 KB of LDS: three workgroups per CU.  (Round 3 read the slab twice --
-// the second time from L2, but each read is a full memory latency in a workgroup that has nothing else to do -- summed the
-// band's cursors itself and, with 2 KB more LDS, fitted twice per CU: 0.44 ms for 40M keys at 2.2 TB/s of traffic,
-// profiles/r05_pmc_sort_and_fused_before.txt.  Measured and dropped in round 5: placing every element in LDS first and
-// streaming the bin out in order -- the scattered stores of a bin merge in the L2 as it is, EA write requests = 64 B x
-// output size; the extra LDS pass cost 4 %.)
-__global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ bin_start,
-                                                           const uint64_t *__restrict__ slab_dig, const uint32_t *__restrict__ slab_row, int64_t n,
-                                                           int32_t bands, int bin_bits, uint64_t *__restrict__ out_dig, uint32_t *__restrict__ out_row) {
+__global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32_t *__restrict__ cursor, const uint64_t *__restrict__ slab_dig,
+                                                           const uint32_t *__restrict__ slab_row, int64_t n, int32_t bands, int bin_bits,
+                                                           uint64_t *__restrict__ out_dig, uint32_t *__restrict__ out_row) {
     __shared__ uint64_t dig[kBinCap];
     __shared__ uint32_t row[kBinCap];
     __shared__ uint32_t cnt[1 << kSubBits], start[1 << kSubBits];
+    __shared__ uint32_t part[kSortThreads];
     __shared__ uint32_t scan_tmp[kSortThreads / 64];
     const int nb = 1 << bin_bits, tid = threadIdx.x;
-    constexpr int kSub = 1 << kSubBits, kPer = kSub / kSortThreads, kMine = (kBinCap + kSortThreads - 1) / kSortThreads;
+    constexpr int kSub = 1 << kSubBits, kPer = kSub / kSortThreads;
     for (int64_t item = blockIdx.x; item < (int64_t)bands * nb; item += gridDim.x) {
         const int64_t band = item >> bin_bits;
-        const uint32_t count = min(cursor[item], (uint32_t)kBinCap);
-        const int64_t out_base = band * n + bin_start[item];
+        const int bin = (int)(item & (nb - 1));
+        const uint32_t *cur = cursor + band * nb;
+        const uint32_t count = min(cur[bin], (uint32_t)kBinCap);
+        // where the bin goes: behind the band's bins before it
+        uint32_t before = 0;
+        for (int t = tid; t < bin; t += kSortThreads) before += min(cur[t], (uint32_t)kBinCap);
+        part[tid] = before;
+        for (int t = tid; t < kSub; t += kSortThreads) cnt[t] = 0;
+        __syncthreads();
+        for (int o = kSortThreads / 2; o > 0; o >>= 1) {
+            if (tid < o) part[tid] += part[tid + o];
+            __syncthreads();
+        }
+        const int64_t out_base = band * n + part[0];
         const int64_t slab = item * kBinCap;
         const auto sub_of = [&](uint64_t d) { return (uint32_t)((bin_bits ? d << bin_bits : d) >> (64 - kSubBits)); };
-        uint64_t my_d[kMine];
-        uint32_t my_r[kMine];
-#pragma unroll
-        for (int u = 0; u < kMine; ++u) {  // (all loads in flight together)
-            const uint32_t i = tid + u * kSortThreads;
-            if (i < count) my_d[u] = slab_dig[slab + i], my_r[u] = slab_row[slab + i];
-        }
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) cnt[tid * kPer + j] = 0;
+        // the slab is read twice (the second time from the L2): bucket sizes first, then every element to its bucket's range
+        // in LDS -- one LDS copy of the bin, three workgroups per CU
+        for (uint32_t i = tid; i < count; i += kSortThreads) atomicAdd(&cnt[sub_of(slab_dig[slab + i])], 1u);
         __syncthreads();
-#pragma unroll
-        for (int u = 0; u < kMine; ++u)
-            if (tid + u * kSortThreads < count) atomicAdd(&cnt[sub_of(my_d[u])], 1u);
-        __syncthreads();
-        // exclusive scan of the 2048 bucket sizes: a thread's buckets, then the threads' sums
+        // exclusive scan of the 2048 bucket sizes: a thread's 8 buckets, then the threads' sums
         uint32_t mine[kPer], sum = 0;
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
@@ -277,30 +239,25 @@ __global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32
             at += mine[j];
         }
         __syncthreads();
-#pragma unroll
-        for (int u = 0; u < kMine; ++u) {
-            if (tid + u * kSortThreads < count) {
-                const uint32_t b = sub_of(my_d[u]);
-                const uint32_t p = start[b] + atomicAdd(&cnt[b], 1u);
-                dig[p] = my_d[u];
-                row[p] = my_r[u];
-            }
+        for (uint32_t i = tid; i < count; i += kSortThreads) {
+            const uint64_t d = slab_dig[slab + i];
+            const uint32_t b = sub_of(d);
+            const uint32_t p = start[b] + atomicAdd(&cnt[b], 1u);
+            dig[p] = d;
+            row[p] = slab_row[slab + i];
         }
         __syncthreads();
         // every element finds its place inside its bucket by counting the bucket's smaller (digest, row) pairs -- one or two
         // comparisons for uniform digests, the bucket's size for a cluster of equal ones (spread over the whole workgroup:
         // an element is a thread's, whatever its bucket) -- and goes straight to its position in the output
-#pragma unroll
-        for (int u = 0; u < kMine; ++u) {
-            if (tid + u * kSortThreads < count) {
-                const uint64_t d = my_d[u];
-                const uint32_t rw = my_r[u];
-                const uint32_t b = sub_of(d), lo = start[b], hi = lo + cnt[b];
-                uint32_t rank = 0;
-                for (uint32_t j = lo; j < hi; ++j) rank += pair_less(dig[j], row[j], d, rw) ? 1u : 0u;
-                out_dig[out_base + lo + rank] = d;
-                out_row[out_base + lo + rank] = rw;
-            }
+        for (uint32_t i = tid; i < count; i += kSortThreads) {
+            const uint64_t d = dig[i];
+            const uint32_t rw = row[i];
+            const uint32_t b = sub_of(d), lo = start[b], hi = lo + cnt[b];
+            uint32_t rank = 0;
+            for (uint32_t j = lo; j < hi; ++j) rank += pair_less(dig[j], row[j], d, rw) ? 1u : 0u;
+            out_dig[out_base + lo + rank] = d;
+            out_row[out_base + lo + rank] = rw;
         }
         __syncthreads();
     }
@@ -327,7 +284,7 @@ __global__ __launch_bounds__(256) void band_keys_with_luggage_kernel(const SigT 
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t row = shift >= 0 ? idx >> shift : idx / bands;
-        const uint64_t dg = band_digest_of<SigT>(sig, row, (int)(idx - row * bands), k, r);
+        const uint64_t dg = band_digest_of<SigT>(sig, row, (int)(idx - row * bands), k, r, n);
         const uint64_t prefix = prefix_key(dg, (uint32_t)(idx - row * bands), band_bits, sort_bits);
         const uint64_t hi = h_bits > 0 ? low_bits(dg >> band_bits, h_bits) : 0;  // bits [band_bits, band_bits + h_bits)
         keys[idx] = prefix | (h_bits > 0 ? hi << sort_bits : 0);
@@ -604,13 +561,13 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     while (bin_bits < kMaxBinBits && (n >> bin_bits) > 2500) ++bin_bits;  // about 1250 .. 2500 elements per bin (kBinCap: 3072)
     if ((n >> bin_bits) > 2500) return MHX_OK;                            // more than 12 million rows: the radix sort
     const int64_t nb = (int64_t)1 << bin_bits, bins = nb * bands;
-    const size_t cur_bytes = ((sizeof(uint32_t) * (size_t)(2 * bins + 1)) + 255) & ~(size_t)255;  // cursor[bins] | overflow | bin_start[bins]
+    const size_t cur_bytes = ((sizeof(uint32_t) * (size_t)(bins + 1)) + 255) & ~(size_t)255;
     const size_t dig_bytes = sizeof(uint64_t) * (size_t)bins * kBinCap, row_bytes = sizeof(uint32_t) * (size_t)bins * kBinCap;
     if (cur_bytes + dig_bytes + row_bytes > (size_t)ctx->hbm_bytes / 4) return MHX_OK;
     // bands whose r values of a row share a 128-byte line go to one workgroup (at most four) -- as far as the teams'
     // staging areas fit the LDS of a workgroup (4096 bins x 4 teams would be 272 KB: ADVICE r3); not even one team
     // fitting, a slab that cannot be had, a launch that is refused: the radix sort below handles every size
-    const int piece = r * (sig_dtype == MHX_U32 ? 4 : 8);  // (digests: r = 1, 8 bytes)
+    const int piece = sig_dtype == kSigDigestsBM ? 128 : r * (sig_dtype == MHX_U32 ? 4 : 8);  // (digests: r = 1, 8 bytes; band-major digests: a team's rows are contiguous, bands share nothing)
     int band_share = piece < 128 && 128 % piece == 0 ? std::min(4, 128 / piece) : 1;
     while (bands % band_share) band_share >>= 1;
     const size_t team_bytes = 8 * (size_t)(256 * kScatterRows) + 8 * ((3 * (size_t)nb * 4 + 256 * kScatterRows * 2 + 16 + 7) / 8);
@@ -620,37 +577,32 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     if (ctx->ensure_scratch(3, cur_bytes + dig_bytes + row_bytes + 256) != MHX_OK) return MHX_OK;
     uint32_t *d_cursor = (uint32_t *)ctx->scratch[3];
     uint32_t *d_overflow = d_cursor + bins;
-    uint32_t *d_bin_start = d_overflow + 1;
     uint64_t *d_slab_dig = (uint64_t *)((char *)ctx->scratch[3] + cur_bytes);
     uint32_t *d_slab_row = (uint32_t *)((char *)ctx->scratch[3] + cur_bytes + dig_bytes);
     MHX_HIP_CHECK(hipMemsetAsync(d_cursor, 0, sizeof(uint32_t) * (size_t)(bins + 1), ctx->stream));
     const int64_t items = (n + 256 * kScatterRows - 1) / (256 * kScatterRows) * (bands / band_share);
     const size_t lds1 = team_bytes * band_share;
     const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(32 / (4 * band_share), (int64_t)((size_t)ctx->lds_per_block / (lds1 + 64))));
-    unsigned grid1 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, (int64_t)ctx->num_cus * per_cu * 2));
-    // band groups that read the same 128-byte lines go to one XCD (see the kernel); option lsh.place = 1: round 3's order
-    const int groups = bands / band_share, group_bytes = piece * band_share;
-    int line_share = group_bytes < 128 && 128 % group_bytes == 0 ? 128 / group_bytes : 0;
-    while (line_share > 1 && groups % line_share) line_share >>= 1;
-    if (line_share <= 1 || 8 % (groups / line_share) != 0 || grid1 < 8 || ctx->opt_lsh_place == 1) line_share = 0;
-    if (line_share > 0) grid1 &= ~7u;
-    if (sig_dtype == kSigDigests)
+    const unsigned grid1 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, (int64_t)ctx->num_cus * per_cu * 2));
+    if (sig_dtype == kSigDigestsBM)
+        hipLaunchKernelGGL(lsh_bin_scatter_kernel<Digest64BM>, dim3(grid1), dim3(256 * band_share), lds1, ctx->stream, (const Digest64BM *)d_sig, k, r, n, bands,
+                           bin_bits, band_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
+    else if (sig_dtype == kSigDigests)
         hipLaunchKernelGGL(lsh_bin_scatter_kernel<Digest64>, dim3(grid1), dim3(256 * band_share), lds1, ctx->stream, (const Digest64 *)d_sig, k, r, n, bands,
-                           bin_bits, band_share, line_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
+                           bin_bits, band_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
     else if (sig_dtype == MHX_U32)
         hipLaunchKernelGGL(lsh_bin_scatter_kernel<uint32_t>, dim3(grid1), dim3(256 * band_share), lds1, ctx->stream, (const uint32_t *)d_sig, k, r, n, bands,
-                           bin_bits, band_share, line_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
+                           bin_bits, band_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
     else
         hipLaunchKernelGGL(lsh_bin_scatter_kernel<uint64_t>, dim3(grid1), dim3(256 * band_share), lds1, ctx->stream, (const uint64_t *)d_sig, k, r, n, bands,
-                           bin_bits, band_share, line_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
+                           bin_bits, band_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
     if (hipGetLastError() != hipSuccess) return MHX_OK;  // (a launch the device refuses: nothing has run, the radix sort takes over)
     uint32_t overflow = 0;
     MHX_HIP_CHECK(hipMemcpyAsync(&overflow, d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (overflow) return MHX_OK;
-    hipLaunchKernelGGL(lsh_bin_offsets_kernel, dim3((unsigned)bands), dim3(256), 0, ctx->stream, d_cursor, bin_bits, d_bin_start);
     hipLaunchKernelGGL(lsh_bin_sort_kernel, dim3((unsigned)std::min<int64_t>(bins, (int64_t)ctx->num_cus * 96)), dim3(kSortThreads), 0, ctx->stream, d_cursor,
-                       d_bin_start, d_slab_dig, d_slab_row, n, bands, bin_bits, d_sorted_digests, d_sorted_rows);
+                       d_slab_dig, d_slab_row, n, bands, bin_bits, d_sorted_digests, d_sorted_rows);
     MHX_HIP_CHECK(hipGetLastError());
     *done = true;
     return MHX_OK;
@@ -696,7 +648,10 @@ int launch_lsh_sort_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_
     const bool luggage = n <= ((int64_t)1 << (32 - band_bits)) && ctx->opt_lsh_gather != 1;  // the row and band_bits digest bits fit the 32-bit value
     if (luggage) {
         // the digest region receives the sorted values, d_sorted_rows the final rows
-        if (sig_dtype == kSigDigests)
+        if (sig_dtype == kSigDigestsBM)
+            hipLaunchKernelGGL(band_keys_with_luggage_kernel<Digest64BM>, dim3(grid_for(ctx, total)), dim3(256), 0, ctx->stream, (const Digest64BM *)d_sig, k, r, n,
+                               bands, band_bits, sort_bits, d_keys, d_rows);
+        else if (sig_dtype == kSigDigests)
             hipLaunchKernelGGL(band_keys_with_luggage_kernel<Digest64>, dim3(grid_for(ctx, total)), dim3(256), 0, ctx->stream, (const Digest64 *)d_sig, k, r, n,
                                bands, band_bits, sort_bits, d_keys, d_rows);
         else if (sig_dtype == MHX_U32)
@@ -714,14 +669,15 @@ int launch_lsh_sort_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_
                            d_keys_sorted, d_sorted_digests, d_sorted_rows);
     } else {
         const uint64_t *d_dig_in = d_dig;
-        if (sig_dtype == kSigDigests) d_dig_in = static_cast<const uint64_t *>(d_sig);  // they are there already
+        const int band_major = sig_dtype == kSigDigestsBM ? 1 : 0;
+        if (sig_dtype == kSigDigests || sig_dtype == kSigDigestsBM) d_dig_in = static_cast<const uint64_t *>(d_sig);  // they are there already
         else if (int rc = launch_band_digests(ctx, d_sig, sig_dtype, n, k, bands, r, d_dig)) return rc;
-        hipLaunchKernelGGL(band_keys_for_sort_kernel, grid, dim3(256), 0, ctx->stream, d_dig_in, n, bands, band_bits, sort_bits, d_keys, d_rows);
+        hipLaunchKernelGGL(band_keys_for_sort_kernel, grid, dim3(256), 0, ctx->stream, d_dig_in, n, bands, band_bits, sort_bits, band_major, d_keys, d_rows);
         MHX_HIP_CHECK(hipGetLastError());
         e = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, (const uint64_t *)d_keys, d_keys_sorted, (const uint32_t *)d_rows,
                                       d_sorted_rows, (size_t)total, 0, sort_bits, ctx->stream);
         if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_pairs failed: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL(gather_digests_kernel, grid, dim3(256), 0, ctx->stream, d_dig_in, d_sorted_rows, n, bands, total,
+        hipLaunchKernelGGL(gather_digests_kernel, grid, dim3(256), 0, ctx->stream, d_dig_in, d_sorted_rows, n, bands, total, band_major,
                            d_sorted_digests);
     }
     MHX_HIP_CHECK(hipMemsetAsync(d_mixed, 0, (size_t)total, ctx->stream));

@@ -372,7 +372,6 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "lsh.sort_bits")) ctx->opt_lsh_sort_bits = value;
     else if (!strcmp(key, "lsh.gather")) ctx->opt_lsh_gather = value;
     else if (!strcmp(key, "lsh.sort")) ctx->opt_lsh_sort = value;
-    else if (!strcmp(key, "lsh.place")) ctx->opt_lsh_place = value;
     else if (!strcmp(key, "pack.fused")) ctx->opt_pack_fused = value;
     else if (!strcmp(key, "weighted.refill")) ctx->opt_weighted_refill = value;
     else return fail(MHX_ERR_INVALID, "unknown option '%s'", key);
@@ -1023,22 +1022,28 @@ int mhx_bbit_pack_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int6
     return mhx::launch_bbit_pack(ctx, d_sig, sig_dtype, n, k, b, d_out);
 }
 
-int mhx_band_digests_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t bands,
-                               int32_t r, uint64_t *d_out) {
+int mhx_band_digests_layout_dev(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t bands,
+                                int32_t r, int layout, uint64_t *d_out) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
     MHX_GUARD(ctx);
     MHX_REQUIRE(sig_dtype == MHX_U64 || sig_dtype == MHX_U32, "bad sig_dtype %d", sig_dtype);
     MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
     MHX_REQUIRE(n >= 0, "bad shape");
+    MHX_REQUIRE(layout == MHX_ROW_MAJOR || layout == MHX_BAND_MAJOR, "bad layout %d", layout);
     if (n == 0) return MHX_OK;
     MHX_REQUIRE(d_sig && d_out, "NULL device pointer");
     if (int rc = ctx->activate()) return rc;
-    return mhx::launch_band_digests(ctx, d_sig, sig_dtype, n, k, bands, r, d_out);
+    return mhx::launch_band_digests(ctx, d_sig, sig_dtype, n, k, bands, r, d_out, layout);
+}
+
+int mhx_band_digests_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t bands,
+                               int32_t r, uint64_t *d_out) {
+    return mhx_band_digests_layout_dev(ctx, d_sig, sig_dtype, n, k, bands, r, MHX_ROW_MAJOR, d_out);
 }
 
 // b-bit blocks and band digests of the same matrix: one read when the shape allows the fused kernel, the two kernels otherwise
 int mhx_bbit_pack_band_digests_dev(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t b,
-                                   int32_t bands, int32_t r, uint64_t *d_blocks, uint64_t *d_digests, int *fused) {
+                                   int32_t bands, int32_t r, int digest_layout, uint64_t *d_blocks, uint64_t *d_digests, int *fused) {
     if (fused) *fused = 0;
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
     MHX_GUARD(ctx);
@@ -1046,16 +1051,17 @@ int mhx_bbit_pack_band_digests_dev(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     MHX_REQUIRE(b >= 1 && b <= 32, "b must be in [1, 32]");
     MHX_REQUIRE(bands > 0 && r > 0 && (int64_t)bands * r <= k, "bands*r must be in (0, num_perm]");
     MHX_REQUIRE(n >= 0 && k > 0, "bad shape");
+    MHX_REQUIRE(digest_layout == MHX_ROW_MAJOR || digest_layout == MHX_BAND_MAJOR, "bad layout %d", digest_layout);
     if (n == 0) return MHX_OK;
     MHX_REQUIRE(d_sig && d_blocks && d_digests, "NULL device pointer");
     if (int rc = ctx->activate()) return rc;
     bool done = false;
     if (ctx->opt_pack_fused != 1)
-        if (int rc = mhx::launch_bbit_digest_fused(ctx, d_sig, sig_dtype, n, k, b, bands, r, d_blocks, d_digests, &done)) return rc;
+        if (int rc = mhx::launch_bbit_digest_fused(ctx, d_sig, sig_dtype, n, k, b, bands, r, d_blocks, d_digests, digest_layout, &done)) return rc;
     if (fused) *fused = done ? 1 : 0;
     if (done) return MHX_OK;
     if (int rc = mhx::launch_bbit_pack(ctx, d_sig, sig_dtype, n, k, b, d_blocks)) return rc;
-    return mhx::launch_band_digests(ctx, d_sig, sig_dtype, n, k, bands, r, d_digests);
+    return mhx::launch_band_digests(ctx, d_sig, sig_dtype, n, k, bands, r, d_digests, digest_layout);
 }
 
 int mhx_lsh_sort_bands_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t bands,
@@ -1181,15 +1187,21 @@ int mhx_band_digests(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, in
     return fetch_out(ctx, out, out_bytes);
 }
 
-int mhx_lsh_sort_digests_dev(mhx_ctx *ctx, const uint64_t *d_digests, int64_t n, int32_t bands, uint64_t *d_sorted_digests,
+int mhx_lsh_sort_digests_layout_dev(mhx_ctx *ctx, const uint64_t *d_digests, int64_t n, int32_t bands, int layout, uint64_t *d_sorted_digests,
                              uint32_t *d_sorted_rows) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
     MHX_GUARD(ctx);
     MHX_REQUIRE(n >= 0 && bands > 0, "bad shape");
+    MHX_REQUIRE(layout == MHX_ROW_MAJOR || layout == MHX_BAND_MAJOR, "bad layout %d", layout);
     if (n == 0) return MHX_OK;
     MHX_REQUIRE(d_digests && d_sorted_digests && d_sorted_rows, "NULL device pointer");
     if (int rc = ctx->activate()) return rc;
-    return mhx::launch_lsh_sort_bands(ctx, d_digests, mhx::kSigDigests, n, bands, bands, 1, d_sorted_digests, d_sorted_rows);
+    return mhx::launch_lsh_sort_bands(ctx, d_digests, layout == MHX_BAND_MAJOR ? mhx::kSigDigestsBM : mhx::kSigDigests, n, bands, bands, 1, d_sorted_digests, d_sorted_rows);
+}
+
+int mhx_lsh_sort_digests_dev(mhx_ctx *ctx, const uint64_t *d_digests, int64_t n, int32_t bands, uint64_t *d_sorted_digests,
+                             uint32_t *d_sorted_rows) {
+    return mhx_lsh_sort_digests_layout_dev(ctx, d_digests, n, bands, MHX_ROW_MAJOR, d_sorted_digests, d_sorted_rows);
 }
 
 int mhx_lsh_sort_bands_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands, int32_t r,

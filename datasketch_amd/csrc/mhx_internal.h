@@ -31,6 +31,7 @@ int fail(int code, const char *fmt, ...);
 
 // internal "signature type" of launch_lsh_sort_bands: the matrix holds band digests already ([n, bands] uint64)
 constexpr int kSigDigests = 2;
+constexpr int kSigDigestsBM = 3;  // ... band-major ([bands, n])
 
 // mhx_ctx::d_work: 16 counter words, then the list of sets the second MinHash launch leaves to the pairwise one
 constexpr unsigned int kPairListCap = 16384;
@@ -87,7 +88,6 @@ struct mhx_ctx {
     int64_t opt_lsh_sort = 0;       // mhx_lsh_sort_bands: 0 auto (two-pass bucketing, radix sort when a bin would overflow), 1 radix sort
     int64_t opt_lsh_gather = 0;     // mhx_lsh_sort_bands: 1 = gather the full digests after the sort (the fallback path) even when they could ride along
     int64_t opt_lsh_sort_bits = 0;  // mhx_lsh_sort_bands: bits of (band, digest) the radix sort orders by; 0 = from n
-    int64_t opt_lsh_place = 0;      // lsh_bin_scatter_kernel: 0 = band groups that share 128-byte lines of the input run on one XCD, 1 = round 3's order (band group x on XCD x)
     int64_t opt_pack_fused = 0;     // mhx_bbit_pack_band_digests_dev: 0 auto (one read of the matrix where the shape allows), 1 = always the two kernels
     int64_t opt_weighted_refill = 0; // one-wave-per-row walk: 0 = the next row's loads go out behind the walk, 1 = right after staging (A/B)
     int64_t opt_host_chunk_bytes = 0;  // mhx_minhash_bulk: bytes per pipelined piece; 0 auto (96 MiB, inputs > 256 MiB), < 0 never pipeline
@@ -168,9 +168,9 @@ int launch_bbit_pack(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, 
 int launch_band_keys(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int32_t bands,
                      int32_t r, uint64_t *d_out);
 int launch_band_digests(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t bands, int32_t r,
-                        uint64_t *d_out);
+                        uint64_t *d_out, int layout = 0);
 int launch_bbit_digest_fused(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t b, int32_t bands,
-                             int32_t r, uint64_t *d_blocks, uint64_t *d_digests, bool *done);
+                             int32_t r, uint64_t *d_blocks, uint64_t *d_digests, int layout, bool *done);
 int launch_jaccard_pairs(mhx_ctx *ctx, const void *d_a, const void *d_b, int sig_dtype, int32_t k, const int64_t *d_pairs,
                          int64_t m, int32_t *d_counts);
 int launch_weighted_dense(mhx_wgen *gen, const float *d_x, int values_are_logs, int64_t n_rows, int64_t *d_out,

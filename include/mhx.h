@@ -383,10 +383,21 @@ MHX_API int mhx_band_digests_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_
  * (mhx_band_digests*: ref datasketch/lsh.py:199,344,537-543) of the same [n, num_perm] matrix.  When bands is a power of
  * two <= 64, r is 4, 8 or 16, bands * r == num_perm and rows are 16-byte aligned, ONE kernel reads the matrix once and
  * writes both outputs (*fused = 1); any other shape runs the two kernels one after the other (*fused = 0).  Results are
- * those of the two separate calls, bit for bit.  d_blocks: uint64[n, num_blocks], d_digests: uint64[n, bands]. */
+ * those of the two separate calls, bit for bit.  d_blocks: uint64[n, num_blocks], d_digests: uint64[n, bands] or, with digest_layout =
+ * MHX_BAND_MAJOR, uint64[bands, n]. */
 MHX_API int mhx_bbit_pack_band_digests_dev(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n_sigs,
-                                           int32_t num_perm, int32_t b, int32_t bands, int32_t r,
+                                           int32_t num_perm, int32_t b, int32_t bands, int32_t r, int digest_layout,
                                            uint64_t *d_blocks, uint64_t *d_digests, int *fused);
+/* Layout of a band-digest matrix on the device.  MHX_ROW_MAJOR: [n, bands] (row i's digests together: the keys of one
+ * signature, what a host-side index wants).  MHX_BAND_MAJOR: [bands, n] (band j's digests of all rows together: one
+ * array per hashtable, ref datasketch/lsh.py:199 -- and what the bucketing reads with unit stride: from a row-major
+ * matrix every 128-byte line is fetched by the four XCDs whose bands share it, 1.30 GB of reads for a 320 MB matrix). */
+#define MHX_ROW_MAJOR 0
+#define MHX_BAND_MAJOR 1
+MHX_API int mhx_band_digests_layout_dev(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n_sigs,
+                                        int32_t num_perm, int32_t bands, int32_t r, int layout, uint64_t *d_out);
+MHX_API int mhx_lsh_sort_digests_layout_dev(mhx_ctx *ctx, const uint64_t *d_digests, int64_t n_sigs, int32_t bands,
+                                            int layout, uint64_t *d_sorted_digests, uint32_t *d_sorted_rows);
 MHX_API int mhx_lsh_sort_bands_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n_sigs,
                                          int32_t num_perm, int32_t bands, int32_t r,
                                          uint64_t *d_sorted_digests, uint32_t *d_sorted_rows);

@@ -48,11 +48,13 @@ def main():
                                        keep_on_device=True, transport=os.environ.get("MHX_TEST_TRANSPORT", "host"))
     nb = k // 64
     d_blk, d_dig = ctx.alloc(n * nb * 8), ctx.alloc(n * bands * 8)
-    fused = ctx.bbit_pack_band_digests_dev(got.buffer.ptr, _native.MHX_U32, n, k, 1, bands, r, d_blk.ptr, d_dig.ptr)
+    # the digests band-major ([bands, n]: what the bucketing reads with unit stride), the layout the chain runs on
+    fused = ctx.bbit_pack_band_digests_dev(got.buffer.ptr, _native.MHX_U32, n, k, 1, bands, r, d_blk.ptr, d_dig.ptr, _native.BAND_MAJOR)
     d_sd, d_sr = ctx.alloc(n * bands * 8), ctx.alloc(n * bands * 4)
-    _native.check(lib.mhx_lsh_sort_digests_dev(ctx.handle, d_dig.ptr, n, bands, d_sd.ptr, d_sr.ptr))
+    _native.check(lib.mhx_lsh_sort_digests_layout_dev(ctx.handle, d_dig.ptr, n, bands, _native.BAND_MAJOR, d_sd.ptr, d_sr.ptr))
     ctx.synchronize()
-    arrays = {"sig": got.to_host(np.uint32), "blocks": d_blk.download((n, nb), np.uint64), "digests": d_dig.download((n, bands), np.uint64),
+    arrays = {"sig": got.to_host(np.uint32), "blocks": d_blk.download((n, nb), np.uint64),
+              "digests": np.ascontiguousarray(d_dig.download((bands, n), np.uint64).T),
               "sorted_digests": d_sd.download((bands, n), np.uint64), "sorted_rows": d_sr.download((bands, n), np.uint32)}
     rec = {"rank": group.rank, "world": group.world, "counts": counts, "transport": got.transport, "fused": bool(fused),
            "sha": {name: hashlib.sha256(a.tobytes()).hexdigest() for name, a in arrays.items()}}
