@@ -75,8 +75,9 @@ constexpr int kBinCap = 3072;
 constexpr int kScatterRows = 8;   // rows per thread of pass 1 (2048 per workgroup: 26 KB of LDS, six workgroups per CU)
 constexpr int kSubBits = 10;  // (11 until round 5: 8 KB less LDS puts three workgroups on a CU instead of two, 0.45 -> 0.35 ms for 40M keys; 9 bits and a fourth workgroup gain nothing)
 constexpr int kSortThreads = 512;
-constexpr int kMaxBinBits = 12;
-constexpr int kMaxBinsPerThread = (1 << kMaxBinBits) / 256;
+constexpr int kMaxBinBits = 14;        // final bins per band (two levels beyond kOneLevelBits)
+constexpr int kOneLevelBits = 10;      // at most this many bits in one scatter pass
+constexpr int kMaxBinsPerThread = (1 << kOneLevelBits) / 256;
 
 // inclusive prefix sum over the threads of a workgroup: shuffles inside a wave, the wave totals through LDS
 __device__ __forceinline__ uint32_t block_inclusive_scan(uint32_t v, uint32_t *tmp4, int tid) {
@@ -100,51 +101,80 @@ __device__ __forceinline__ uint32_t bin_of(uint64_t digest, int bin_bits) { retu
 // bands of a group are the ones whose r values of a row share a 128-byte line: the teams load in lock step, so the line
 // comes from HBM once (one workgroup per band left that to the L2 -- whose 4 MB turn over in microseconds under this
 // stream: 1.04 ms for the pass instead of 0.5).
+//
+// Two levels (round 5).  With more than 1024 bins a chunk of 2048 rows leaves one or two elements per bin: 8-byte runs, every
+// one a partial write (10M rows = 4096 bins: 22 ms for 320M keys, 0.04 of HBM).  So beyond 2^10 bins the split is done in two
+// scatter passes of about the square root each: level 0 spreads a band over 2^hi big bins (slabs of `cap` = n / 2^hi + slack
+// elements), level 1 takes every big bin as its source (SlabPairs: (digest, row) pairs instead of a signature matrix) and
+// spreads it over its 2^lo final bins -- the same slabs and cursors a one-level split would have filled, so pass 2 does not
+// know the difference.  A source "unit" is a band (level 0 / one level) or a (band, big bin); its elements' output bin inside
+// the band is the top hi + lo digest bits, of which the low lo bits index the team's histogram.
+struct SlabPairs {};  // source of level 1: src_dig / src_row slabs of src_cap elements per unit, src_cursor[unit] of them filled
+
 template <typename SigT>
-__global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__restrict__ sig, int32_t k, int32_t r, int64_t n, int32_t bands,
-                                                               int bin_bits, int band_share, uint32_t *__restrict__ cursor,
-                                                               uint64_t *__restrict__ slab_dig, uint32_t *__restrict__ slab_row,
-                                                               uint32_t *__restrict__ overflow) {
+__global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__restrict__ sig, int32_t k, int32_t r, int64_t n, int32_t units,
+                                                               int hi_bits, int lo_bits, int band_share, uint32_t cap,
+                                                               uint32_t *__restrict__ cursor, uint64_t *__restrict__ slab_dig,
+                                                               uint32_t *__restrict__ slab_row, uint32_t *__restrict__ overflow,
+                                                               const uint64_t *__restrict__ src_dig, const uint32_t *__restrict__ src_row,
+                                                               const uint32_t *__restrict__ src_cursor, uint32_t src_cap) {
+    constexpr bool kPairs = std::is_same<SigT, SlabPairs>::value;
+    using RowT = typename std::conditional<kPairs, uint32_t, uint16_t>::type;  // staged per element: the row itself, or row - row0
     constexpr int kChunk = 256 * kScatterRows;
-    extern __shared__ uint64_t scatter_lds[];  // per team: st_dig[kChunk] | hist[nb] | base[nb] | lstart[nb] | st_row u16[kChunk] | scan_tmp[4]
-    const int nb = 1 << bin_bits, team = threadIdx.x >> 8, tid = threadIdx.x & 255;
-    const size_t team_words = kChunk + (3 * (size_t)nb * 4 + kChunk * 2 + 16 + 7) / 8;
+    extern __shared__ uint64_t scatter_lds[];  // per team: st_dig[kChunk] | hist[nb] | base[nb] | lstart[nb] | st_row RowT[kChunk] | scan_tmp[4]
+    const int nb = 1 << lo_bits, team = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const size_t team_words = kChunk + (3 * (size_t)nb * 4 + kChunk * sizeof(RowT) + 16 + 7) / 8;
     uint64_t *st_dig = scatter_lds + team * team_words;  // the chunk's elements grouped by bin before they go out
     uint32_t *hist = reinterpret_cast<uint32_t *>(st_dig + kChunk), *base = hist + nb, *lstart = base + nb;
-    uint16_t *st_row = reinterpret_cast<uint16_t *>(lstart + nb);  // row - row0
+    RowT *st_row = reinterpret_cast<RowT *>(lstart + nb);
     uint32_t *scan_tmp = reinterpret_cast<uint32_t *>(st_row + kChunk);
-    const int64_t chunks = (n + kChunk - 1) / kChunk;
-    const int groups = bands / band_share;
-    // item = band group fastest: with 8 band groups and a grid that is a multiple of 8, band group x is always on XCD x (workgroups
-    // go round the XCDs), whose L2 then merges the short runs of that band's bins into whole lines.  (Measured and dropped in round 5:
-    // dealing the band groups that share 128-byte input lines of a ROW-major digest matrix to one XCD -- reads 1.30 GB -> 0.32 GB, but
-    // 16 bands' slabs per XCD no longer merge: writes 0.62 -> 1.02 GB in 32-byte requests, 447 -> 493 us,
+    const int64_t span = kPairs ? (int64_t)src_cap : n;  // a unit's elements are [0, count) with count <= span
+    const int64_t chunks = (span + kChunk - 1) / kChunk;
+    const int groups = units / band_share;
+    const int tot_bits = hi_bits + lo_bits;
+    // item = unit group fastest: with 8 groups and a grid that is a multiple of 8, group x is always on XCD x (workgroups go round
+    // the XCDs), whose L2 then merges the short runs of its bins into whole lines.  (Measured and dropped in round 5: dealing the
+    // band groups that share 128-byte input lines of a ROW-major digest matrix to one XCD -- reads 1.30 GB -> 0.32 GB, but 16
+    // bands' slabs per XCD no longer merge: writes 0.62 -> 1.02 GB in 32-byte requests, 447 -> 493 us,
     // profiles/r05_pmc_scatter_work_orders.txt.  The band-major input (Digest64BM) keeps both properties.)
     for (int64_t item = blockIdx.x; item < chunks * groups; item += gridDim.x) {
-        const int band = (int)(item % groups) * band_share + team;
+        const int unit = (int)(item % groups) * band_share + team;
         const int64_t row0 = item / groups * kChunk;
+        const int64_t count = kPairs ? (int64_t)min(src_cursor[unit], src_cap) : n;
+        if (kPairs && row0 >= count) continue;  // (band_share is 1 for pair sources: workgroup-uniform)
+        const int band = kPairs ? unit >> hi_bits : unit;
+        const int64_t src0 = kPairs ? (int64_t)unit * src_cap : 0;
         for (int t = tid; t < nb; t += 256) hist[t] = 0;
         __syncthreads();
+        // the element's bin inside the band (top hi + lo digest bits) and inside this source unit (the low lo bits of that)
+        const auto gbin_of = [&](uint64_t d) { return tot_bits ? (uint32_t)(d >> (64 - tot_bits)) : 0u; };
         uint64_t dg[kScatterRows];
+        uint32_t rw[kPairs ? kScatterRows : 1];
 #pragma unroll
         for (int j = 0; j < kScatterRows; ++j) {
             const int64_t row = row0 + j * 256 + tid;
-            if (row < n) {
-                dg[j] = band_digest_of<SigT>(sig, row, band, k, r, n);
-                atomicAdd(&hist[bin_of(dg[j], bin_bits)], 1u);
+            if (row < count) {
+                if constexpr (kPairs) {
+                    dg[j] = src_dig[src0 + row];
+                    rw[j] = src_row[src0 + row];
+                } else {
+                    dg[j] = band_digest_of<SigT>(sig, row, band, k, r, n);
+                }
+                atomicAdd(&hist[gbin_of(dg[j]) & (nb - 1)], 1u);
             }
         }
         __syncthreads();
         // per bin: a range of its slab (one global atomic) and the start of its elements in the team's staging area
         // (exclusive scan of the counts: thread t owns bins [t * per, t * per + per))
+        const int64_t out0 = ((int64_t)band << tot_bits) + (kPairs ? (int64_t)(unit & ((1 << hi_bits) - 1)) << lo_bits : 0);  // the unit's first output bin
         {
-            const int per = (nb + 255) / 256;  // (<= 16: nb <= 4096)
+            const int per = (nb + 255) / 256;  // (<= kMaxBinsPerThread)
             uint32_t cnts[kMaxBinsPerThread], bases[kMaxBinsPerThread], sum = 0;
 #pragma unroll
             for (int j = 0; j < kMaxBinsPerThread; ++j) {  // the thread's returning atomics go out back to back: one round trip to the L2, not `per`
                 const int t = tid * per + j;
                 cnts[j] = j < per && t < nb ? hist[t] : 0u;
-                bases[j] = cnts[j] ? atomicAdd(&cursor[(int64_t)band * nb + t], cnts[j]) : 0u;
+                bases[j] = cnts[j] ? atomicAdd(&cursor[out0 + t], cnts[j]) : 0u;
                 sum += cnts[j];
             }
             const uint32_t incl = block_inclusive_scan(sum, scan_tmp, tid);
@@ -153,7 +183,7 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
             for (int j = 0; j < kMaxBinsPerThread; ++j) {
                 const int t = tid * per + j;
                 if (j < per && t < nb) {
-                    if (bases[j] + cnts[j] > (uint32_t)kBinCap) *overflow = 1u;
+                    if (bases[j] + cnts[j] > cap) *overflow = 1u;
                     base[t] = bases[j];
                     lstart[t] = at;
                     hist[t] = 0;
@@ -165,24 +195,25 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
 #pragma unroll
         for (int j = 0; j < kScatterRows; ++j) {
             const int64_t row = row0 + j * 256 + tid;
-            if (row < n) {
-                const uint32_t bin = bin_of(dg[j], bin_bits);
+            if (row < count) {
+                const uint32_t bin = gbin_of(dg[j]) & (nb - 1);
                 const uint32_t lp = lstart[bin] + atomicAdd(&hist[bin], 1u);
                 st_dig[lp] = dg[j];
-                st_row[lp] = (uint16_t)(j * 256 + tid);
+                if constexpr (kPairs) st_row[lp] = rw[j];
+                else st_row[lp] = (uint16_t)(j * 256 + tid);
             }
         }
         __syncthreads();
         // out: consecutive threads carry consecutive elements of a bin -- every (team, bin) piece is one contiguous run
-        const uint32_t total = (uint32_t)min((int64_t)kChunk, n - row0);
+        const uint32_t total = (uint32_t)min((int64_t)kChunk, count - row0);
         for (uint32_t i = tid; i < total; i += 256) {
             const uint64_t d = st_dig[i];
-            const uint32_t bin = bin_of(d, bin_bits);
+            const uint32_t bin = gbin_of(d) & (nb - 1);
             const uint32_t pos = base[bin] + (i - lstart[bin]);
-            if (pos < (uint32_t)kBinCap) {
-                const int64_t at = ((int64_t)band * nb + bin) * kBinCap + pos;
+            if (pos < cap) {
+                const int64_t at = (out0 + bin) * cap + pos;
                 slab_dig[at] = d;
-                slab_row[at] = (uint32_t)(row0 + st_row[i]);
+                slab_row[at] = kPairs ? (uint32_t)st_row[i] : (uint32_t)(row0 + st_row[i]);
             }
         }
         __syncthreads();
@@ -554,53 +585,88 @@ int launch_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *d_sorted_digests, c
 }
 
 // the two-pass bucketing; *done = false when a bin overflowed (the caller falls back to the radix sort)
+// one scatter pass (see lsh_bin_scatter_kernel); returns false when the launch is refused
+template <typename SigT>
+static bool launch_scatter(mhx_ctx *ctx, const SigT *d_sig, int32_t k, int32_t r, int64_t n, int32_t units, int hi_bits, int lo_bits, int band_share,
+                           uint32_t cap, uint32_t *d_cursor, uint64_t *d_slab_dig, uint32_t *d_slab_row, uint32_t *d_overflow, const uint64_t *d_src_dig,
+                           const uint32_t *d_src_row, const uint32_t *d_src_cursor, uint32_t src_cap, size_t team_bytes) {
+    const int64_t span = std::is_same<SigT, SlabPairs>::value ? (int64_t)src_cap : n;
+    const int64_t items = (span + 256 * kScatterRows - 1) / (256 * kScatterRows) * (units / band_share);
+    const size_t lds = team_bytes * band_share;
+    const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(32 / (4 * band_share), (int64_t)((size_t)ctx->lds_per_block / (lds + 64))));
+    const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, (int64_t)ctx->num_cus * per_cu * 2));
+    hipLaunchKernelGGL(lsh_bin_scatter_kernel<SigT>, dim3(grid), dim3(256 * band_share), lds, ctx->stream, d_sig, k, r, n, units, hi_bits, lo_bits, band_share, cap,
+                       d_cursor, d_slab_dig, d_slab_row, d_overflow, d_src_dig, d_src_row, d_src_cursor, src_cap);
+    return hipGetLastError() == hipSuccess;
+}
+
+static size_t scatter_team_bytes(int lo_bits, bool pairs) {
+    const size_t nb = (size_t)1 << lo_bits, chunk = 256 * kScatterRows;
+    return 8 * chunk + 8 * ((3 * nb * 4 + chunk * (pairs ? 4 : 2) + 16 + 7) / 8);
+}
+
+// the two-pass (or, beyond 2^10 bins per band, three-pass) bucketing; *done = false when a bin overflowed or a resource could not
+// be had (the caller falls back to the radix sort, which handles every size)
 static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int32_t bands, int32_t r,
                                    uint64_t *d_sorted_digests, uint32_t *d_sorted_rows, bool *done) {
     *done = false;
     int bin_bits = 0;
     while (bin_bits < kMaxBinBits && (n >> bin_bits) > 2500) ++bin_bits;  // about 1250 .. 2500 elements per bin (kBinCap: 3072)
-    if ((n >> bin_bits) > 2500) return MHX_OK;                            // more than 12 million rows: the radix sort
+    if ((n >> bin_bits) > 2500) return MHX_OK;                            // more than 41 million rows: the radix sort
+    // beyond 2^10 bins: two scatter levels of about half the bits each (see the kernel)
+    const int hi_bits = bin_bits > kOneLevelBits || (ctx->opt_lsh_levels == 2 && bin_bits >= 2) ? bin_bits / 2 : 0, lo_bits = bin_bits - hi_bits;  // (option lsh.levels = 2: two levels at any size, for the tests)
     const int64_t nb = (int64_t)1 << bin_bits, bins = nb * bands;
-    const size_t cur_bytes = ((sizeof(uint32_t) * (size_t)(bins + 1)) + 255) & ~(size_t)255;
+    const int64_t big_bins = hi_bits ? ((int64_t)bands << hi_bits) : 0;
+    const uint32_t cap0 = hi_bits ? (uint32_t)std::min<int64_t>(0xFFFFFFFFll, (n >> hi_bits) + (n >> hi_bits) / 32 + 4096) : 0;  // 3 % + 4096 over the mean (sigma = sqrt(mean))
+    const size_t cur_bytes = ((sizeof(uint32_t) * (size_t)(bins + big_bins + 2)) + 255) & ~(size_t)255;  // cursor[bins] | overflow | cursor0[big_bins] | overflow0
     const size_t dig_bytes = sizeof(uint64_t) * (size_t)bins * kBinCap, row_bytes = sizeof(uint32_t) * (size_t)bins * kBinCap;
-    if (cur_bytes + dig_bytes + row_bytes > (size_t)ctx->hbm_bytes / 4) return MHX_OK;
+    const size_t dig0_bytes = ((sizeof(uint64_t) * (size_t)big_bins * cap0) + 255) & ~(size_t)255, row0_bytes = ((sizeof(uint32_t) * (size_t)big_bins * cap0) + 255) & ~(size_t)255;
+    if (cur_bytes + dig_bytes + row_bytes + dig0_bytes + row0_bytes > (size_t)ctx->hbm_bytes / 4) return MHX_OK;
     // bands whose r values of a row share a 128-byte line go to one workgroup (at most four) -- as far as the teams'
-    // staging areas fit the LDS of a workgroup (4096 bins x 4 teams would be 272 KB: ADVICE r3); not even one team
-    // fitting, a slab that cannot be had, a launch that is refused: the radix sort below handles every size
+    // staging areas fit the LDS of a workgroup; not even one team fitting, a slab that cannot be had, a launch that is
+    // refused: the radix sort handles every size
     const int piece = sig_dtype == kSigDigestsBM ? 128 : r * (sig_dtype == MHX_U32 ? 4 : 8);  // (digests: r = 1, 8 bytes; band-major digests: a team's rows are contiguous, bands share nothing)
     int band_share = piece < 128 && 128 % piece == 0 ? std::min(4, 128 / piece) : 1;
     while (bands % band_share) band_share >>= 1;
-    const size_t team_bytes = 8 * (size_t)(256 * kScatterRows) + 8 * ((3 * (size_t)nb * 4 + 256 * kScatterRows * 2 + 16 + 7) / 8);
+    const int first_bits = hi_bits ? hi_bits : lo_bits;  // bits of the pass that reads the signatures
+    const size_t team_bytes = scatter_team_bytes(first_bits, false);
     const size_t lds_limit = (size_t)ctx->lds_per_block;
     while (band_share > 1 && team_bytes * band_share > lds_limit) band_share >>= 1;
-    if (team_bytes * band_share > lds_limit) return MHX_OK;
-    if (ctx->ensure_scratch(3, cur_bytes + dig_bytes + row_bytes + 256) != MHX_OK) return MHX_OK;
-    uint32_t *d_cursor = (uint32_t *)ctx->scratch[3];
+    if (team_bytes * band_share > lds_limit || scatter_team_bytes(lo_bits, true) > lds_limit) return MHX_OK;
+    if (ctx->ensure_scratch(3, cur_bytes + dig_bytes + row_bytes + dig0_bytes + row0_bytes + 256) != MHX_OK) return MHX_OK;
+    char *base = (char *)ctx->scratch[3];
+    uint32_t *d_cursor = (uint32_t *)base;
     uint32_t *d_overflow = d_cursor + bins;
-    uint64_t *d_slab_dig = (uint64_t *)((char *)ctx->scratch[3] + cur_bytes);
-    uint32_t *d_slab_row = (uint32_t *)((char *)ctx->scratch[3] + cur_bytes + dig_bytes);
-    MHX_HIP_CHECK(hipMemsetAsync(d_cursor, 0, sizeof(uint32_t) * (size_t)(bins + 1), ctx->stream));
-    const int64_t items = (n + 256 * kScatterRows - 1) / (256 * kScatterRows) * (bands / band_share);
-    const size_t lds1 = team_bytes * band_share;
-    const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(32 / (4 * band_share), (int64_t)((size_t)ctx->lds_per_block / (lds1 + 64))));
-    const unsigned grid1 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, (int64_t)ctx->num_cus * per_cu * 2));
-    if (sig_dtype == kSigDigestsBM)
-        hipLaunchKernelGGL(lsh_bin_scatter_kernel<Digest64BM>, dim3(grid1), dim3(256 * band_share), lds1, ctx->stream, (const Digest64BM *)d_sig, k, r, n, bands,
-                           bin_bits, band_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
-    else if (sig_dtype == kSigDigests)
-        hipLaunchKernelGGL(lsh_bin_scatter_kernel<Digest64>, dim3(grid1), dim3(256 * band_share), lds1, ctx->stream, (const Digest64 *)d_sig, k, r, n, bands,
-                           bin_bits, band_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
-    else if (sig_dtype == MHX_U32)
-        hipLaunchKernelGGL(lsh_bin_scatter_kernel<uint32_t>, dim3(grid1), dim3(256 * band_share), lds1, ctx->stream, (const uint32_t *)d_sig, k, r, n, bands,
-                           bin_bits, band_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
-    else
-        hipLaunchKernelGGL(lsh_bin_scatter_kernel<uint64_t>, dim3(grid1), dim3(256 * band_share), lds1, ctx->stream, (const uint64_t *)d_sig, k, r, n, bands,
-                           bin_bits, band_share, d_cursor, d_slab_dig, d_slab_row, d_overflow);
-    if (hipGetLastError() != hipSuccess) return MHX_OK;  // (a launch the device refuses: nothing has run, the radix sort takes over)
-    uint32_t overflow = 0;
-    MHX_HIP_CHECK(hipMemcpyAsync(&overflow, d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t *d_cursor0 = d_overflow + 1;
+    uint32_t *d_overflow0 = d_cursor0 + big_bins;
+    uint64_t *d_slab_dig = (uint64_t *)(base + cur_bytes);
+    uint32_t *d_slab_row = (uint32_t *)(base + cur_bytes + dig_bytes);
+    uint64_t *d_slab0_dig = (uint64_t *)(base + cur_bytes + dig_bytes + row_bytes);
+    uint32_t *d_slab0_row = (uint32_t *)(base + cur_bytes + dig_bytes + row_bytes + dig0_bytes);
+    MHX_HIP_CHECK(hipMemsetAsync(d_cursor, 0, sizeof(uint32_t) * (size_t)(bins + big_bins + 2), ctx->stream));
+    // the pass that reads the signatures: into the final slabs (one level) or into the big bins (level 0 of two)
+    uint32_t *cur_a = hi_bits ? d_cursor0 : d_cursor, *ovf_a = hi_bits ? d_overflow0 : d_overflow;
+    uint64_t *dig_a = hi_bits ? d_slab0_dig : d_slab_dig;
+    uint32_t *row_a = hi_bits ? d_slab0_row : d_slab_row;
+    const uint32_t cap_a = hi_bits ? cap0 : (uint32_t)kBinCap;
+    bool ok;
+#define MHX_SCATTER_A(T) ok = launch_scatter<T>(ctx, (const T *)d_sig, k, r, n, bands, 0, first_bits, band_share, cap_a, cur_a, dig_a, row_a, ovf_a, nullptr, nullptr, nullptr, 0, team_bytes)
+    if (sig_dtype == kSigDigestsBM) MHX_SCATTER_A(Digest64BM);
+    else if (sig_dtype == kSigDigests) MHX_SCATTER_A(Digest64);
+    else if (sig_dtype == MHX_U32) MHX_SCATTER_A(uint32_t);
+    else MHX_SCATTER_A(uint64_t);
+#undef MHX_SCATTER_A
+    if (!ok) return MHX_OK;  // (a launch the device refuses: nothing has run, the radix sort takes over)
+    if (hi_bits) {  // level 1: every big bin into its 2^lo final bins
+        if (!launch_scatter<SlabPairs>(ctx, (const SlabPairs *)nullptr, k, r, n, (int32_t)big_bins, hi_bits, lo_bits, 1, (uint32_t)kBinCap, d_cursor, d_slab_dig, d_slab_row,
+                                       d_overflow, d_slab0_dig, d_slab0_row, d_cursor0, cap0, scatter_team_bytes(lo_bits, true)))
+            return MHX_OK;
+    }
+    uint32_t overflow[2] = {0, 0};
+    MHX_HIP_CHECK(hipMemcpyAsync(&overflow[0], d_overflow, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    if (hi_bits) MHX_HIP_CHECK(hipMemcpyAsync(&overflow[1], d_overflow0, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (overflow) return MHX_OK;
+    if (overflow[0] || overflow[1]) return MHX_OK;
     hipLaunchKernelGGL(lsh_bin_sort_kernel, dim3((unsigned)std::min<int64_t>(bins, (int64_t)ctx->num_cus * 96)), dim3(kSortThreads), 0, ctx->stream, d_cursor,
                        d_slab_dig, d_slab_row, n, bands, bin_bits, d_sorted_digests, d_sorted_rows);
     MHX_HIP_CHECK(hipGetLastError());

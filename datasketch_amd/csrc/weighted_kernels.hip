@@ -1901,14 +1901,19 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
     do {                                          \
         if (nv == 4) MHX_WALK_WAVE(LOGS, 4, PAIRS_);      \
         else if (nv == 8) MHX_WALK_WAVE(LOGS, 8, PAIRS_); \
-        else if (fetch_mode == 1) MHX_WALK_WAVE(LOGS, 16, PAIRS_, 1); \
         else if (fetch_mode == 2) MHX_WALK_WAVE(LOGS, 16, PAIRS_, 2); \
         else if (fetch_mode == 3) MHX_WALK_WAVE(LOGS, 16, PAIRS_, 3); \
         else MHX_WALK_WAVE(LOGS, 16, PAIRS_);             \
     } while (0)
-            const int fetch_mode = (int)(ctx->opt_weighted_refill & 3);
+            // 4096-column rows (NV = 16), measured on config 4 (profiles/r05_ab_weighted_refill.txt): non-temporal row loads 0.426 -> 0.408 ms with
+            // logs in; with values in, chunk after chunk + the refill right after staging + non-temporal 0.526 -> 0.499 ms.  The early refill
+            // alone gains nothing (0.427) and costs the chunk-pair walk 17-32 spilled VGPRs (0.489).  Option weighted.refill: 0 auto,
+            // 1 = plain loads behind the walk (round 4), 2 / 3 = force that mode.
+            const bool auto_fetch = ctx->opt_weighted_refill == 0;
+            const int fetch_mode = auto_fetch ? (values_are_logs ? 2 : 3) : ctx->opt_weighted_refill == 1 ? 0 : (int)(ctx->opt_weighted_refill & 3);
             const int32_t rescue_lanes = ctx->opt_weighted_rescue < 0 ? 0 : ctx->opt_weighted_rescue > 0 ? (int32_t)ctx->opt_weighted_rescue : 8;  // (lognormal rows at steady clocks: 2: 0.557, 4: 0.535, 8: 0.529, 16: 0.563, 32: 0.68 ms per 20k; config 4 the same for all)
-            const bool pairs = ctx->opt_weighted_kernel != 2;  // two chunks of samples as one stream (0.424 -> 0.405 ms on config 4); 2 = chunk after chunk
+            // two chunks of samples as one stream (0.424 -> 0.405 ms on config 4 with logs in); 2 = chunk after chunk, which values in take at NV = 16
+            const bool pairs = ctx->opt_weighted_kernel == 0 ? !(nv == 16 && !values_are_logs && auto_fetch) : ctx->opt_weighted_kernel != 2;
             if (values_are_logs) {
                 if (pairs) MHX_WALK_WAVE_NV(true, true);
                 else MHX_WALK_WAVE_NV(true, false);

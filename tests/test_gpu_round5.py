@@ -89,14 +89,15 @@ def test_fused_entry_point_on_shapes_the_fused_kernel_does_not_take(ctx, k, band
 
 
 # ------------------------------------------------------------------ bucketing: the round-5 passes
-@pytest.mark.parametrize("n", [1, 63, 2500, 2501, 70_001, 400_000])
+@pytest.mark.parametrize("n", [1, 63, 2500, 2501, 10_001, 70_001, 400_000, 3_000_000])
 def test_bucketing_passes_in_both_layouts_equal_numpy_and_the_radix_sort(ctx, n):
     """mhx_lsh_sort_digests_dev ([n, bands] input) and mhx_lsh_sort_digests_layout_dev with MHX_BAND_MAJOR ([bands, n]: the layout
     the chain runs on, read with unit stride): the (band, digest, row) order must be numpy's stable order and the stable
     radix sort's (lsh.sort = 1, with and without the digests riding through the sort) -- on uniform digests, on clusters of
-    equal digests inside a bin's capacity and beyond it (the fallback), with rows shared by many bands."""
+    equal digests inside a bin's capacity and beyond it (the fallback), with rows shared by many bands; one scatter level and
+    two (lsh.levels = 2 forces what more than 2^10 bins per band -- 2.56M rows -- select by themselves: the 3M-row case)."""
     rng = np.random.RandomState(n)
-    bands = 16
+    bands = 16 if n <= 400_000 else 8
     dig = rng.randint(0, 2**63, (n, bands), dtype=np.uint64) * np.uint64(2) + rng.randint(0, 2, (n, bands)).astype(np.uint64)
     if n > 100:
         dig[rng.randint(0, n, min(n // 7, 600)), 3] = dig[0, 3]  # one big bucket in band 3 (within a bin's capacity: the two passes run)
@@ -106,7 +107,7 @@ def test_bucketing_passes_in_both_layouts_equal_numpy_and_the_radix_sort(ctx, n)
     d_dig, d_dig_bm = ctx.to_device(dig), ctx.to_device(np.ascontiguousarray(dig.T))
     d_sd, d_sr = ctx.alloc(max(1, n * bands * 8)), ctx.alloc(max(1, n * bands * 4))
     res = {}
-    for name, opts in (("lds", {}), ("radix", {"lsh.sort": 1}),
+    for name, opts in (("lds", {}), ("two_levels", {"lsh.levels": 2}), ("radix", {"lsh.sort": 1}), ("band_major_two_levels", {"lsh.levels": 2}),
                        ("band_major", {}), ("band_major_radix", {"lsh.sort": 1}), ("band_major_gather", {"lsh.sort": 1, "lsh.gather": 1})):
         for key, v in opts.items():
             ctx.set_option(key, v)
@@ -124,7 +125,7 @@ def test_bucketing_passes_in_both_layouts_equal_numpy_and_the_radix_sort(ctx, n)
         order = np.lexsort((np.arange(n), dig[:, j]))
         assert np.array_equal(res["lds"][1][j], order.astype(np.uint32)), j
         assert np.array_equal(res["lds"][0][j], dig[order, j]), j
-    for name in ("radix", "band_major", "band_major_radix", "band_major_gather"):
+    for name in ("two_levels", "radix", "band_major", "band_major_two_levels", "band_major_radix", "band_major_gather"):
         assert np.array_equal(res[name][0], res["lds"][0]) and np.array_equal(res[name][1], res["lds"][1]), name
 
 
