@@ -491,15 +491,37 @@ def allgather_probe(ctx, group, gather, perms, d_tok, tok_dtype, n, t, k, reps=5
 def _cpu_worker(args):
     """One host core of the all-cores baseline: the numpy per-set loop of MinHash.bulk on its own
     shard (generated in the worker: nothing but a checksum travels)."""
-    seed, n, t, k, pseed = args
+    seed, n, t, k, pseed, ref_path = args
     sys.path.insert(0, ROOT)
+    tokens = np.random.RandomState(seed).randint(0, 2**32, size=(n, t), dtype=np.uint64)
+    if ref_path:  # the reference itself (DATASKETCH_REFERENCE): MinHash.bulk with its per-set copy()
+        sys.path.insert(0, ref_path)
+        import datasketch as ref
+
+        t0 = time.perf_counter()
+        objs = ref.MinHash.bulk(tokens, num_perm=k, seed=pseed, hashfunc=_identity)
+        return time.perf_counter() - t0, int(sum(int(m.hashvalues[0]) for m in objs))
     from oracle import oracle as O
 
     a, b = O.np_init_permutations(k, pseed)
-    tokens = np.random.RandomState(seed).randint(0, 2**32, size=(n, t), dtype=np.uint64)
     t0 = time.perf_counter()
     sig = O.np_minhash_bulk(list(tokens), a, b)
     return time.perf_counter() - t0, int(sig[:, 0].sum())
+
+
+def _identity(x):
+    return x
+
+
+def reference_path():
+    """Where the real reference (ekzhu/datasketch) can be imported from, or None.  Only when DATASKETCH_REFERENCE names it:
+    the GPU box has no reference, and nothing here looks for one on its own."""
+    path = os.environ.get("DATASKETCH_REFERENCE", "").strip()
+    if not path or not os.path.isdir(os.path.join(path, "datasketch")):
+        return None
+    probe = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, sys.argv[1]); import datasketch; print(datasketch.MinHash.__module__)", path],
+                           capture_output=True, text=True, timeout=120)
+    return path if probe.returncode == 0 and "datasketch" in probe.stdout else None
 
 
 def _usable_cores(cap=64, why=None):
@@ -568,6 +590,25 @@ def cpu_baseline(tokens, a, b, sample, k, t, gpu_rows, seed=1):
     t0 = time.perf_counter()
     got = O.np_minhash_bulk(sets, a, b)
     dt = time.perf_counter() - t0
+    ref_path = reference_path()
+    ref_dt = None
+    if ref_path:  # the real reference on the same sample, same core; its rows must be the restatement's
+        code = ("import sys, time, numpy as np; sys.path.insert(0, sys.argv[1]); import datasketch as ref\n"
+                "tok = np.load(sys.argv[2]); t0 = time.perf_counter()\n"
+                "objs = ref.MinHash.bulk(tok, num_perm=int(sys.argv[3]), seed=int(sys.argv[4]), hashfunc=lambda x: x); dt = time.perf_counter() - t0\n"
+                "np.save(sys.argv[5], np.stack([m.hashvalues for m in objs])); print(dt)")
+        import tempfile
+
+        with tempfile.TemporaryDirectory() as tmp:
+            np.save(os.path.join(tmp, "tok.npy"), tokens[:single])
+            p = subprocess.run([sys.executable, "-c", code, ref_path, os.path.join(tmp, "tok.npy"), str(k), str(seed), os.path.join(tmp, "sig.npy")],
+                               capture_output=True, text=True, timeout=600)
+            if p.returncode == 0:
+                ref_dt = float(p.stdout.strip().splitlines()[-1])
+                if not np.array_equal(np.load(os.path.join(tmp, "sig.npy")), got):
+                    raise SystemExit("PARITY FAILURE: the reference's MinHash.bulk differs from the numpy restatement on the cpu_baseline sample")
+            else:
+                ref_path = None
     c0 = time.perf_counter()
     want = O.c_minhash_bulk_dense(tokens[:single], a, b)
     cdt = time.perf_counter() - c0
@@ -578,38 +619,46 @@ def cpu_baseline(tokens, a, b, sample, k, t, gpu_rows, seed=1):
     cores_why = {}
     cores = _usable_cores(why=cores_why)
     per = max(2_000, sample // 8)  # sets per process: 1.5-3 s of numpy each, 41 MB of tokens
+    is_ref = ref_path is not None and ref_dt is not None
+    what = "the reference's MinHash.bulk (DATASKETCH_REFERENCE)" if is_ref else "numpy per-set loop as MinHash.bulk"
     out = {
-        "value": single / dt,
+        "value": single / (ref_dt if is_ref else dt),
         "unit": "signatures/s",
         "cores": 1,
-        "kind": "port",
-        "sample": f"first {single} sets of the benchmark corpus ({t} tokens, num_perm={k}), numpy per-set loop as MinHash.bulk; {dt:.1f} s",
+        "kind": "reference" if is_ref else "port",
+        "sample": f"first {single} sets of the benchmark corpus ({t} tokens, num_perm={k}), {what}; {(ref_dt if is_ref else dt):.1f} s",
     }
     try:
         w0 = time.perf_counter()
         with mp.get_context("spawn").Pool(cores) as pool:  # spawn: children never see the HIP runtime
-            res = pool.map_async(_cpu_worker, [(1000 + i, per, t, k, seed) for i in range(cores)]).get(timeout=90)
+            res = pool.map_async(_cpu_worker, [(1000 + i, per, t, k, seed, ref_path if is_ref else None) for i in range(cores)]).get(timeout=180 if is_ref else 90)
         wall = time.perf_counter() - w0
         busy = max(r[0] for r in res)
         out.update({
             "value": cores * per / busy,
             "cores": cores,
             "cores_source": dict(cores_why, used=cores, rule="min(affinity mask, cgroup CPU quota, cap)"),
-            "sample": f"{cores} processes x {per} sets of the same shape ({t} tokens, num_perm={k}), numpy per-set loop as "
-                      f"MinHash.bulk; slowest process {busy:.1f} s (pool wall {wall:.1f} s incl. start-up)",
+            "sample": f"{cores} processes x {per} sets of the same shape ({t} tokens, num_perm={k}), {what}; "
+                      f"slowest process {busy:.1f} s (pool wall {wall:.1f} s incl. start-up)",
         })
     except Exception as e:  # the all-cores leg is best effort; the single-core figure stands
         out["all_cores_error"] = repr(e)
     out.update({
-        "single_core_value": single / dt,
-        "single_core_sample": f"first {single} sets of the benchmark corpus, {dt:.1f} s",
+        "single_core_value": single / (ref_dt if is_ref else dt),
+        "single_core_sample": f"first {single} sets of the benchmark corpus, {(ref_dt if is_ref else dt):.1f} s",
         "host_cpus": os.cpu_count(),
         "cpu_model": cpu_model(),
         # the real reference (MinHash.bulk with its per-set copy()) timed beside this restatement in the build container,
         # same sample and core: tools/cpu_reference_vs_port.py -> profiles/r02_cpu_reference_vs_port.txt
-        "reference_over_port_time": 1.20,
-        "note": "kind 'port' = numpy restatement pinned to the reference; the reference itself is not on the GPU box and runs "
-                "1.20x slower than the restatement (object churn), so the reference-equivalent rate is value / 1.20",
+        # the real reference timed beside the restatement: here when DATASKETCH_REFERENCE resolves, else the build container's
+        # figure (tools/cpu_reference_vs_port.py -> profiles/r05_cpu_reference_vs_port.txt, 2026-09-22)
+        "reference_over_port_time": (ref_dt / dt) if is_ref else 1.21,
+        "reference_over_port_measured": "in this run" if is_ref else "2026-09-22, build container, profiles/r05_cpu_reference_vs_port.txt",
+        "port_single_core_value": single / dt,
+        "note": ("kind 'reference' = ekzhu/datasketch's own MinHash.bulk imported from DATASKETCH_REFERENCE, rows equal to the restatement's and the GPU's"
+                 if is_ref else
+                 "kind 'port' = numpy restatement pinned to the reference; the reference itself is not on this box (DATASKETCH_REFERENCE unset) and "
+                 "runs 1.21x slower than the restatement (object churn), so the reference-equivalent rate is value / 1.21"),
         "c_oracle_single_core_value": single / cdt,
         "rows_equal_to_gpu": int(m),
     })

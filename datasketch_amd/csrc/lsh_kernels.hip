@@ -4,14 +4,12 @@
 // (datasketch/lsh.py:326-347 insert, :370-400 query); two signatures are candidates iff they share a
 // key in at least one band.  Here the grouping is a sort: per band, the 64-bit digests of the band keys
 // (pack_kernels.hip: FNV-1a-64 of exactly the reference's key bytes) are sorted together with the row
-// numbers, so every bucket becomes a run of equal digests.  The sort is rocPRIM's device radix sort
-// (a library primitive), ONE call over all n x bands keys ordered by (band, digest prefix); the kernels
-// around it -- which also make the order exact -- are ours.
+// numbers, so every bucket becomes a run of equal digests.  The bucketing itself is hand-written (two or three passes, below);
+// its fallback for corpora it cannot bin, and the sort of the raw candidate pairs, are rocPRIM's device radix sort (a library
+// primitive) -- everything around it, including the scans and the deduplication, is ours.
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/device/device_select.hpp>
 
 #include "band_digest.h"
 #include "mhx_internal.h"
@@ -507,6 +505,126 @@ __global__ __launch_bounds__(256) void query_emit_kernel(const uint32_t *__restr
     }
 }
 
+// ---- device-wide exclusive scan, hand-written (round 5: rocPRIM's exclusive_scan and unique are gone from this file) ------
+// Three launches over tiles of 256 threads x 16 items: (1) every tile's sum, (2) one workgroup turns the tile sums into tile
+// offsets (and the grand total), (3) every tile scans again from its offset and hands (index, exclusive prefix, value) to the
+// output functor.  The input is a functor too, so that "unique" is the same three launches: value = 1 where a sorted key
+// differs from its predecessor, output = the key written at its prefix.  The input is read twice (8 B + 8 B per element for
+// 40M counts -> where: 0.5 GB, ~0.15 ms); a decoupled look-back would read it once and is not worth its spin loops here.
+constexpr int kScanItems = 16, kScanTile = 256 * kScanItems;
+
+struct CountsIn {  // value = counts[i]
+    const uint32_t *counts;
+    __device__ __forceinline__ uint32_t get(int64_t i) const { return counts[i]; }
+};
+struct WhereOut {  // where[i] = exclusive prefix
+    uint64_t *where;
+    __device__ __forceinline__ void put(int64_t i, uint64_t prefix, uint32_t) const { where[i] = prefix; }
+};
+struct HeadsIn {  // value = 1 at the first element of a run of equal sorted keys
+    const uint64_t *keys;
+    __device__ __forceinline__ uint32_t get(int64_t i) const { return i == 0 || keys[i] != keys[i - 1] ? 1u : 0u; }
+};
+struct CompactOut {  // the run heads, packed
+    const uint64_t *keys;
+    uint64_t *out;
+    __device__ __forceinline__ void put(int64_t i, uint64_t prefix, uint32_t head) const {
+        if (head) out[prefix] = keys[i];
+    }
+};
+
+__device__ __forceinline__ uint64_t block_inclusive_scan64(uint64_t v, uint64_t *tmp4, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)v, o), hi = (uint32_t)__shfl_up((int)(uint32_t)(v >> 32), o);
+        if (lane >= o) v += ((uint64_t)hi << 32) | lo;
+    }
+    if (lane == 63) tmp4[wave] = v;
+    __syncthreads();
+    uint64_t add = 0;
+    for (int w = 0; w < wave; ++w) add += tmp4[w];
+    __syncthreads();
+    return v + add;
+}
+
+template <typename In>
+__global__ __launch_bounds__(256) void scan_tile_sums_kernel(In in, int64_t n, uint64_t *__restrict__ tile_sums) {
+    __shared__ uint64_t tmp[4];
+    const int64_t first = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    uint64_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j)
+        if (first + j < n) sum += in.get(first + j);
+    const uint64_t incl = block_inclusive_scan64(sum, tmp, threadIdx.x);
+    if (threadIdx.x == 255) tile_sums[blockIdx.x] = incl;
+}
+
+// tile sums -> exclusive tile offsets in place; total[0] = the grand total.  One workgroup: a 10M-row index has 80 000 tiles.
+__global__ __launch_bounds__(1024) void scan_tile_offsets_kernel(uint64_t *__restrict__ tiles, int64_t n_tiles, uint64_t *__restrict__ total) {
+    __shared__ uint64_t tmp[16];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n_tiles; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const uint64_t v = i < n_tiles ? tiles[i] : 0;
+        // inclusive scan over the 1024 threads: 16 waves
+        uint64_t x = v;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)x, o), hi = (uint32_t)__shfl_up((int)(uint32_t)(x >> 32), o);
+            if (lane >= o) x += ((uint64_t)hi << 32) | lo;
+        }
+        if (lane == 63) tmp[wave] = x;
+        __syncthreads();
+        uint64_t add = carry;
+        for (int w = 0; w < wave; ++w) add += tmp[w];
+        if (i < n_tiles) tiles[i] = add + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = add + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[0] = carry;
+}
+
+template <typename In, typename Out>
+__global__ __launch_bounds__(256) void scan_apply_kernel(In in, int64_t n, const uint64_t *__restrict__ tile_offsets, Out out) {
+    __shared__ uint64_t tmp[4];
+    const int64_t first = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    uint32_t v[kScanItems];
+    uint64_t sum = 0;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        v[j] = first + j < n ? in.get(first + j) : 0u;
+        sum += v[j];
+    }
+    uint64_t at = tile_offsets[blockIdx.x] + block_inclusive_scan64(sum, tmp, threadIdx.x) - sum;
+#pragma unroll
+    for (int j = 0; j < kScanItems; ++j) {
+        if (first + j < n) out.put(first + j, at, v[j]);
+        at += v[j];
+    }
+}
+
+// scratch words the scan needs for n elements: the tile sums and the total
+inline size_t scan_tmp_bytes(int64_t n) { return ((sizeof(uint64_t) * (size_t)((n + kScanTile - 1) / kScanTile + 2)) + 255) & ~(size_t)255; }
+
+// enqueues the three launches; the grand total lands in d_tmp[n_tiles] (device) -- the caller reads it back when it needs it
+template <typename In, typename Out>
+int device_exclusive_scan(mhx_ctx *ctx, In in, Out out, int64_t n, void *d_tmp, uint64_t **d_total) {
+    const int64_t n_tiles = (n + kScanTile - 1) / kScanTile;
+    uint64_t *tiles = static_cast<uint64_t *>(d_tmp);
+    *d_total = tiles + n_tiles;
+    if (n_tiles >= (int64_t)1 << 31) return fail(MHX_ERR_UNSUPPORTED, "scan of more than 2^43 elements");
+    hipLaunchKernelGGL(scan_tile_sums_kernel<In>, dim3((unsigned)n_tiles), dim3(256), 0, ctx->stream, in, n, tiles);
+    hipLaunchKernelGGL(scan_tile_offsets_kernel, dim3(1), dim3(1024), 0, ctx->stream, tiles, n_tiles, *d_total);
+    hipLaunchKernelGGL((scan_apply_kernel<In, Out>), dim3((unsigned)n_tiles), dim3(256), 0, ctx->stream, in, n, tiles, out);
+    MHX_HIP_CHECK(hipGetLastError());
+    return MHX_OK;
+}
+
 unsigned grid_for(const mhx_ctx *ctx, int64_t items) {
     return (unsigned)std::max<int64_t>(1, std::min<int64_t>((items + 255) / 256, (int64_t)ctx->num_cus * 16));
 }
@@ -522,10 +640,7 @@ int launch_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *d_sorted_digests, c
     // scratch[4], first part: ahead u32[total] | where u64[total] | tail u64[2] | scan temporary
     const size_t ahead_bytes = ((sizeof(uint32_t) * (size_t)total) + 255) & ~(size_t)255;
     const size_t where_bytes = ((sizeof(uint64_t) * (size_t)total) + 255) & ~(size_t)255;
-    size_t scan_tmp = 0;
-    hipError_t e = rocprim::exclusive_scan(nullptr, scan_tmp, (const uint32_t *)nullptr, (uint64_t *)nullptr, (uint64_t)0,
-                                           (size_t)total, rocprim::plus<uint64_t>(), ctx->stream);
-    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::exclusive_scan (size query) failed: %s", hipGetErrorString(e));
+    const size_t scan_tmp = scan_tmp_bytes(total);
     if (int rc = ctx->ensure_scratch(4, ahead_bytes + where_bytes + 256 + scan_tmp)) return rc;
     uint32_t *d_ahead = (uint32_t *)ctx->scratch[4];
     uint64_t *d_where = (uint64_t *)((char *)ctx->scratch[4] + ahead_bytes);
@@ -533,15 +648,12 @@ int launch_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *d_sorted_digests, c
     hipLaunchKernelGGL(run_position_kernel, dim3(grid_for(ctx, total)), dim3(256), 0, ctx->stream, d_sorted_digests, n, total,
                        d_ahead);
     MHX_HIP_CHECK(hipGetLastError());
-    e = rocprim::exclusive_scan(d_scan_tmp, scan_tmp, (const uint32_t *)d_ahead, d_where, (uint64_t)0, (size_t)total,
-                                rocprim::plus<uint64_t>(), ctx->stream);
-    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::exclusive_scan failed: %s", hipGetErrorString(e));
-    uint64_t last_where = 0;
-    uint32_t last_ahead = 0;
-    MHX_HIP_CHECK(hipMemcpyAsync(&last_where, d_where + (total - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    MHX_HIP_CHECK(hipMemcpyAsync(&last_ahead, d_ahead + (total - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    uint64_t *d_raw_total = nullptr;
+    if (int rc = device_exclusive_scan(ctx, CountsIn{d_ahead}, WhereOut{d_where}, total, d_scan_tmp, &d_raw_total)) return rc;
+    uint64_t raw_total = 0;
+    MHX_HIP_CHECK(hipMemcpyAsync(&raw_total, d_raw_total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    const int64_t raw = (int64_t)(last_where + last_ahead);  // pairs before deduplication across bands
+    const int64_t raw = (int64_t)raw_total;  // pairs before deduplication across bands
     if (n_raw) *n_raw = raw;
     if (raw == 0) return MHX_OK;
     if ((size_t)raw * 16 > (size_t)ctx->hbm_bytes / 2)
@@ -552,27 +664,23 @@ int launch_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *d_sorted_digests, c
     const size_t raw_bytes = ((sizeof(uint64_t) * (size_t)raw) + 255) & ~(size_t)255;
     int end_bit = 33;  // the high word holds a row number < n
     while (end_bit < 64 && ((int64_t)1 << (end_bit - 32)) < n) ++end_bit;
-    size_t sort_tmp = 0, uniq_tmp = 0;
-    e = rocprim::radix_sort_keys(nullptr, sort_tmp, (const uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)raw, 0, end_bit,
-                                 ctx->stream);
-    if (e == hipSuccess)
-        e = rocprim::unique(nullptr, uniq_tmp, (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)raw,
-                            rocprim::equal_to<uint64_t>(), ctx->stream);
+    size_t sort_tmp = 0;
+    hipError_t e = rocprim::radix_sort_keys(nullptr, sort_tmp, (const uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)raw, 0, end_bit,
+                                            ctx->stream);  // (the one library primitive left on this path: a radix sort of the raw pairs)
     if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim size query failed: %s", hipGetErrorString(e));
-    const size_t tmp_bytes = std::max(sort_tmp, uniq_tmp);
+    const size_t tmp_bytes = std::max(sort_tmp, scan_tmp_bytes(raw));
     if (int rc = ctx->ensure_scratch(3, 2 * raw_bytes + 256 + tmp_bytes)) return rc;
     uint64_t *d_raw = (uint64_t *)ctx->scratch[3];
     uint64_t *d_sorted = (uint64_t *)((char *)ctx->scratch[3] + raw_bytes);
-    uint64_t *d_count = (uint64_t *)((char *)ctx->scratch[3] + 2 * raw_bytes);
     void *d_tmp = (char *)ctx->scratch[3] + 2 * raw_bytes + 256;
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(grid_for(ctx, total)), dim3(256), 0, ctx->stream, d_sorted_rows, d_ahead, d_where,
                        total, d_raw);
     MHX_HIP_CHECK(hipGetLastError());
     e = rocprim::radix_sort_keys(d_tmp, sort_tmp, (const uint64_t *)d_raw, d_sorted, (size_t)raw, 0, end_bit, ctx->stream);
     if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_keys failed: %s", hipGetErrorString(e));
-    e = rocprim::unique(d_tmp, uniq_tmp, (const uint64_t *)d_sorted, d_raw, d_count, (size_t)raw, rocprim::equal_to<uint64_t>(),
-                        ctx->stream);
-    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::unique failed: %s", hipGetErrorString(e));
+    // unique: the heads of the runs of equal sorted pairs, packed (the scan above with other functors)
+    uint64_t *d_count = nullptr;
+    if (int rc = device_exclusive_scan(ctx, HeadsIn{d_sorted}, CompactOut{d_sorted, d_raw}, raw, d_tmp, &d_count)) return rc;
     uint64_t unique_count = 0;
     MHX_HIP_CHECK(hipMemcpyAsync(&unique_count, d_count, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -763,10 +871,7 @@ int launch_lsh_query(mhx_ctx *ctx, const uint64_t *d_sorted_digests, const uint3
     // scratch[4]: probe digests u64[total] | first u32[total] | count u32[total] | where u64[total] | scan temporary
     const size_t dig_bytes = ((sizeof(uint64_t) * (size_t)total) + 255) & ~(size_t)255;
     const size_t u32_bytes = ((sizeof(uint32_t) * (size_t)total) + 255) & ~(size_t)255;
-    size_t scan_tmp = 0;
-    hipError_t e = rocprim::exclusive_scan(nullptr, scan_tmp, (const uint32_t *)nullptr, (uint64_t *)nullptr, (uint64_t)0,
-                                           (size_t)total, rocprim::plus<uint64_t>(), ctx->stream);
-    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::exclusive_scan (size query) failed: %s", hipGetErrorString(e));
+    const size_t scan_tmp = scan_tmp_bytes(total);
     if (int rc = ctx->ensure_scratch(4, 2 * dig_bytes + 2 * u32_bytes + 256 + scan_tmp)) return rc;
     char *base = (char *)ctx->scratch[4];
     uint64_t *d_qdig = (uint64_t *)base;
@@ -778,31 +883,24 @@ int launch_lsh_query(mhx_ctx *ctx, const uint64_t *d_sorted_digests, const uint3
     const dim3 grid(grid_for(ctx, total));
     hipLaunchKernelGGL(query_ranges_kernel, grid, dim3(256), 0, ctx->stream, d_qdig, m, bands, d_sorted_digests, n, d_first, d_count);
     MHX_HIP_CHECK(hipGetLastError());
-    e = rocprim::exclusive_scan(d_scan_tmp, scan_tmp, (const uint32_t *)d_count, d_where, (uint64_t)0, (size_t)total,
-                                rocprim::plus<uint64_t>(), ctx->stream);
-    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::exclusive_scan failed: %s", hipGetErrorString(e));
-    uint64_t last_where = 0;
-    uint32_t last_count = 0;
-    MHX_HIP_CHECK(hipMemcpyAsync(&last_where, d_where + (total - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
-    MHX_HIP_CHECK(hipMemcpyAsync(&last_count, d_count + (total - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    uint64_t *d_raw_total = nullptr;
+    if (int rc = device_exclusive_scan(ctx, CountsIn{d_count}, WhereOut{d_where}, total, d_scan_tmp, &d_raw_total)) return rc;
+    uint64_t raw_total = 0;
+    MHX_HIP_CHECK(hipMemcpyAsync(&raw_total, d_raw_total, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    const int64_t raw = (int64_t)(last_where + last_count);
+    const int64_t raw = (int64_t)raw_total;
     if (raw == 0) return MHX_OK;
     if ((size_t)raw * 16 > (size_t)ctx->hbm_bytes / 2)
         return fail(MHX_ERR_OOM, "%lld candidates before deduplication do not fit in device memory", (long long)raw);
     // scratch[3]: raw u64[raw] | sorted u64[raw] | count u64 | sort / select temporary
     const size_t raw_bytes = ((sizeof(uint64_t) * (size_t)raw) + 255) & ~(size_t)255;
-    size_t sort_tmp = 0, uniq_tmp = 0;
-    e = rocprim::radix_sort_keys(nullptr, sort_tmp, (const uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)raw, 0, 64, ctx->stream);
-    if (e == hipSuccess)
-        e = rocprim::unique(nullptr, uniq_tmp, (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)raw,
-                            rocprim::equal_to<uint64_t>(), ctx->stream);
+    size_t sort_tmp = 0;
+    hipError_t e = rocprim::radix_sort_keys(nullptr, sort_tmp, (const uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)raw, 0, 64, ctx->stream);
     if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim size query failed: %s", hipGetErrorString(e));
-    const size_t tmp_bytes = std::max(sort_tmp, uniq_tmp);
+    const size_t tmp_bytes = std::max(sort_tmp, scan_tmp_bytes(raw));
     if (int rc = ctx->ensure_scratch(3, 2 * raw_bytes + 256 + tmp_bytes)) return rc;
     uint64_t *d_raw = (uint64_t *)ctx->scratch[3];
     uint64_t *d_sorted = (uint64_t *)((char *)ctx->scratch[3] + raw_bytes);
-    uint64_t *d_cnt = (uint64_t *)((char *)ctx->scratch[3] + 2 * raw_bytes);
     void *d_tmp = (char *)ctx->scratch[3] + 2 * raw_bytes + 256;
     const bool verify = d_idx_sig != nullptr;
     if (sig_dtype == MHX_U32) {
@@ -823,8 +921,8 @@ int launch_lsh_query(mhx_ctx *ctx, const uint64_t *d_sorted_digests, const uint3
     MHX_HIP_CHECK(hipGetLastError());
     e = rocprim::radix_sort_keys(d_tmp, sort_tmp, (const uint64_t *)d_raw, d_sorted, (size_t)raw, 0, 64, ctx->stream);
     if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::radix_sort_keys failed: %s", hipGetErrorString(e));
-    e = rocprim::unique(d_tmp, uniq_tmp, (const uint64_t *)d_sorted, d_raw, d_cnt, (size_t)raw, rocprim::equal_to<uint64_t>(), ctx->stream);
-    if (e != hipSuccess) return fail(MHX_ERR_HIP, "rocprim::unique failed: %s", hipGetErrorString(e));
+    uint64_t *d_cnt = nullptr;  // unique: the run heads of the sorted candidates, packed
+    if (int rc = device_exclusive_scan(ctx, HeadsIn{d_sorted}, CompactOut{d_sorted, d_raw}, raw, d_tmp, &d_cnt)) return rc;
     uint64_t unique_count = 0, last_key = 0;
     MHX_HIP_CHECK(hipMemcpyAsync(&unique_count, d_cnt, sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -66,7 +66,13 @@ int guard_align() {
     std::lock_guard<std::mutex> lk(g_guard_mu);
     if (g_guard_align == -0x7fffffff) {
         const char *e = getenv("MHX_GUARD_ALLOC");
-        g_guard_align = e ? atoi(e) : 0;
+        int a = e ? atoi(e) : 0;
+        const int m = a < 0 ? -a : a;
+        if (a != 0 && (m > 4096 || (m & (m - 1)))) {  // the rule of mhx_debug_guard_alloc: 0 or +-(a power of two <= 4096)
+            fprintf(stderr, "libmhx: MHX_GUARD_ALLOC=%s is not 0 or +-(a power of two <= 4096): guard pages stay off\n", e);
+            a = 0;
+        }
+        g_guard_align = a;
     }
     return g_guard_align;
 }
@@ -244,7 +250,9 @@ int mhx_ctx::ensure_work() {
         d_work = nullptr;
         return fail(MHX_ERR_OOM, "work counter allocation failed: %s", hipGetErrorString(e));
     }
-    MHX_HIP_CHECK(hipMemset(d_work, 0, mhx::kWorkBytes));  // (word 8, what the last call learned about the corpus, lives across calls)
+    // on the kernels' own stream (created non-blocking: nothing orders the null stream before it); word 8, what the last call
+    // learned about the corpus, lives across calls
+    MHX_HIP_CHECK(hipMemsetAsync(d_work, 0, mhx::kWorkBytes, stream));
     return MHX_OK;
 }
 

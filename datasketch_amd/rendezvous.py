@@ -175,13 +175,23 @@ class Group:
             try:  # anything that is not a rank of this group is dropped, not fatal: a port scanner, a stale job
                 conn.settimeout(min(1.0, max(0.1, left)))  # (hellos are read one after the other: a silent connection holds the others up this long)
                 peer, hello = _recv_frame(conn, _HELLO_MAX)
-                if not (0 < peer < self.world) or self._peers[peer] is not None or not hmac.compare_digest(hello, want):
+                if not (0 < peer < self.world) or not hmac.compare_digest(hello, want):
                     raise ConnectionError("unexpected rendezvous peer")
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 conn.settimeout(timeout)
                 _send_frame(conn, 0, _ACK)  # the joiner waits for this: a rank that was dropped must not believe it has joined
+                old = self._peers[peer]
+                if old is not None:
+                    # a valid hello from a rank that is registered already: its first ACK reached it too late (it waits
+                    # min(timeout, 10 s) while rank 0 reads silent connections at 1 s each), so it closed that socket and
+                    # came again -- the new connection replaces the dead one instead of being turned away for good
+                    try:
+                        old.close()
+                    except OSError:
+                        pass
+                else:
+                    missing -= 1
                 self._peers[peer] = conn
-                missing -= 1
             except (OSError, struct.error):
                 conn.close()
 

@@ -10,6 +10,8 @@ float32 without FMA fusion on the device and yields bit-identical ``(k, t)`` pai
 from __future__ import annotations
 
 import collections.abc
+import logging
+import os
 import copy
 from typing import List, Optional, Union
 
@@ -94,7 +96,23 @@ class WeightedMinHashGenerator:
         return False
 
     def _log_on_device(self, ctx) -> bool:
-        return ctx.device_log_matches_numpy() if self._device_log is None else bool(self._device_log)
+        """Where this generator's ``np.log`` is taken.  ``device_log`` given: that.  Else the environment override
+        ``MHX_WEIGHTED_DEVICE_LOG`` (0 = always on the host, 1 = always on the device: for hosts whose numpy or GPU is
+        not the pair the exhaustive 2^32-pattern proof was run on).  Else the start-up check on sentinel values.  The
+        side chosen is kept in ``log_taken_on`` ('device' / 'host') and logged once at DEBUG level."""
+        if self._device_log is not None:
+            on_device, why = bool(self._device_log), "device_log argument"
+        else:
+            env = os.environ.get("MHX_WEIGHTED_DEVICE_LOG", "").strip()
+            if env in ("0", "1"):
+                on_device, why = env == "1", "MHX_WEIGHTED_DEVICE_LOG"
+            else:
+                on_device, why = bool(ctx.device_log_matches_numpy()), "start-up check of the device log against this host's np.log"
+        side = "device" if on_device else "host"
+        if getattr(self, "log_taken_on", None) != side:
+            self.log_taken_on = side
+            logging.getLogger("datasketch_amd").debug("WeightedMinHashGenerator: np.log taken on the %s (%s)", side, why)
+        return on_device
 
     def _device_handle(self):
         ctx = _native.context()

@@ -37,7 +37,7 @@ def test_detect_falls_back_to_numpy_with_one_warning(broken_library_on_a_gpu_hos
         blocks = pack_matrix(sigs, 1, gpu_mode="detect")
         dig = lsh_bulk.band_digests(sigs, 4, 4, gpu_mode="detect")
         g = WeightedMinHashGenerator(8, 4, seed=1, gpu_mode="detect")
-        out = g.minhash_many([[1, 0, 3, 0, .5, 2, 0, 7], [0] * 8])
+        out = g.minhash_many(np.array([[1, 0, 3, 0, .5, 2, 0, 7], [0] * 8], dtype=np.float32))
     assert np.array_equal(m.hashvalues, ref.hashvalues)
     assert sigs.shape == (6, 16) and blocks.shape == (6, 1) and dig.shape == (6, 4)
     assert out[1] is None and out[0].hashvalues.tolist() == [[0, 0], [7, 3], [5, 0], [2, 1]]   # SURVEY.md 8c golden
@@ -66,3 +66,93 @@ def test_detect_is_silent_on_a_host_without_a_gpu(monkeypatch):
         warnings.simplefilter("always")
         assert _native.gpu_detected() is False and _native.gpu_available() is False
     assert not seen
+
+
+def test_device_log_side_can_be_overridden_and_is_recorded(monkeypatch):
+    """the start-up check is a probabilistic stand-in for the exhaustive proof run on one numpy / GPU pair; an
+    environment override and a record of the side chosen."""
+    class Ctx:
+        calls = 0
+
+        def device_log_matches_numpy(self):
+            Ctx.calls += 1
+            return True
+
+    g = WeightedMinHashGenerator(8, 4, seed=1, gpu_mode="disable")
+    monkeypatch.delenv("MHX_WEIGHTED_DEVICE_LOG", raising=False)
+    assert g._log_on_device(Ctx()) is True and g.log_taken_on == "device" and Ctx.calls == 1
+    monkeypatch.setenv("MHX_WEIGHTED_DEVICE_LOG", "0")
+    assert g._log_on_device(Ctx()) is False and g.log_taken_on == "host" and Ctx.calls == 1   # the check is not even asked
+    monkeypatch.setenv("MHX_WEIGHTED_DEVICE_LOG", "1")
+    assert g._log_on_device(Ctx()) is True
+    g2 = WeightedMinHashGenerator(8, 4, seed=1, gpu_mode="disable", device_log=False)      # the argument wins over the environment
+    assert g2._log_on_device(Ctx()) is False and g2.log_taken_on == "host"
+
+
+def test_a_rank_whose_first_ack_came_too_late_can_join_again():
+    """rank 0 used to turn a second hello of a registered rank away for good.  Here 'rank 1' says hello, gets its ACK
+    and hangs up (what a joiner does whose ACK wait timed out); the real rank 1 then joins, and the group of three works."""
+    import socket
+    import struct
+    import threading
+    import time
+
+    from datasketch_amd import rendezvous
+
+    with socket.socket() as s0:
+        s0.bind(("127.0.0.1", 0))
+        port = s0.getsockname()[1]
+    res = {}
+
+    def run(rank, delay=0.0):
+        time.sleep(delay)
+        try:
+            with rendezvous.Group(rank, 3, "127.0.0.1", port, timeout=30, nonce="n5") as g:
+                res[rank] = g.allgather(bytes([rank]))
+        except Exception as e:  # noqa: BLE001
+            res[rank] = e
+
+    t0 = threading.Thread(target=run, args=(0,))
+    t0.start()
+    deadline = time.time() + 10
+    while True:
+        try:
+            c = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+            break
+        except OSError:
+            assert time.time() < deadline
+            time.sleep(0.02)
+    c.sendall(struct.pack("<4sIQ", b"MHXR", 1, 2) + b"n5")
+    assert c.recv(64)  # the ACK
+    c.close()           # ... which this joiner believes it never got
+    ts = [threading.Thread(target=run, args=(1, 0.1)), threading.Thread(target=run, args=(2, 0.2))]
+    for t in ts:
+        t.start()
+    for t in [t0] + ts:
+        t.join(40)
+    assert all(res.get(r) == [b"\x00", b"\x01", b"\x02"] for r in range(3)), res
+
+
+def test_cpu_baseline_times_the_real_reference_when_it_is_named(monkeypatch):
+    """bench.py's cpu_baseline: kind 'reference' when DATASKETCH_REFERENCE names an importable ekzhu/datasketch (rows
+    compared with the restatement's), kind 'port' with the dated ratio otherwise.  The reference exists in the build
+    container only; without it the first half is skipped."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from oracle import oracle as O
+
+    tokens = np.random.RandomState(42).randint(0, 2**32, (2000, 64), dtype=np.uint64)
+    a, b = O.np_init_permutations(16, 1)
+    monkeypatch.delenv("DATASKETCH_REFERENCE", raising=False)
+    port = bench.cpu_baseline(tokens, a, b, 2000, 16, 64, None, seed=1)
+    assert port["kind"] == "port" and port["reference_over_port_time"] == 1.21 and "2026-09-22" in port["reference_over_port_measured"]
+    if not os.path.isdir("/root/reference/datasketch"):
+        pytest.skip("the reference is not on this box")
+    monkeypatch.setenv("DATASKETCH_REFERENCE", "/root/reference")
+    ref = bench.cpu_baseline(tokens, a, b, 2000, 16, 64, None, seed=1)
+    assert ref["kind"] == "reference" and ref["reference_over_port_measured"] == "in this run" and ref["cores"] >= 1
+    assert 0.5 < ref["reference_over_port_time"] < 5 and "DATASKETCH_REFERENCE" in ref["sample"]
