@@ -18,6 +18,7 @@ pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS
 pass sq  SQ_INSTS_VALU SQ_INSTS_SALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES
 pass wait SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD
 python tools/rocpd_summary.py "${OUT}" > "${OUT}/summary.txt" 2>&1
+python tools/r5_summary_json.py "${OUT}" > "${OUT}/traffic_lsh_sort.json" 2> "${OUT}/traffic_lsh_sort.err"
 unset R5_PROFILED
 timeout 120 python tools/r5_probe.py > "${OUT}/events.json" 2> "${OUT}/events.err"; echo "events rc=$?"; cat "${OUT}/events.json" | cut -c1-600
 find "${OUT}" -name "*.db" -delete 2>/dev/null
