@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void gather_digests_kernel(const uint64_t *__r
 // A bin can hold kBinCap elements; one that would overflow (a corpus of near-identical signatures) raises a flag that the
 // host reads after pass 1, and the call falls back to the radix sort.
 constexpr int kBinCap = 3072;
-constexpr int kScatterRows = 8;   // rows per thread of pass 1 (2048 per workgroup: 26 KB of LDS, six workgroups per CU)
+constexpr int kScatterRowsDefault = 8;   // rows per thread of pass 1 (2048 per team: 26 KB of LDS, six one-team workgroups per CU)
 constexpr int kSubBits = 10;  // (11 until round 5: 8 KB less LDS puts three workgroups on a CU instead of two, 0.45 -> 0.35 ms for 40M keys; 9 bits and a fourth workgroup gain nothing)
 constexpr int kSortThreads = 512;
 constexpr int kMaxBinBits = 14;        // final bins per band (two levels beyond kOneLevelBits)
@@ -109,7 +109,7 @@ __device__ __forceinline__ uint32_t bin_of(uint64_t digest, int bin_bits) { retu
 // the band is the top hi + lo digest bits, of which the low lo bits index the team's histogram.
 struct SlabPairs {};  // source of level 1: src_dig / src_row slabs of src_cap elements per unit, src_cursor[unit] of them filled
 
-template <typename SigT>
+template <typename SigT, int kScatterRows>
 __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__restrict__ sig, int32_t k, int32_t r, int64_t n, int32_t units,
                                                                int hi_bits, int lo_bits, int band_share, uint32_t cap,
                                                                uint32_t *__restrict__ cursor, uint64_t *__restrict__ slab_dig,
@@ -694,23 +694,41 @@ int launch_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *d_sorted_digests, c
 
 // the two-pass bucketing; *done = false when a bin overflowed (the caller falls back to the radix sort)
 // one scatter pass (see lsh_bin_scatter_kernel); returns false when the launch is refused
-template <typename SigT>
-static bool launch_scatter(mhx_ctx *ctx, const SigT *d_sig, int32_t k, int32_t r, int64_t n, int32_t units, int hi_bits, int lo_bits, int band_share,
-                           uint32_t cap, uint32_t *d_cursor, uint64_t *d_slab_dig, uint32_t *d_slab_row, uint32_t *d_overflow, const uint64_t *d_src_dig,
-                           const uint32_t *d_src_row, const uint32_t *d_src_cursor, uint32_t src_cap, size_t team_bytes) {
-    const int64_t span = std::is_same<SigT, SlabPairs>::value ? (int64_t)src_cap : n;
-    const int64_t items = (span + 256 * kScatterRows - 1) / (256 * kScatterRows) * (units / band_share);
-    const size_t lds = team_bytes * band_share;
+static size_t scatter_team_bytes(int lo_bits, bool pairs, int rows) {
+    const size_t nb = (size_t)1 << lo_bits, chunk = 256 * (size_t)rows;
+    return 8 * chunk + 8 * ((3 * nb * 4 + chunk * (pairs ? 4 : 2) + 16 + 7) / 8);
+}
+
+template <typename SigT, int ROWS>
+static bool launch_scatter_rows(mhx_ctx *ctx, const SigT *d_sig, int32_t k, int32_t r, int64_t n, int32_t units, int hi_bits, int lo_bits, int band_share,
+                                uint32_t cap, uint32_t *d_cursor, uint64_t *d_slab_dig, uint32_t *d_slab_row, uint32_t *d_overflow, const uint64_t *d_src_dig,
+                                const uint32_t *d_src_row, const uint32_t *d_src_cursor, uint32_t src_cap) {
+    constexpr bool kPairs = std::is_same<SigT, SlabPairs>::value;
+    const int64_t span = kPairs ? (int64_t)src_cap : n;
+    const int64_t items = (span + 256 * ROWS - 1) / (256 * ROWS) * (units / band_share);
+    const size_t lds = scatter_team_bytes(lo_bits, kPairs, ROWS) * band_share;
     const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(32 / (4 * band_share), (int64_t)((size_t)ctx->lds_per_block / (lds + 64))));
     const unsigned grid = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items, (int64_t)ctx->num_cus * per_cu * 2));
-    hipLaunchKernelGGL(lsh_bin_scatter_kernel<SigT>, dim3(grid), dim3(256 * band_share), lds, ctx->stream, d_sig, k, r, n, units, hi_bits, lo_bits, band_share, cap,
+    hipLaunchKernelGGL((lsh_bin_scatter_kernel<SigT, ROWS>), dim3(grid), dim3(256 * band_share), lds, ctx->stream, d_sig, k, r, n, units, hi_bits, lo_bits, band_share, cap,
                        d_cursor, d_slab_dig, d_slab_row, d_overflow, d_src_dig, d_src_row, d_src_cursor, src_cap);
     return hipGetLastError() == hipSuccess;
 }
 
-static size_t scatter_team_bytes(int lo_bits, bool pairs) {
-    const size_t nb = (size_t)1 << lo_bits, chunk = 256 * kScatterRows;
-    return 8 * chunk + 8 * ((3 * nb * 4 + chunk * (pairs ? 4 : 2) + 16 + 7) / 8);
+// rows per thread: 16 for the sources a team reads with unit stride (band-major digests, the big bins of level 0) -- twice the run
+// per (team, bin), half the atomics per key, 46 KB of LDS per one-team workgroup: 0.714 -> 0.664 ms for 40M keys, same box -- and 8
+// where four teams share the lines of a signature matrix (four times 46 KB would not fit); option lsh.chunk = 8 forces eight
+static int scatter_rows(const mhx_ctx *ctx, bool unit_stride) { return unit_stride && ctx->opt_lsh_chunk != 8 ? 16 : kScatterRowsDefault; }
+
+template <typename SigT>
+static bool launch_scatter(mhx_ctx *ctx, const SigT *d_sig, int32_t k, int32_t r, int64_t n, int32_t units, int hi_bits, int lo_bits, int band_share,
+                           uint32_t cap, uint32_t *d_cursor, uint64_t *d_slab_dig, uint32_t *d_slab_row, uint32_t *d_overflow, const uint64_t *d_src_dig,
+                           const uint32_t *d_src_row, const uint32_t *d_src_cursor, uint32_t src_cap) {
+    constexpr bool kUnit = std::is_same<SigT, SlabPairs>::value || std::is_same<SigT, Digest64BM>::value;
+    if (scatter_rows(ctx, kUnit) == 16)
+        return launch_scatter_rows<SigT, 16>(ctx, d_sig, k, r, n, units, hi_bits, lo_bits, band_share, cap, d_cursor, d_slab_dig, d_slab_row, d_overflow, d_src_dig,
+                                             d_src_row, d_src_cursor, src_cap);
+    return launch_scatter_rows<SigT, 8>(ctx, d_sig, k, r, n, units, hi_bits, lo_bits, band_share, cap, d_cursor, d_slab_dig, d_slab_row, d_overflow, d_src_dig, d_src_row,
+                                        d_src_cursor, src_cap);
 }
 
 // the two-pass (or, beyond 2^10 bins per band, three-pass) bucketing; *done = false when a bin overflowed or a resource could not
@@ -737,10 +755,10 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     int band_share = piece < 128 && 128 % piece == 0 ? std::min(4, 128 / piece) : 1;
     while (bands % band_share) band_share >>= 1;
     const int first_bits = hi_bits ? hi_bits : lo_bits;  // bits of the pass that reads the signatures
-    const size_t team_bytes = scatter_team_bytes(first_bits, false);
+    const size_t team_bytes = scatter_team_bytes(first_bits, false, scatter_rows(ctx, sig_dtype == kSigDigestsBM));
     const size_t lds_limit = (size_t)ctx->lds_per_block;
     while (band_share > 1 && team_bytes * band_share > lds_limit) band_share >>= 1;
-    if (team_bytes * band_share > lds_limit || scatter_team_bytes(lo_bits, true) > lds_limit) return MHX_OK;
+    if (team_bytes * band_share > lds_limit || scatter_team_bytes(lo_bits, true, scatter_rows(ctx, true)) > lds_limit) return MHX_OK;
     if (ctx->ensure_scratch(3, cur_bytes + dig_bytes + row_bytes + dig0_bytes + row0_bytes + 256) != MHX_OK) return MHX_OK;
     char *base = (char *)ctx->scratch[3];
     uint32_t *d_cursor = (uint32_t *)base;
@@ -758,7 +776,7 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     uint32_t *row_a = hi_bits ? d_slab0_row : d_slab_row;
     const uint32_t cap_a = hi_bits ? cap0 : (uint32_t)kBinCap;
     bool ok;
-#define MHX_SCATTER_A(T) ok = launch_scatter<T>(ctx, (const T *)d_sig, k, r, n, bands, 0, first_bits, band_share, cap_a, cur_a, dig_a, row_a, ovf_a, nullptr, nullptr, nullptr, 0, team_bytes)
+#define MHX_SCATTER_A(T) ok = launch_scatter<T>(ctx, (const T *)d_sig, k, r, n, bands, 0, first_bits, band_share, cap_a, cur_a, dig_a, row_a, ovf_a, nullptr, nullptr, nullptr, 0)
     if (sig_dtype == kSigDigestsBM) MHX_SCATTER_A(Digest64BM);
     else if (sig_dtype == kSigDigests) MHX_SCATTER_A(Digest64);
     else if (sig_dtype == MHX_U32) MHX_SCATTER_A(uint32_t);
@@ -767,7 +785,7 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     if (!ok) return MHX_OK;  // (a launch the device refuses: nothing has run, the radix sort takes over)
     if (hi_bits) {  // level 1: every big bin into its 2^lo final bins
         if (!launch_scatter<SlabPairs>(ctx, (const SlabPairs *)nullptr, k, r, n, (int32_t)big_bins, hi_bits, lo_bits, 1, (uint32_t)kBinCap, d_cursor, d_slab_dig, d_slab_row,
-                                       d_overflow, d_slab0_dig, d_slab0_row, d_cursor0, cap0, scatter_team_bytes(lo_bits, true)))
+                                       d_overflow, d_slab0_dig, d_slab0_row, d_cursor0, cap0))
             return MHX_OK;
     }
     uint32_t overflow[2] = {0, 0};

@@ -75,6 +75,9 @@ if not profiled:
     for rnd in range(2):
         out.setdefault("sort_digests_row_major_ms", []).extend(timed(sort, 3))
         out.setdefault("sort_digests_band_major_ms", []).extend(timed(sort_bm, 3))
+        ctx.set_option("lsh.chunk", 8)
+        out.setdefault("sort_digests_band_major_chunk8_ms", []).extend(timed(sort_bm, 3))
+        ctx.set_option("lsh.chunk", 0)
         out.setdefault("digests_band_major_ms", []).extend(timed(digests_bm, 3))
         out.setdefault("fused_band_major_ms", []).extend(timed(fused_bm, 3))
         out.setdefault("pack_ms", []).extend(timed(pack, 3))
