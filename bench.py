@@ -41,7 +41,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-TRAFFIC_FILE = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_traffic_minhash_bulk.json") for r in (4, 3)) if os.path.exists(p)),
+TRAFFIC_FILE = next((p for p in (os.path.join(ROOT, "profiles", f"r0{r}_traffic_minhash_bulk.json") for r in (5, 4, 3)) if os.path.exists(p)),
                     os.path.join(ROOT, "profiles", "r03_traffic_minhash_bulk.json"))
 
 
@@ -1208,14 +1208,16 @@ def extra_c4(ctx, n=100_000, dim=4096, s=128):
         raise SystemExit(f"PARITY FAILURE (extra.c4): {gate['unexplained']} device-log mismatches outside the 1e-6 ln_a tolerance")
     alg = n * (4 * dim + 16 * s)
     out.update({
-        "kernel": dict(_roof(alg, ms), vectors_per_s=n / (ms * 1e-3), element_evaluations_per_s=n * dim * s / (ms * 1e-3),
-                       kernels="walk_plan_kernel + walk_build_kernel (no-op once the tables stand) + weighted_walk_dense_kernel",
-                       note="bound-ordered walk: ~2 exact evaluations per (row, sample) instead of 4096 (the element rate counts the "
-                            "evaluations the reference makes); the matrix is read once, logs precomputed and resident; "
-                            "algorithmic bytes = 4*dim + 16*S per vector"),
+        # the reference's function takes VALUES (weighted_minhash.py:212 takes np.log itself): that is config 4's primary number
+        "kernel": dict(_roof(alg, ms_log), vectors_per_s=n / (ms_log * 1e-3), element_evaluations_per_s=n * dim * s / (ms_log * 1e-3),
+                       kernels="walk_plan_kernel + walk_build_kernel (no-op once the tables stand) + weighted_walk_wave_kernel<values in>",
+                       note="VALUES in, as the reference's minhash_many takes them: the device takes numpy's float32 log (np_logf) of the entries a walk "
+                            "meets; bound-ordered walk: ~2 exact evaluations per (row, sample) instead of 4096 (the element rate counts the "
+                            "evaluations the reference makes); the matrix is read once; algorithmic bytes = 4*dim + 16*S per vector"),
+        "kernel_logs_in": dict(_roof(alg, ms), vectors_per_s=n / (ms * 1e-3),
+                               note="the same with np.log of the matrix precomputed and resident (what the host-log parity mode hands over)"),
         "kernel_every_element": dict(_roof(alg, ms_every), vectors_per_s=n / (ms_every * 1e-3),
                                      note="weighted.path=2: round 2's kernels (every element evaluated), same call, same box"),
-        "kernel_device_log": dict(_roof(alg, ms_log), vectors_per_s=n / (ms_log * 1e-3)),
         "from_python_parity_mode": {"seconds": dt_auto, "vectors_per_s": n / dt_auto, "log_taken_on": "device" if log_matches else "host",
                                     "note": "numpy in -> numpy out, the default mode: (k, t) bit-identical to the reference; the log is taken on the device when "
                                             "its float32 log reproduces this host's np.log on the start-up sentinels (device_log_matches_numpy), else on the host; "

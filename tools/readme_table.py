@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""tools/readme_table.py -- README.md's "Measured" table, generated from profiles/r05_bench.json (the headline bench line with
+its extra configs) and profiles/r05_bench_n{2,8}_host.json (ranks sharing one GPU over the host-staged transport).
+
+    python tools/readme_table.py            # rewrites the block between the markers in README.md
+    python tools/readme_table.py --print    # the block on stdout"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BEGIN, END = "<!-- measured:begin (tools/readme_table.py) -->", "<!-- measured:end -->"
+
+
+def load(name):
+    path = os.path.join(ROOT, "profiles", name)
+    if not os.path.exists(path) or os.path.getsize(path) == 0:
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def row(what, shape, ms, frac, note=""):
+    return f"| {what} | {shape} | {ms:.3g} | {frac:.2f} | {note} |" if frac is not None else f"| {what} | {shape} | {ms:.3g} | — | {note} |"
+
+
+def main():
+    d = load("r05_bench.json")
+    if d is None:
+        raise SystemExit("profiles/r05_bench.json is missing")
+    e, r, cpu = d["extra"], d["roofline"], d["cpu_baseline"]
+    # (files written before the values-in figure became config 4's primary one keep it under kernel_device_log)
+    c4v = e["c4"].get("kernel_device_log") or e["c4"]["kernel"]
+    c4l = e["c4"].get("kernel_logs_in") or e["c4"]["kernel"]
+    lines = [BEGIN,
+             f"Measured on one MI355X (`profiles/r05_bench.json`: `python bench.py`, every launch timed with HIP events behind a clock warm-up; "
+             f"`frac` = algorithmic bytes / time against 8 TB/s).  Headline: **{d['value']:.3g} signatures/s** ({d['ms_per_step']:.2f} ms per 10^6 sets, "
+             f"traffic {r['traffic'] / r['algorithmic_bytes_per_launch']:.2f}x algorithmic, VALU issue {r['valu_issue_frac']:.2f}); the numpy path "
+             f"({cpu['kind']}) does {cpu['single_core_value']:.3g}/s per core, {cpu['value']:.3g}/s on {cpu['cores']} cores of the box's {cpu['cpu_model']}; "
+             f"host numpy in -> host numpy out (PCIe included) {d['pcie_inclusive_value']:.2g}/s, {d['pcie_inclusive_u32_value']:.2g}/s with uint32 tokens and signatures.",
+             "",
+             "| kernel / chain | shape | ms | frac of 8 TB/s | |",
+             "|---|---|---|---|---|",
+             row("MinHash signatures (config 2, headline)", "1M x 256 tokens, K=128, uint64", r["kernel_ms"], r["frac"], "integer-VALU-bound"),
+             row("MinHash signatures (config 3 shard)", "1.25M x 256, K=256, uint32 out", e["c3"]["signatures"]["kernel_ms"], e["c3"]["signatures"]["frac"]),
+             row("band digests, band-major", "1.25M x 256 -> 32 x 8", e["c3"]["band_digests"]["kernel_ms"], e["c3"]["band_digests"]["frac"]),
+             row("LSH bucketing from the digests", "40M (band, digest) keys", e["c3"]["lsh_sort_digests"]["kernel_ms"], e["c3"]["lsh_sort_digests"]["frac"],
+                 f"library radix sort: {e['c3']['lsh_sort_bands_radix']['kernel_ms']:.2f} ms"),
+             row("config 3 shard, whole chain", "signatures -> digests -> bucketing", e["c3"]["pipeline_ms"], None),
+             row("config 5 shard: b=1 blocks + band digests, ONE read", "1.25M x 256", e["c5"]["fused_band_major"]["kernel_ms"], e["c5"]["fused_band_major"]["frac"],
+                 f"two kernels: {e['c5']['pipeline_ms_two_kernels']:.2f} ms"),
+             row("config 4: weighted minhash_many, values in (as the reference takes them)", "100k x 4096, S=128", c4v["kernel_ms"], c4v["frac"],
+                 f"every element evaluated: {e['c4']['kernel_every_element']['kernel_ms']:.1f} ms; from Python, bit-exact mode: {e['c4']['from_python_parity_mode']['seconds'] * 1e3:.0f} ms"),
+             row("config 4, logs precomputed and resident", "100k x 4096, S=128", c4l["kernel_ms"], c4l["frac"]),
+             ]
+    if "c3_full" in e:
+        f3, f5 = e["c3_full"], e["c5_full"]
+        lines += [row("**config 3 at its stated size**: signatures", "10M x 256 (2.56e9 tokens), K=256", f3["signatures"]["kernel_ms"], f3["signatures"]["frac"]),
+                  row("... band digests", "10M x 256 -> 32 x 8", f3["band_digests"]["kernel_ms"], f3["band_digests"]["frac"]),
+                  row("... bucketing (two scatter levels + bin pass)", "320M keys", f3["lsh_sort_digests"]["kernel_ms"], f3["lsh_sort_digests"]["frac"]),
+                  row("... whole chain", "", f3["pipeline_ms"], None),
+                  row("**config 5 at its stated size**: blocks + digests, one read", "10M x 256", f5["fused"]["kernel_ms"], f5["fused"]["frac"],
+                      f"two kernels: {f5['two_kernels_ms']:.2f} ms")]
+    for n in (2, 8):
+        m = load(f"r05_bench_n{n}_host.json")
+        if m and "extra" in m and "c3_sharded" in m["extra"] and "ms" in m["extra"]["c3_sharded"]:
+            c = m["extra"]["c3_sharded"]
+            lines.append(f"| config 3 across {n} ranks SHARING this one GPU (plumbing, not a scaling number) | {c['rows_total']} rows, transport `{c['allgather']['transport']}` | "
+                         f"{c['pipeline_ms']:.3g} | — | signatures {c['ms']['signatures']:.1f} + all-gather {c['ms']['allgather']:.0f} + digests {c['ms']['band_digests']:.2f} + bucketing {c['ms']['bucketing']:.2f} |")
+    lines += ["", "No multi-GPU node has been available: the RCCL all-gather has run with one rank only (`DESIGN.md` section 6).", END]
+    block = "\n".join(lines)
+    if "--print" in sys.argv:
+        print(block)
+        return
+    path = os.path.join(ROOT, "README.md")
+    text = open(path).read()
+    if BEGIN not in text or END not in text:
+        raise SystemExit("README.md lacks the markers")
+    a, b = text.index(BEGIN), text.index(END) + len(END)
+    open(path, "w").write(text[:a] + block + text[b:])
+    print("README.md updated")
+
+
+if __name__ == "__main__":
+    main()
