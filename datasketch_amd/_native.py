@@ -38,6 +38,7 @@ _PROTOTYPES = {
     "mhx_ctx_device_info": [_vp, ctypes.c_char_p, _int, ctypes.POINTER(_int), ctypes.POINTER(_i64)],
     "mhx_ctx_set_option": [_vp, ctypes.c_char_p, _i64],
     "mhx_ctx_counters": [_vp, _int, ctypes.POINTER(ctypes.c_uint64)],
+    "mhx_ctx_minhash_mode": [_vp, _int, ctypes.POINTER(_int)],
     "mhx_dev_alloc": [_vp, _sz, ctypes.POINTER(_vp)],
     "mhx_dev_free": [_vp, _vp],
     "mhx_debug_guard_alloc": [_int, ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
@@ -397,6 +398,13 @@ class Context:
         check(self.lib.mhx_ctx_counters(self.handle, 1 if enable else 0, out))
         return {"sieve_sets_redone": int(out[0]), "exact_sets_redone": int(out[1]), "sieve_blocks": int(out[2]),
                 "pairwise_sets": int(out[3])}
+
+    def minhash_mode(self, reset: bool = False) -> int:
+        """What the last MinHash call on this context learned about the corpus (0 clean, 1 many sets defeat the one-candidate
+        proof, 2 heavily repeated tokens): the next call's first launch follows it.  ``reset=True`` forgets it."""
+        mode = _int(0)
+        check(self.lib.mhx_ctx_minhash_mode(self.handle, 1 if reset else 0, ctypes.byref(mode)))
+        return mode.value
 
     def synchronize(self) -> None:
         check(self.lib.mhx_ctx_synchronize(self.handle))

@@ -388,6 +388,22 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     return MHX_OK;
 }
 
+// What the previous MinHash call on this context learned about the corpus (d_work word 8, written by the last launch of every
+// call and read by the first launch of the next one): 0 = one-candidate proof first, 1 = most sets defeat it (tie-tolerant proof
+// first), 2 = heavily repeated tokens.  Timings depend on it, results never; reset = 1 puts it back to 0 (a fresh context).
+int mhx_ctx_minhash_mode(mhx_ctx *ctx, int reset, int *mode) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    if (int rc = ctx->activate()) return rc;
+    if (int rc = ctx->ensure_work()) return rc;
+    unsigned int word = 0;
+    MHX_HIP_CHECK(hipMemcpyAsync(&word, ctx->d_work + 8, sizeof(word), hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (mode) *mode = (int)word;
+    if (reset) MHX_HIP_CHECK(hipMemsetAsync(ctx->d_work + 8, 0, sizeof(word), ctx->stream));
+    return MHX_OK;
+}
+
 int mhx_ctx_counters(mhx_ctx *ctx, int enable, uint64_t out[MHX_NUM_COUNTERS]) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
     MHX_GUARD(ctx);

@@ -105,6 +105,11 @@ MHX_API int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value);
  * enable != 0 starts/keeps counting, 0 stops it (counting costs one atomic per event). */
 #define MHX_NUM_COUNTERS 4
 MHX_API int mhx_ctx_counters(mhx_ctx *ctx, int enable, uint64_t out[MHX_NUM_COUNTERS]);
+/* What the previous MinHash call on this context learned about the corpus and the first launch of the next call acts on:
+ * 0 = the one-candidate proof goes first, 1 = most sets defeated it (the tie-tolerant proof goes first), 2 = heavily
+ * repeated tokens.  Timings depend on it (so a benchmark may want to know, or to reset it), results never.  reset != 0 puts it
+ * back to 0, the state of a fresh context.  mode may be NULL.  Blocking. */
+MHX_API int mhx_ctx_minhash_mode(mhx_ctx *ctx, int reset, int *mode);
 
 /* ---- device memory + events (so callers can keep corpora resident and time kernels) ------- */
 MHX_API int mhx_dev_alloc(mhx_ctx *ctx, size_t bytes, void **dptr);

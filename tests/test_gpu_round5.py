@@ -320,3 +320,28 @@ def test_full_size_chain_under_guard_pages():
     assert "ok" in probe.stdout, "the HIP virtual-memory API is not usable on this box:\n" + probe.stdout[-1000:] + probe.stderr[-1000:]
     line, c3, c5 = _full(10_000_000, env={"MHX_GUARD_ALLOC": "16"})
     assert line["guard_alloc"] == "16"
+
+
+# ------------------------------------------------------------------ what a context learned about the corpus is visible
+def test_minhash_mode_word_is_readable_follows_the_corpus_and_resets(ctx):
+    """mhx_ctx_minhash_mode: 0 on a clean corpus, non-zero after calls whose sets mostly defeat the one-candidate proof (every
+    set full of repeated tokens), 0 again after a reset -- and the signatures are the oracle's whatever the word says."""
+    rng = np.random.RandomState(5)
+    k, n, t = 128, 6000, 256
+    a, b = O.np_init_permutations(k, 4)
+    clean = rng.randint(0, 2**32, size=(n, t), dtype=np.uint64)
+    dirty = clean.copy()
+    dirty[:, 1::2] = dirty[:, 0::2]                       # every token twice in every set
+    want_clean, want_dirty = O.c_minhash_bulk_dense(clean, a, b), O.c_minhash_bulk_dense(dirty, a, b)
+    assert ctx.minhash_mode(reset=True) in (0, 1, 2)
+    assert ctx.minhash_mode() == 0
+    for _ in range(3):
+        assert np.array_equal(ctx.minhash_bulk((a, b), clean.reshape(-1), None, t, n), want_clean)
+    assert ctx.minhash_mode() == 0
+    for _ in range(3):
+        assert np.array_equal(ctx.minhash_bulk((a, b), dirty.reshape(-1), None, t, n), want_dirty)
+    learned = ctx.minhash_mode()
+    assert learned in (1, 2), learned
+    assert np.array_equal(ctx.minhash_bulk((a, b), clean.reshape(-1), None, t, n), want_clean)   # first launch chosen for the dirty corpus: same result
+    assert ctx.minhash_mode(reset=True) in (0, 1, 2) and ctx.minhash_mode() == 0
+    assert np.array_equal(ctx.minhash_bulk((a, b), dirty.reshape(-1), None, t, n), want_dirty)
