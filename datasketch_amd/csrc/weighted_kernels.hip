@@ -1442,7 +1442,7 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
                                                                  const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos,
                                                                  int32_t sample_size, int32_t s_pad, int32_t list_cap, int32_t direct_permille,
                                                                  int32_t stripe_words, int32_t rescue_lanes, int64_t *__restrict__ out,
-                                                                 uint8_t *__restrict__ nonempty) {
+                                                                 uint8_t *__restrict__ nonempty, int32_t debug) {
     extern __shared__ float lds[];  // cached list positions of the first n_cc chunks | per wave: row[dim] | list[list_cap] u16
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), n_waves = blockDim.x >> 6;
@@ -1510,6 +1510,11 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
         // (FETCH bit 0) the refill goes out as soon as the registers are free: two rows per wave are in flight for the whole
         // of the scan and the walk, at the price of the walk's first table load waiting behind it
         if constexpr ((FETCH & 1) != 0) fetch(pre, d + 2 * stride);
+        if (debug == 2) {  // profiling only (results are wrong): rows fetched and staged, nothing else
+            if (lane == 0) nonempty[d] = lane_above || lane_odd ? 1 : 0;
+            if constexpr ((FETCH & 1) == 0) fetch(pre, d + 2 * stride);
+            return;
+        }
         const bool any_above = __any(lane_above), any_odd = __any(lane_odd);
         int n_stored = dim, n_out = 0;
         bool has_nan = false;
@@ -1570,6 +1575,11 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
             n_list = n_stored;
         }
         const bool walked = n_stored > 0 && !has_nan && !(by_entry && !listable);
+        if (debug == 1) {  // profiling only (results are wrong): staged and scanned, not walked
+            if (lane == 0) nonempty[d] = walked ? 1 : 0;
+            if constexpr ((FETCH & 1) == 0) fetch(pre, d + 2 * stride);
+            return;
+        }
         {
             constexpr bool VALS = !LOGS;  // (values in: the stripe holds values unless this row's logs were taken in place: logs_staged)
             for (int32_t ch = 0; ch < chunks; ++ch) {
@@ -1887,7 +1897,7 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
         const int64_t fit = ((int64_t)ctx->lds_per_block - (int64_t)cache_bytes - 64) / (int64_t)stripe_bytes;
         const int waves = (int)std::min<int64_t>(8, fit);
         const bool shape_ok = (dim & 3) == 0 && (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 && dim >= 1024 && dim <= 4096;
-        if (shape_ok && waves >= 4 && ctx->opt_weighted_kernel != 1 && ctx->opt_weighted_debug == 0) {
+        if (shape_ok && waves >= 4 && ctx->opt_weighted_kernel != 1) {  // (weighted.debug 1 / 2: this kernel's phases alone, profiling)
             const size_t lds = cache_bytes + stripe_bytes * (size_t)waves;
             const int64_t groups = (n_rows + waves - 1) / waves;
             const int64_t per_cu = ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu : std::max<int64_t>(1, (int64_t)ctx->lds_per_block / (int64_t)(lds + 64));
@@ -1896,7 +1906,7 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
 #define MHX_WALK_WAVE(LOGS, NV_, ...)                                                                                                  \
     hipLaunchKernelGGL((weighted_walk_wave_kernel<LOGS, NV_, __VA_ARGS__>), dim3(blocks), dim3(64 * waves), lds, ctx->stream, d_x, n_rows, dim, plan, walk_a, \
                        gen->d_walk_c, reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, list_cap_w, direct_permille_w,  \
-                       (int32_t)(stripe_bytes / 4), rescue_lanes, d_out, d_nonempty)
+                       (int32_t)(stripe_bytes / 4), rescue_lanes, d_out, d_nonempty, (int32_t)ctx->opt_weighted_debug)
 #define MHX_WALK_WAVE_NV(LOGS, PAIRS_)            \
     do {                                          \
         if (nv == 4) MHX_WALK_WAVE(LOGS, 4, PAIRS_);      \
