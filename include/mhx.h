@@ -119,8 +119,11 @@ MHX_API int mhx_dev_free(mhx_ctx *ctx, void *dptr);
  * unmapped granules, its LAST byte (align > 0; the size is rounded up to `align` bytes: 16, 8, 4, 1 ...) or its FIRST
  * byte (align < 0) abutting the unmapped range, so that an over- or under-read by a kernel raises a GPU memory access
  * fault instead of touching a neighbour.  align = 0 switches back to hipMalloc (live guarded blocks stay valid).  The
- * environment variable MHX_GUARD_ALLOC=<align> does the same from the first allocation.  granule (may be NULL)
- * receives the mapping granularity in bytes, live (may be NULL) the number of guarded blocks currently allocated. */
+ * environment variable MHX_GUARD_ALLOC=<align> does the same from the first allocation (a value that is not 0 or
+ * +-(a power of two <= 4096) is reported on stderr and ignored).  granule (may be NULL) receives the mapping granularity
+ * in bytes, live (may be NULL) the number of guarded blocks currently allocated.  A debugging mode, not a production one:
+ * the virtual address ranges of freed guarded blocks are never reused (a stale pointer must fault, not alias), so a long
+ * guarded run grows its address space by (size + 2 granules) per allocation, and every free synchronises the device. */
 MHX_API int mhx_debug_guard_alloc(int align, int64_t *granule, int64_t *live);
 /* Debugging: poison.  From this call on every fresh device allocation of the library in this process is filled with
  * byte_value (0..255; -1 switches it off) before it is handed out -- what a board that has been in use gives a process
