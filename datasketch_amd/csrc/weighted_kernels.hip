@@ -1489,24 +1489,27 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
         // on the scalar unit: a lane's "seen one" flags are lane masks in scalar registers, OR-ed per element (s_or_b64; 128
         // explicit ballots instead made the compiler keep every mask alive: 440 spilled SGPRs), and only a row that has an
         // entry above the cut, a NaN or an absent entry is looked at again, from LDS.
-        bool lane_above = false, lane_odd = false;
+        // A lane behind the row's end holds a clamped copy of the row's last four entries (fetch): what it finds is what the lane
+        // that really owns them finds, and what it stores goes where that lane stores the same bytes -- so neither the scan nor the
+        // store is predicated.  (Round 4 wrote `if (in)` around the store: sixteen exec-mask regions per row, each with its own
+        // conservative s_waitcnt vmcnt(0) -- a wait for the rows fetched ahead as well -- and the masks spilled to VGPR lanes.)
+        // The three questions the scan asks -- an entry above the cut? a NaN? an entry that is not stored (LOGS: -inf; values: <=
+        // 0)? -- are asked of a maximum, a sum and a minimum over the lane's 64 entries (v_max3 / v_min3 / v_add: ~100 VALU
+        // instructions, no scalar ones) instead of two compares and two scalar ORs per entry: max and min skip NaNs, the sum
+        // carries them (and is NaN without one only for +inf and -inf together, a row the minimum flags anyway).
+        float mx = -__builtin_inff(), mn = __builtin_inff(), sum = 0.0f;
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int c = (u * kWave + lane) * 4;
-            const bool in = c < dim;  // (a lane behind the row's end holds a clamped copy of its last entries: computed, not kept)
-            const float l[4] = {pre[u].x, pre[u].y, pre[u].z, pre[u].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (LOGS) {
-                    lane_above |= in && l[e] > lcut;                              // +inf too
-                    lane_odd |= in && __builtin_amdgcn_class(l[e], 0x007);        // signalling / quiet NaN, -inf (= not stored)
-                } else {
-                    lane_above |= in && l[e] > vcut;                              // candidates: their logs are taken below
-                    lane_odd |= in && __builtin_amdgcn_class(l[e], 0x07F);        // NaN, negative (log: NaN), +-0 (= not stored)
-                }
-            }
-            if (in) *reinterpret_cast<float4 *>(row + c) = make_float4(l[0], l[1], l[2], l[3]);
+            const float4 v = pre[u];
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fmaxf(v.x, v.y)), __builtin_fmaxf(v.z, v.w));
+            mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fminf(v.x, v.y)), __builtin_fminf(v.z, v.w));
+            sum += (v.x + v.y) + (v.z + v.w);
+            *reinterpret_cast<float4 *>(row + (c < dim ? c : dim - 4)) = v;
         }
+        const bool lane_above = LOGS ? mx > lcut : mx > vcut;                    // (+inf too; values: candidates, their logs are taken below)
+        const bool lane_odd = sum != sum || (LOGS ? mn == -__builtin_inff()      // a NaN, or an entry that is not stored: log -inf,
+                                                  : mn <= 0.0f);                 // a value that is zero (+-0) or negative (its log: NaN)
         // (FETCH bit 0) the refill goes out as soon as the registers are free: two rows per wave are in flight for the whole
         // of the scan and the walk, at the price of the walk's first table load waiting behind it
         if constexpr ((FETCH & 1) != 0) fetch(pre, d + 2 * stride);
