@@ -8,6 +8,10 @@ set -uo pipefail
 TAG="${1:-run}"
 OUT="gpurun_out/refresh_${TAG}"
 mkdir -p "${OUT}"
+# which box this is, and what its RAS counters say before anything runs: a "Memory access fault ... Reason: Unknown" (met twice in
+# round 4, never in round 5) can then be told from a kernel's fault by where it happened, not argued
+{ echo "# $(date -u +%FT%TZ) host $(hostname)"; for f in /sys/class/drm/card*/device/unique_id; do echo "$f $(cat "$f" 2>/dev/null)"; done
+  rocm-smi --showrasinfo all 2>&1 | head -60; rocm-smi --showmemuse --showuse 2>&1 | head -20; dmesg 2>/dev/null | grep -iE "amdgpu|gpu fault|page fault" | tail -20; } > "${OUT}/box.txt" 2>&1
 timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider > "${OUT}/pytest_gpu.log" 2>&1; echo "pytest rc=$?"; grep -aE "passed|failed" "${OUT}/pytest_gpu.log" | tail -1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "${OUT}/smoke.log" 2>&1; rc=$?; echo "smoke rc=${rc}"
 if [[ ${rc} -ne 0 ]]; then echo "smoke failed: not profiling on this box"; tail -5 "${OUT}/smoke.log"; exit 1; fi
@@ -23,4 +27,5 @@ for n in 2 8; do
 done
 { echo "## config 4: logs in, the walk's fetch modes (weighted.refill: 1 = round 4, 0 = auto)"; timeout 200 python tools/bench_weighted.py --check 2048 --reps 5 --variants "refill=0;refill=1;refill=0";
   echo "## config 4, values in"; timeout 200 python tools/bench_weighted.py --values --check 0 --reps 5 --variants "refill=0;refill=1;kernel=2,refill=3;refill=0"; } > "${OUT}/bench_weighted.txt" 2>&1; echo "weighted rc=$?"
+{ echo "# after the run:"; rocm-smi --showrasinfo all 2>&1 | head -60; dmesg 2>/dev/null | grep -iE "amdgpu|gpu fault|page fault" | tail -20; } >> "${OUT}/box.txt" 2>&1
 find gpurun_out -name "*.db" -delete 2>/dev/null; find gpurun_out -type f -size +8M -delete 2>/dev/null; du -sh gpurun_out | tail -1
