@@ -1482,8 +1482,6 @@ int mhx_wgen_destroy(mhx_wgen *gen) {
     (void)mhx::dev_free(gen->d_walk_a);
     (void)mhx::dev_free(gen->d_walk_c);
     (void)mhx::dev_free(gen->d_walk_plan);
-    if (gen->d_left_over) (void)mhx::dev_free(gen->d_left_over);
-    if (gen->h_left_over) (void)hipHostFree(gen->h_left_over);
     delete gen;
     return MHX_OK;
 }

@@ -142,13 +142,6 @@ struct mhx_wgen {
     void *d_walk_plan = nullptr;  // two WalkPlan records: the one the last call wrote (plan_index) and the one the next call will write
     int plan_index = 0;
     bool walk_ok = false;
-    // the compact walk kernel (weighted_kernels.hip) leaves rows that are not plain stored numbers to the kernel behind it and
-    // counts them: d_left_over on the device, copied after every call into h_left_over (page-locked) so that the NEXT call can
-    // see, without a synchronisation, that this generator's data is mostly such rows and go straight to that kernel
-    unsigned int *d_left_over = nullptr;
-    unsigned int *h_left_over = nullptr;
-    int64_t compact_rows = 0;   // rows of the call whose count h_left_over holds
-    int compact_backoff = 0;    // calls that skip the compact kernel before it is tried again
 };
 
 struct mhx_event {

@@ -167,27 +167,6 @@ __device__ __forceinline__ float row_log(const float *row, uint32_t c, bool stag
     return np_logf(v);
 }
 
-// A row of which only the columns some sample can reach within its first cached list positions sit in LDS (the compact walk
-// kernel: weighted_walk_compact_kernel): `cs` is a column, or -- for the cached list positions, whose LDS copy of the table carries
-// it -- (slot + 1) << 16 | column; a column without a slot is read from the matrix itself (the row has just been streamed: an L2 hit
-// as a rule).  Same value, same treatment as row_log above, so a walk over a CompactRow takes exactly the steps of a walk over the
-// staged row.
-struct CompactRow {
-    const float *stripe;  // LDS: the row's entries at the reachable columns, by slot
-    const float *glob;    // the row in the matrix (device memory)
-};
-__device__ __forceinline__ uint32_t column_of(const float *, uint32_t cs) { return cs; }
-__device__ __forceinline__ uint32_t column_of(const CompactRow &, uint32_t cs) { return cs & 0xFFFFu; }
-template <bool VALS = false>
-__device__ __forceinline__ float row_log(const CompactRow &row, uint32_t cs, bool staged = false) {
-    const uint32_t slot = cs >> 16;
-    const float v = slot ? row.stripe[slot - 1] : row.glob[cs & 0xFFFFu];
-    if (!VALS || staged) return v;
-    const bool zero = v == 0.0f;
-    if (__builtin_expect(__all(zero || np_logf_is_normal(v)), 1)) return zero ? -__builtin_inff() : np_logf_normal(v);
-    return np_logf(v);
-}
-
 // ---- pre-pass: one wave per row -------------------------------------------------------------
 // logs[j] = ln(x) (device-log mode only), flags[row] = kFlagSamePattern (same column list as the
 // first row of its block of 8) | kFlagSane (every log value is 0, +-inf or 2^-40 <= |L| <= 2^40).
@@ -879,7 +858,6 @@ struct Held {
 };
 
 constexpr int kCachedChunks = 4;
-constexpr int64_t MHX_COMPACT_AUTO = -1;  // value of weighted.kernel at which the compact kernel is chosen by itself (-1: never; 0 would make it the default)
 
 // The second half of a row, one wave per 64 samples: the row's logs are in LDS (row[c]; -inf: not stored), `list` holds
 // n_list columns -- every stored one (all_listed: the row is evaluated entry by entry) or the ones above the cut, which
@@ -1016,8 +994,8 @@ __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list,
 // sequential walk would hold on reaching it, the first position whose bound exceeds that is where the walk stops, and the
 // smallest (ln_a, column) in front of it -- np.argmin's choice, ties to the smaller column -- is its result.  Same
 // evaluations (IEEE division here), same stop rule, same answer as position by position.
-template <bool VALS = false, typename ROW = const float *>
-__device__ __forceinline__ void walk_rescue(const ROW &row, int32_t dim, int32_t ch, int ls, int32_t k, const float4 *__restrict__ walk_a,
+template <bool VALS = false>
+__device__ __forceinline__ void walk_rescue(const float *row, int32_t dim, int32_t ch, int ls, int32_t k, const float4 *__restrict__ walk_a,
                                             const uint32_t *__restrict__ walk_c, int lane, Held &held, bool staged = false) {
     const auto lane_value = [](float v, int from) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), from)); };  // (the builtin is int -> int)
     float best_a = lane_value(held.ln_a, ls), best_t = lane_value(held.t, ls);
@@ -1073,8 +1051,8 @@ __device__ __forceinline__ void walk_rescue(const ROW &row, int32_t dim, int32_t
 // still walks or not (a finished lane's are dropped), so a finished lane can at most cause the exact re-evaluation of a
 // round, never a different value.  The chunks ch0 .. ch0 + NC - 1 all have their first positions cached (cache_a /
 // cache_c: chunk ch0's, the others' behind it).
-template <int NC, bool VALS = false, typename ROW = const float *, int RESCUE_AFTER = 2>  // RESCUE_AFTER: rounds beyond the cached positions before the last lanes are rescued
-__device__ __forceinline__ void walk_chunks(const ROW &row, const uint16_t *list, int n_list, bool all_listed, int32_t dim, int32_t ch0,
+template <int NC, bool VALS = false>
+__device__ __forceinline__ void walk_chunks(const float *row, const uint16_t *list, int n_list, bool all_listed, int32_t dim, int32_t ch0,
                                             int lane, int32_t sample_size, const float4 *__restrict__ walk_a,
                                             const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos, int32_t s_pad,
                                             const float4 *cache_a, const uint32_t *cache_c, int32_t rescue_lanes, Held (&held)[NC], bool staged = false) {
@@ -1165,7 +1143,7 @@ __device__ __forceinline__ void walk_chunks(const ROW &row, const uint16_t *list
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
                 done[i] = done[i] || e[i][u].x > held[i].ln_a;
-                held[i].take_if(!done[i] && !(l[i][u] == -__builtin_inff()), a[i][u], t[i][u], column_of(row, c[i][u]));  // (a cached position may carry its LDS slot: CompactRow)
+                held[i].take_if(!done[i] && !(l[i][u] == -__builtin_inff()), a[i][u], t[i][u], c[i][u]);
             }
     }
     if (k == n_cached && k < dim && walking()) {  // beyond the cached positions: rounds of two from registers (four: no faster on heavy-tailed rows, whose walks wait for the slowest of 128 lanes), the next round's entries on their way
@@ -1197,7 +1175,7 @@ __device__ __forceinline__ void walk_chunks(const ROW &row, const uint16_t *list
 #pragma unroll
             for (int i = 0; i < NC; ++i) done[i] = done[i] || e[i][0].x > held[i].ln_a;
             if (!walking()) break;
-            if (rescue_lanes > 0 && k >= n_cached + RESCUE_AFTER * kG) {  // few lanes left after two rounds out here: each of them in turn gets the whole wave (walk_rescue; a tail of a round or two is cheaper in lock step: uniform weights)
+            if (rescue_lanes > 0 && k >= n_cached + 2 * kG) {  // few lanes left after two rounds out here: each of them in turn gets the whole wave (walk_rescue; a tail of a round or two is cheaper in lock step: uniform weights)
                 unsigned long long act[NC];
                 int n_act = 0;
 #pragma unroll
@@ -1208,7 +1186,7 @@ __device__ __forceinline__ void walk_chunks(const ROW &row, const uint16_t *list
                         while (act[i]) {
                             const int ls = __builtin_ctzll(act[i]);
                             act[i] &= act[i] - 1;
-                            walk_rescue<VALS, ROW>(row, dim, ch0 + i, ls, k, walk_a, walk_c, lane, held[i], staged);
+                            walk_rescue<VALS>(row, dim, ch0 + i, ls, k, walk_a, walk_c, lane, held[i], staged);
                         }
                         done[i] = true;
                     }
@@ -1458,9 +1436,7 @@ __global__ __launch_bounds__(256, 4) void weighted_walk_dense_kernel(const float
 // Same arithmetic, same rules, same helper (walk_row) as the kernel above; rows it does not take (dim > 4096 or not a
 // multiple of 4, fewer than two stripes fitting the LDS) stay with that kernel.
 // FETCH (A/B, option weighted.refill): bit 0 = the next row's loads go out right after staging instead of behind the walk, bit 1 = non-temporal loads
-// LISTED: only the rows whose nonempty[] byte still holds 0xFF (what weighted_walk_compact_kernel left to this kernel), fetched when
-// they are met, nothing ahead
-template <bool LOGS, int NV, bool PAIRS, int FETCH = 0, bool LISTED = false>  // NV: 16-byte loads per lane that hold a row (dim <= 256 NV); PAIRS: two chunks of samples walked as one instruction stream
+template <bool LOGS, int NV, bool PAIRS, int FETCH = 0>  // NV: 16-byte loads per lane that hold a row (dim <= 256 NV); PAIRS: two chunks of samples walked as one instruction stream
 __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__restrict__ x, int64_t n_rows, int32_t dim,
                                                                  const WalkPlan *__restrict__ plan, const float4 *__restrict__ walk_a,
                                                                  const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos,
@@ -1536,10 +1512,10 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
                                                   : mn <= 0.0f);                 // a value that is zero (+-0) or negative (its log: NaN)
         // (FETCH bit 0) the refill goes out as soon as the registers are free: two rows per wave are in flight for the whole
         // of the scan and the walk, at the price of the walk's first table load waiting behind it
-        if constexpr ((FETCH & 1) != 0 && !LISTED) fetch(pre, d + 2 * stride);
+        if constexpr ((FETCH & 1) != 0) fetch(pre, d + 2 * stride);
         if (debug == 2) {  // profiling only (results are wrong): rows fetched and staged, nothing else
             if (lane == 0) nonempty[d] = lane_above || lane_odd ? 1 : 0;
-            if constexpr ((FETCH & 1) == 0 && !LISTED) fetch(pre, d + 2 * stride);
+            if constexpr ((FETCH & 1) == 0) fetch(pre, d + 2 * stride);
             return;
         }
         const bool any_above = __any(lane_above), any_odd = __any(lane_odd);
@@ -1604,7 +1580,7 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
         const bool walked = n_stored > 0 && !has_nan && !(by_entry && !listable);
         if (debug == 1) {  // profiling only (results are wrong): staged and scanned, not walked
             if (lane == 0) nonempty[d] = walked ? 1 : 0;
-            if constexpr ((FETCH & 1) == 0 && !LISTED) fetch(pre, d + 2 * stride);
+            if constexpr ((FETCH & 1) == 0) fetch(pre, d + 2 * stride);
             return;
         }
         {
@@ -1655,188 +1631,16 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
         if (lane == 0) nonempty[d] = n_stored > 0 ? 1 : 0;
         // the refill goes out behind the walk (vector loads complete in order: a walk's own table load must not sit out
         // the HBM latency of a row that is not needed for two rows)
-        if constexpr ((FETCH & 1) == 0 && !LISTED) fetch(pre, d + 2 * stride);
+        if constexpr ((FETCH & 1) == 0) fetch(pre, d + 2 * stride);
     };
     float4 pre0[NV], pre1[NV];
     const int64_t d0 = (int64_t)blockIdx.x * n_waves + wave;
-    if constexpr (LISTED) {
-        for (int64_t d = d0; d < n_rows; d += stride) {
-            if (__builtin_amdgcn_readfirstlane((int)nonempty[d]) != 0xFF) continue;  // done by the compact kernel
-            fetch(pre0, d);
-            one_row(pre0, d);
-        }
-        (void)pre1;
-        return;
-    }
     fetch(pre0, d0);
     fetch(pre1, d0 + stride);
     for (int64_t d = d0; d < n_rows; d += 2 * stride) {
         one_row(pre0, d);
         if (d + stride < n_rows) one_row(pre1, d + stride);
     }
-}
-
-// ---- dense rows, one wave per row, only the REACHABLE columns staged (round 5) --------------------------------------------------
-// The kernel above is latency-bound at its occupancy: the row stream (0.26 ms) and the walks' instruction streams (0.12 ms) add up
-// instead of overlapping, with two waves per SIMD -- and what holds the occupancy there is the row itself: 16 KB of LDS per wave to
-// stage it, 2 x 64 VGPRs for the rows fetched ahead.  But a walk only ever looks at the columns at the head of its sample's list:
-// the first kWalkCached positions of the chunks' lists, the same for every row, name ~900 distinct columns of 4096 (config 4).  So
-// here a wave stages only those -- a 4-KB stripe: every entry of the row is written to the slot of its column, the ~3 000 columns
-// nobody can reach all to one spare word, no branch --, reads a column beyond them from the matrix itself, where the row has just
-// been streamed, and keeps one row in registers: sixteen waves per CU instead of eight.  The slot of a column is decided per
-// workgroup at the start (mark the columns of the cached positions, prefix-sum the marks) and rides in the upper half of the cached
-// column words (CompactRow).  Rows this kernel does not take -- an entry that is not a plain stored number (NaN, zero / -inf, a
-// negative value), more entries above the cut than the list holds -- keep 0xFF in nonempty[] and are done by
-// weighted_walk_wave_kernel<..., LISTED> behind it.  Same arithmetic, same helpers (walk_chunks), same (k, t).
-template <bool LOGS, int NV>
-__global__ __launch_bounds__(1024) void weighted_walk_compact_kernel(const float *__restrict__ x, int64_t n_rows, int32_t dim,
-                                                                     const WalkPlan *__restrict__ plan, const float4 *__restrict__ walk_a,
-                                                                     const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos,
-                                                                     int32_t sample_size, int32_t s_pad, int32_t list_cap, int32_t slots_cap,
-                                                                     int32_t rescue_lanes, int64_t *__restrict__ out, uint8_t *__restrict__ nonempty,
-                                                                     unsigned int *__restrict__ left_over) {
-    extern __shared__ float lds[];  // cached list positions of the chunks | slot_of_col u16[dim] | scan scratch u32[32] | per wave: stripe[slots_cap + 1 spare] | list u16[list_cap]
-    const int tid = threadIdx.x, lane = tid & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), n_waves = blockDim.x >> 6;
-    const int32_t chunks = s_pad / kWave;  // (<= kCachedChunks: the launcher sees to it)
-    const int32_t n_cached = (dim < kWalkCached ? dim : kWalkCached) / 4 * 4;
-    float4 *s_cache_a = reinterpret_cast<float4 *>(lds);
-    uint32_t *s_cache_c = reinterpret_cast<uint32_t *>(s_cache_a + chunks * kWalkCached * kWave);
-    uint16_t *slot_of_col = reinterpret_cast<uint16_t *>(s_cache_c + chunks * kWalkCached * kWave);
-    uint32_t *scan_tmp = reinterpret_cast<uint32_t *>(slot_of_col + ((dim + 7) & ~7));
-    float *stripes = reinterpret_cast<float *>(scan_tmp + 32);
-    const int32_t stripe_words = ((slots_cap + 1 + 3) & ~3) + ((list_cap + 1) >> 1);
-    for (int j = tid; j < chunks * kWalkCached * kWave; j += blockDim.x) {
-        const int ch = j / (kWalkCached * kWave), k = j / kWave % kWalkCached;
-        if (k < dim) {
-            s_cache_a[j] = walk_a[((int64_t)ch * dim + k) * kWave + (j & (kWave - 1))];
-            s_cache_c[j] = walk_c[((int64_t)ch * dim + k) * kWave + (j & (kWave - 1))];
-        }
-    }
-    for (int c = tid; c < dim; c += blockDim.x) slot_of_col[c] = 0xFFFFu;
-    __syncthreads();
-    // mark the columns of the cached positions (walk_chunks reads n_cached of them), number the marked ones in column order
-    for (int j = tid; j < chunks * kWalkCached * kWave; j += blockDim.x)
-        if (j / kWave % kWalkCached < n_cached) slot_of_col[s_cache_c[j]] = 0;
-    __syncthreads();
-    {
-        const int per = (dim + (int)blockDim.x - 1) / (int)blockDim.x;
-        uint32_t mine = 0;
-        for (int q = 0; q < per; ++q) {
-            const int c = tid * per + q;
-            if (c < dim && slot_of_col[c] == 0) ++mine;
-        }
-        uint32_t incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, o);
-            if (lane >= o) incl += up;
-        }
-        if (lane == 63) scan_tmp[wave] = incl;
-        __syncthreads();
-        uint32_t at = incl - mine;
-        for (int w = 0; w < wave; ++w) at += scan_tmp[w];
-        for (int q = 0; q < per; ++q) {
-            const int c = tid * per + q;
-            if (c < dim) slot_of_col[c] = slot_of_col[c] == 0 ? (uint16_t)at++ : (uint16_t)slots_cap;  // a column nobody reaches: the spare word
-        }
-    }
-    __syncthreads();
-    for (int j = tid; j < chunks * kWalkCached * kWave; j += blockDim.x)
-        if (j / kWave % kWalkCached < n_cached) {
-            const uint32_t col = s_cache_c[j];
-            s_cache_c[j] = (((uint32_t)slot_of_col[col] + 1u) << 16) | col;
-        }
-    __syncthreads();  // the last barrier of the kernel
-    float *stripe = stripes + (int64_t)wave * stripe_words;
-    uint16_t *list = reinterpret_cast<uint16_t *>(stripe + ((slots_cap + 1 + 3) & ~3));
-    const float lcut = plan->lcut;
-    const float vcut = LOGS ? 0.0f : (lcut >= 88.0f ? __FLT_MAX__ : lcut <= -87.0f ? 0.0f : expf(lcut - 1e-5f * fmaxf(1.0f, fabsf(lcut))));  // (as in the kernel above)
-    const int64_t stride = (int64_t)gridDim.x * n_waves;
-    unsigned int mine_left = 0;
-    for (int64_t d = (int64_t)blockIdx.x * n_waves + wave; d < n_rows; d += stride) {
-        const float *src = x + d * dim;
-        float4 pre[NV];
-#pragma unroll
-        for (int u = 0; u < NV; ++u) {
-            const int c = (u * kWave + lane) * 4;
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            const f4 v = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(src + (c < dim ? c : dim - 4)));
-            pre[u] = make_float4(v.x, v.y, v.z, v.w);
-        }
-        // scan (max / min / sum, as above) + every entry to the slot of its column: nothing is predicated (a lane behind the row's
-        // end holds a copy of the last four entries and writes them where their owner does)
-        float mx = -__builtin_inff(), mn = __builtin_inff(), sum = 0.0f;
-#pragma unroll
-        for (int u = 0; u < NV; ++u) {
-            const int c = (u * kWave + lane) * 4;
-            const float4 v = pre[u];
-            mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fmaxf(v.x, v.y)), __builtin_fmaxf(v.z, v.w));
-            mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fminf(v.x, v.y)), __builtin_fminf(v.z, v.w));
-            sum += (v.x + v.y) + (v.z + v.w);
-            const ushort4 sl = *reinterpret_cast<const ushort4 *>(slot_of_col + (c < dim ? c : dim - 4));
-            stripe[sl.x] = v.x;
-            stripe[sl.y] = v.y;
-            stripe[sl.z] = v.z;
-            stripe[sl.w] = v.w;
-        }
-        const bool lane_above = LOGS ? mx > lcut : mx > vcut;
-        const bool lane_odd = sum != sum || (LOGS ? mn == -__builtin_inff() : mn <= 0.0f);
-        if (__any(lane_odd)) {  // (wave-uniform) not a row of plain stored numbers: the kernel behind this one takes it
-            ++mine_left;
-            continue;
-        }
-        int n_out = 0;
-        if (__any(lane_above)) {  // list the columns above the cut, ascending (rows with outliers only)
-#pragma unroll
-            for (int u = 0; u < NV; ++u) {
-                const int c0 = (u * kWave + lane) * 4;
-                const float l[4] = {pre[u].x, pre[u].y, pre[u].z, pre[u].w};
-                bool is[4];
-                int cnt = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    bool above = c0 < dim && (LOGS ? l[e] > lcut : l[e] > vcut);
-                    if (!LOGS && above) above = np_logf(l[e]) > lcut;  // (only candidates have their log taken)
-                    is[e] = above;
-                    cnt += above ? 1 : 0;
-                }
-                if (!__any(cnt != 0)) continue;
-                int incl = cnt;  // inclusive prefix of cnt over the lanes: lane l's columns 4 l .. 4 l + 3 come before lane l + 1's
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    const int up = __shfl_up(incl, o);
-                    if (lane >= o) incl += up;
-                }
-                int at = n_out + incl - cnt;
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (is[e]) {
-                        if (at < list_cap) list[at] = (uint16_t)(c0 + e);
-                        ++at;
-                    }
-                n_out += __shfl(incl, 63);
-            }
-        }
-        if (n_out > list_cap) {  // more outliers than the list holds: entry by entry, in the kernel behind this one
-            ++mine_left;
-            continue;
-        }
-        const CompactRow row{stripe, src};
-        for (int32_t ch = 0; ch < chunks; ++ch) {
-            Held held[1];
-            walk_chunks<1, !LOGS, CompactRow, 0>(row, list, n_out, false, dim, ch, lane, sample_size, walk_a, walk_c, aos, s_pad, s_cache_a + ch * kWalkCached * kWave,
-                                                 s_cache_c + ch * kWalkCached * kWave, rescue_lanes, held, false);
-            const int32_t my = ch * kWave + lane;
-            if (my < sample_size) {
-                int64_t *o = out + (d * sample_size + my) * 2;
-                o[0] = held[0].c;
-                o[1] = (int64_t)held[0].t;
-            }
-        }
-        if (lane == 0) nonempty[d] = 1;  // (every entry of the row is stored)
-    }
-    if (lane == 0 && mine_left) atomicAdd(left_over, mine_left);
 }
 
 // ---- CSR rows ---------------------------------------------------------------------------------------
@@ -2096,74 +1900,6 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
         const int64_t fit = ((int64_t)ctx->lds_per_block - (int64_t)cache_bytes - 64) / (int64_t)stripe_bytes;
         const int waves = (int)std::min<int64_t>(8, fit);
         const bool shape_ok = (dim & 3) == 0 && (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 && dim >= 1024 && dim <= 4096;
-        // the compact kernel (only the reachable columns staged, sixteen waves per CU) + the LISTED kernel behind it for the rows it
-        // leaves; option weighted.kernel: 0 auto, 3 = always (where the shape allows), 4 = never
-        const int32_t chunks_c = gen->s_pad / kWave;
-        bool compact = shape_ok && waves >= 4 && chunks_c <= kCachedChunks && ctx->opt_weighted_debug == 0 && (ctx->opt_weighted_kernel == MHX_COMPACT_AUTO || ctx->opt_weighted_kernel == 3);
-        if (compact && ctx->opt_weighted_kernel != 3) {
-            if (gen->h_left_over && gen->compact_rows > 0 && (int64_t)gen->h_left_over[0] * 4 > gen->compact_rows) {
-                gen->compact_backoff = 16;  // the last compact call left more than a quarter of its rows over: this data is not for it
-                gen->compact_rows = 0;
-            }
-            if (gen->compact_backoff > 0) {
-                --gen->compact_backoff;
-                compact = false;
-            }
-        }
-        if (compact) {
-            const size_t fixed = (size_t)chunks_c * kWalkCached * kWave * 20 + 2 * (size_t)((dim + 7) & ~7) + 128;
-            const int32_t slots_cap = chunks_c * kWalkCached * kWave;
-            const size_t wave_bytes = 4 * ((size_t)((slots_cap + 1 + 3) & ~3) + (size_t)((list_cap_w + 1) >> 1));
-            const int64_t fit_c = ((int64_t)ctx->lds_per_block - (int64_t)fixed - 64) / (int64_t)wave_bytes;
-            const int waves_c = (int)std::min<int64_t>(16, fit_c);
-            if (waves_c >= 8) {
-                if (!gen->d_left_over) {
-                    if (mhx::dev_malloc(reinterpret_cast<void **>(&gen->d_left_over), 64) != hipSuccess) gen->d_left_over = nullptr;
-                    if (gen->d_left_over && hipHostMalloc(reinterpret_cast<void **>(&gen->h_left_over), 64, hipHostMallocDefault) != hipSuccess) gen->h_left_over = nullptr;
-                    if (gen->h_left_over) gen->h_left_over[0] = 0;
-                }
-                if (gen->d_left_over && gen->h_left_over) {
-                    const size_t lds_c = fixed + wave_bytes * (size_t)waves_c;
-                    const int64_t groups_c = (n_rows + waves_c - 1) / waves_c;
-                    const unsigned blocks_c = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups_c, (int64_t)ctx->num_cus * std::max<int64_t>(1, (int64_t)ctx->lds_per_block / (int64_t)(lds_c + 64))));
-                    const int nv = dim <= 1024 ? 4 : dim <= 2048 ? 8 : 16;
-                    const int32_t rescue_c = ctx->opt_weighted_rescue < 0 ? 0 : ctx->opt_weighted_rescue > 0 ? (int32_t)ctx->opt_weighted_rescue : 8;
-                    MHX_HIP_CHECK(hipMemsetAsync(d_nonempty, 0xFF, (size_t)n_rows, ctx->stream));
-                    MHX_HIP_CHECK(hipMemsetAsync(gen->d_left_over, 0, sizeof(unsigned int), ctx->stream));
-#define MHX_WALK_COMPACT(LOGS, NV_)                                                                                                                 \
-    hipLaunchKernelGGL((weighted_walk_compact_kernel<LOGS, NV_>), dim3(blocks_c), dim3(64 * waves_c), lds_c, ctx->stream, d_x, n_rows, dim, plan, walk_a,   \
-                       gen->d_walk_c, reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, list_cap_w, slots_cap, rescue_c, d_out, \
-                       d_nonempty, gen->d_left_over)
-                    if (values_are_logs) {
-                        if (nv == 4) MHX_WALK_COMPACT(true, 4); else if (nv == 8) MHX_WALK_COMPACT(true, 8); else MHX_WALK_COMPACT(true, 16);
-                    } else {
-                        if (nv == 4) MHX_WALK_COMPACT(false, 4); else if (nv == 8) MHX_WALK_COMPACT(false, 8); else MHX_WALK_COMPACT(false, 16);
-                    }
-#undef MHX_WALK_COMPACT
-                    MHX_HIP_CHECK(hipGetLastError());
-                    // behind it: the rows it left (nonempty[] still 0xFF), by the one-wave-per-row kernel, fetched as they are met
-                    {
-                        const size_t lds = cache_bytes + stripe_bytes * (size_t)waves;
-                        const int64_t groups = (n_rows + waves - 1) / waves;
-                        const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, std::max<int64_t>(1, (int64_t)ctx->lds_per_block / (int64_t)(lds + 64)) * ctx->num_cus));
-#define MHX_WALK_LISTED(LOGS, NV_)                                                                                                                      \
-    hipLaunchKernelGGL((weighted_walk_wave_kernel<LOGS, NV_, false, 0, true>), dim3(blocks), dim3(64 * waves), lds, ctx->stream, d_x, n_rows, dim, plan, walk_a, \
-                       gen->d_walk_c, reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, list_cap_w, direct_permille_w,           \
-                       (int32_t)(stripe_bytes / 4), rescue_c, d_out, d_nonempty, 0)
-                        if (values_are_logs) {
-                            if (nv == 4) MHX_WALK_LISTED(true, 4); else if (nv == 8) MHX_WALK_LISTED(true, 8); else MHX_WALK_LISTED(true, 16);
-                        } else {
-                            if (nv == 4) MHX_WALK_LISTED(false, 4); else if (nv == 8) MHX_WALK_LISTED(false, 8); else MHX_WALK_LISTED(false, 16);
-                        }
-#undef MHX_WALK_LISTED
-                        MHX_HIP_CHECK(hipGetLastError());
-                        MHX_HIP_CHECK(hipMemcpyAsync(gen->h_left_over, gen->d_left_over, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
-                        gen->compact_rows = n_rows;
-                        return MHX_OK;
-                    }
-                }
-            }
-        }
         if (shape_ok && waves >= 4 && ctx->opt_weighted_kernel != 1) {  // (weighted.debug 1 / 2: this kernel's phases alone, profiling)
             const size_t lds = cache_bytes + stripe_bytes * (size_t)waves;
             const int64_t groups = (n_rows + waves - 1) / waves;
