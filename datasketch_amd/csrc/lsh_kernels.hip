@@ -146,21 +146,26 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
         __syncthreads();
         // the element's bin inside the band (top hi + lo digest bits) and inside this source unit (the low lo bits of that)
         const auto gbin_of = [&](uint64_t d) { return tot_bits ? (uint32_t)(d >> (64 - tot_bits)) : 0u; };
+        // All of the thread's loads go out before any of them is waited for: a thread behind the unit's end reads the unit's last
+        // element again (nothing is predicated), and the histogram's LDS atomics come in a loop of their own.  (Until round 5 the
+        // atomic sat next to its load inside `if (row < count)`: the compiler put an s_waitcnt vmcnt(0) between every load and its
+        // atomic -- sixteen memory latencies in a row per chunk, which is what the pass's 24 us per chunk were made of.)
         uint64_t dg[kScatterRows];
         uint32_t rw[kPairs ? kScatterRows : 1];
 #pragma unroll
         for (int j = 0; j < kScatterRows; ++j) {
             const int64_t row = row0 + j * 256 + tid;
-            if (row < count) {
-                if constexpr (kPairs) {
-                    dg[j] = src_dig[src0 + row];
-                    rw[j] = src_row[src0 + row];
-                } else {
-                    dg[j] = band_digest_of<SigT>(sig, row, band, k, r, n);
-                }
-                atomicAdd(&hist[gbin_of(dg[j]) & (nb - 1)], 1u);
+            const int64_t at = row < count ? row : count - 1;  // (count > 0 here)
+            if constexpr (kPairs) {
+                dg[j] = src_dig[src0 + at];
+                rw[j] = src_row[src0 + at];
+            } else {
+                dg[j] = band_digest_of<SigT>(sig, at, band, k, r, n);
             }
         }
+#pragma unroll
+        for (int j = 0; j < kScatterRows; ++j)
+            if (row0 + j * 256 + tid < count) atomicAdd(&hist[gbin_of(dg[j]) & (nb - 1)], 1u);
         __syncthreads();
         // per bin: a range of its slab (one global atomic) and the start of its elements in the team's staging area
         // (exclusive scan of the counts: thread t owns bins [t * per, t * per + per))
@@ -250,7 +255,22 @@ __global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32
         const auto sub_of = [&](uint64_t d) { return (uint32_t)((bin_bits ? d << bin_bits : d) >> (64 - kSubBits)); };
         // the slab is read twice (the second time from the L2): bucket sizes first, then every element to its bucket's range
         // in LDS -- one LDS copy of the bin, three workgroups per CU
-        for (uint32_t i = tid; i < count; i += kSortThreads) atomicAdd(&cnt[sub_of(slab_dig[slab + i])], 1u);
+        // (a thread's loads all go out before the first is waited for -- a thread behind the bin's end reads its last element again --
+        // and the LDS atomics follow in a loop of their own: with the atomic next to its load the compiler waited for every load
+        // in turn, six memory latencies per bin and pass)
+        constexpr int kMine = (kBinCap + kSortThreads - 1) / kSortThreads;
+        const uint32_t last = count ? count - 1 : 0;
+        {
+            uint64_t d[kMine];
+#pragma unroll
+            for (int u = 0; u < kMine; ++u) {
+                const uint32_t i = tid + u * kSortThreads;
+                d[u] = slab_dig[slab + (i < count ? i : last)];
+            }
+#pragma unroll
+            for (int u = 0; u < kMine; ++u)
+                if (tid + u * kSortThreads < count) atomicAdd(&cnt[sub_of(d[u])], 1u);
+        }
         __syncthreads();
         // exclusive scan of the 2048 bucket sizes: a thread's 8 buckets, then the threads' sums
         uint32_t mine[kPer], sum = 0;
@@ -268,12 +288,23 @@ __global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32
             at += mine[j];
         }
         __syncthreads();
-        for (uint32_t i = tid; i < count; i += kSortThreads) {
-            const uint64_t d = slab_dig[slab + i];
-            const uint32_t b = sub_of(d);
-            const uint32_t p = start[b] + atomicAdd(&cnt[b], 1u);
-            dig[p] = d;
-            row[p] = slab_row[slab + i];
+        {
+            uint64_t d[kMine];
+            uint32_t rw[kMine];
+#pragma unroll
+            for (int u = 0; u < kMine; ++u) {
+                const uint32_t i = tid + u * kSortThreads;
+                d[u] = slab_dig[slab + (i < count ? i : last)];
+                rw[u] = slab_row[slab + (i < count ? i : last)];
+            }
+#pragma unroll
+            for (int u = 0; u < kMine; ++u)
+                if (tid + u * kSortThreads < count) {
+                    const uint32_t b = sub_of(d[u]);
+                    const uint32_t p = start[b] + atomicAdd(&cnt[b], 1u);
+                    dig[p] = d[u];
+                    row[p] = rw[u];
+                }
         }
         __syncthreads();
         // every element finds its place inside its bucket by counting the bucket's smaller (digest, row) pairs -- one or two
