@@ -724,6 +724,39 @@ int launch_lsh_candidate_pairs(mhx_ctx *ctx, const uint64_t *d_sorted_digests, c
 }
 
 // the two-pass bucketing; *done = false when a bin overflowed (the caller falls back to the radix sort)
+// [n, bands] digests -> [bands, n] (bands a power of two <= 64): a workgroup takes 2048 consecutive (row, band) pairs -- whole rows,
+// read with unit stride --, parks them in LDS as [band][row of the tile] (one word of padding per band: the lanes of a wave differ
+// in the band first) and writes every band's run of the tile with consecutive lanes.  In front of the bucketing of a ROW-major
+// digest matrix: its scatter pass reads a band with a stride of `bands` words, every 128-byte line fetched by the four XCDs whose
+// bands share it (1.30 GB of reads for 320 MB), and with all of a thread's loads in flight at once that costs more than this pass
+// (0.64 GB of traffic) and the unit-stride bucketing behind it together.
+__global__ __launch_bounds__(256) void digests_to_band_major_kernel(const uint64_t *__restrict__ in, int64_t n, int shift, uint64_t *__restrict__ out) {
+    constexpr int kTile = 2048;
+    __shared__ uint64_t tile[kTile + 64];
+    const int bands = 1 << shift, tr = kTile >> shift;
+    const int64_t total = n << shift;
+    for (int64_t base = (int64_t)blockIdx.x * kTile; base < total; base += (int64_t)gridDim.x * kTile) {
+        uint64_t v[kTile / 256];
+#pragma unroll
+        for (int it = 0; it < kTile / 256; ++it) {
+            const int64_t idx = base + it * 256 + threadIdx.x;
+            v[it] = in[idx < total ? idx : total - 1];
+        }
+#pragma unroll
+        for (int it = 0; it < kTile / 256; ++it) {
+            const int local = it * 256 + threadIdx.x;
+            tile[(local & (bands - 1)) * (tr + 1) + (local >> shift)] = v[it];
+        }
+        __syncthreads();
+        const int64_t row0 = base >> shift;
+        for (int e = threadIdx.x; e < kTile; e += 256) {
+            const int band = e / tr, row = e - band * tr;
+            if (row0 + row < n) out[(int64_t)band * n + row0 + row] = tile[band * (tr + 1) + row];
+        }
+        __syncthreads();
+    }
+}
+
 // one scatter pass (see lsh_bin_scatter_kernel); returns false when the launch is refused
 static size_t scatter_team_bytes(int lo_bits, bool pairs, int rows) {
     const size_t nb = (size_t)1 << lo_bits, chunk = 256 * (size_t)rows;
@@ -836,7 +869,17 @@ int launch_lsh_sort_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_
     if (n >= ((int64_t)1 << 32)) return fail(MHX_ERR_UNSUPPORTED, "more than 2^32-1 signatures per call");
     if (ctx->opt_lsh_sort != 1 && ctx->opt_lsh_sort_bits == 0 && ctx->opt_lsh_gather == 0 && n > 0) {  // the options of the radix path select it
         bool done = false;
-        if (int rc = launch_lsh_bucket_bands(ctx, d_sig, sig_dtype, n, k, bands, r, d_sorted_digests, d_sorted_rows, &done)) return rc;
+        const void *d_in = d_sig;
+        int in_dtype = sig_dtype;
+        if (sig_dtype == kSigDigests && bands >= 2 && bands <= 64 && (bands & (bands - 1)) == 0 &&
+            ctx->ensure_scratch(4, sizeof(uint64_t) * (size_t)n * (size_t)bands) == MHX_OK) {
+            // a row-major digest matrix is turned band-major first (see digests_to_band_major_kernel)
+            const int64_t tiles = (n * bands + 2047) / 2048;
+            hipLaunchKernelGGL(digests_to_band_major_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)ctx->num_cus * 16))), dim3(256), 0, ctx->stream,
+                               (const uint64_t *)d_sig, n, __builtin_ctz((unsigned)bands), (uint64_t *)ctx->scratch[4]);
+            if (hipGetLastError() == hipSuccess) d_in = ctx->scratch[4], in_dtype = kSigDigestsBM;
+        }
+        if (int rc = launch_lsh_bucket_bands(ctx, d_in, in_dtype, n, k, bands, r, d_sorted_digests, d_sorted_rows, &done)) return rc;
         if (done) return MHX_OK;
     }
     // scratch[3]: digests[n, bands] | keys u64[total] | sorted keys u64[total] | rows u32[total] | marks u8[total] |
