@@ -225,32 +225,45 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
 
 __device__ __forceinline__ bool pair_less(uint64_t da, uint32_t ra, uint64_t db, uint32_t rb) { return da < db || (da == db && ra < rb); }
 
-__global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32_t *__restrict__ cursor, const uint64_t *__restrict__ slab_dig,
-                                                           const uint32_t *__restrict__ slab_row, int64_t n, int32_t bands, int bin_bits,
-                                                           uint64_t *__restrict__ out_dig, uint32_t *__restrict__ out_row) {
+// where every bin's elements go in the output: the sizes of the band's bins before it (one workgroup per band; a bin holds at
+// most kBinCap elements).  Computed once here: lsh_bin_sort_kernel used to sum the band's cursors in every workgroup -- a loop of
+// dependent loads (eight L2 round trips per thread at 4096 bins) and a 512-thread tree reduction, nine barriers per bin.
+__global__ __launch_bounds__(256) void lsh_bin_offsets_kernel(const uint32_t *__restrict__ cursor, int bin_bits, uint32_t *__restrict__ bin_start) {
+    __shared__ uint32_t scan_tmp[4];
+    const int nb = 1 << bin_bits, tid = threadIdx.x;
+    const uint32_t *cur = cursor + (int64_t)blockIdx.x * nb;
+    uint32_t *dst = bin_start + (int64_t)blockIdx.x * nb;
+    const int per = (nb + 255) / 256;
+    uint32_t sum = 0;
+    for (int j = 0; j < per; ++j) {
+        const int t = tid * per + j;
+        if (t < nb) sum += min(cur[t], (uint32_t)kBinCap);
+    }
+    uint32_t at = block_inclusive_scan(sum, scan_tmp, tid) - sum;
+    for (int j = 0; j < per; ++j) {
+        const int t = tid * per + j;
+        if (t < nb) {
+            dst[t] = at;
+            at += min(cur[t], (uint32_t)kBinCap);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ bin_start,
+                                                           const uint64_t *__restrict__ slab_dig, const uint32_t *__restrict__ slab_row, int64_t n,
+                                                           int32_t bands, int bin_bits, uint64_t *__restrict__ out_dig, uint32_t *__restrict__ out_row) {
     __shared__ uint64_t dig[kBinCap];
     __shared__ uint32_t row[kBinCap];
     __shared__ uint32_t cnt[1 << kSubBits], start[1 << kSubBits];
-    __shared__ uint32_t part[kSortThreads];
     __shared__ uint32_t scan_tmp[kSortThreads / 64];
     const int nb = 1 << bin_bits, tid = threadIdx.x;
     constexpr int kSub = 1 << kSubBits, kPer = kSub / kSortThreads;
     for (int64_t item = blockIdx.x; item < (int64_t)bands * nb; item += gridDim.x) {
         const int64_t band = item >> bin_bits;
-        const int bin = (int)(item & (nb - 1));
-        const uint32_t *cur = cursor + band * nb;
-        const uint32_t count = min(cur[bin], (uint32_t)kBinCap);
-        // where the bin goes: behind the band's bins before it
-        uint32_t before = 0;
-        for (int t = tid; t < bin; t += kSortThreads) before += min(cur[t], (uint32_t)kBinCap);
-        part[tid] = before;
+        const uint32_t count = min(cursor[item], (uint32_t)kBinCap);
+        const int64_t out_base = band * n + bin_start[item];  // behind the band's bins before it (lsh_bin_offsets_kernel)
         for (int t = tid; t < kSub; t += kSortThreads) cnt[t] = 0;
         __syncthreads();
-        for (int o = kSortThreads / 2; o > 0; o >>= 1) {
-            if (tid < o) part[tid] += part[tid + o];
-            __syncthreads();
-        }
-        const int64_t out_base = band * n + part[0];
         const int64_t slab = item * kBinCap;
         const auto sub_of = [&](uint64_t d) { return (uint32_t)((bin_bits ? d << bin_bits : d) >> (64 - kSubBits)); };
         // the slab is read twice (the second time from the L2): bucket sizes first, then every element to its bucket's range
@@ -808,7 +821,7 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     const int64_t nb = (int64_t)1 << bin_bits, bins = nb * bands;
     const int64_t big_bins = hi_bits ? ((int64_t)bands << hi_bits) : 0;
     const uint32_t cap0 = hi_bits ? (uint32_t)std::min<int64_t>(0xFFFFFFFFll, (n >> hi_bits) + (n >> hi_bits) / 32 + 4096) : 0;  // 3 % + 4096 over the mean (sigma = sqrt(mean))
-    const size_t cur_bytes = ((sizeof(uint32_t) * (size_t)(bins + big_bins + 2)) + 255) & ~(size_t)255;  // cursor[bins] | overflow | cursor0[big_bins] | overflow0
+    const size_t cur_bytes = ((sizeof(uint32_t) * (size_t)(2 * bins + big_bins + 2)) + 255) & ~(size_t)255;  // cursor[bins] | overflow | cursor0[big_bins] | overflow0 | bin_start[bins]
     const size_t dig_bytes = sizeof(uint64_t) * (size_t)bins * kBinCap, row_bytes = sizeof(uint32_t) * (size_t)bins * kBinCap;
     const size_t dig0_bytes = ((sizeof(uint64_t) * (size_t)big_bins * cap0) + 255) & ~(size_t)255, row0_bytes = ((sizeof(uint32_t) * (size_t)big_bins * cap0) + 255) & ~(size_t)255;
     if (cur_bytes + dig_bytes + row_bytes + dig0_bytes + row0_bytes > (size_t)ctx->hbm_bytes / 4) return MHX_OK;
@@ -829,6 +842,7 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     uint32_t *d_overflow = d_cursor + bins;
     uint32_t *d_cursor0 = d_overflow + 1;
     uint32_t *d_overflow0 = d_cursor0 + big_bins;
+    uint32_t *d_bin_start = d_overflow0 + 1;
     uint64_t *d_slab_dig = (uint64_t *)(base + cur_bytes);
     uint32_t *d_slab_row = (uint32_t *)(base + cur_bytes + dig_bytes);
     uint64_t *d_slab0_dig = (uint64_t *)(base + cur_bytes + dig_bytes + row_bytes);
@@ -857,8 +871,9 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     if (hi_bits) MHX_HIP_CHECK(hipMemcpyAsync(&overflow[1], d_overflow0, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (overflow[0] || overflow[1]) return MHX_OK;
+    hipLaunchKernelGGL(lsh_bin_offsets_kernel, dim3((unsigned)bands), dim3(256), 0, ctx->stream, d_cursor, bin_bits, d_bin_start);
     hipLaunchKernelGGL(lsh_bin_sort_kernel, dim3((unsigned)std::min<int64_t>(bins, (int64_t)ctx->num_cus * 96)), dim3(kSortThreads), 0, ctx->stream, d_cursor,
-                       d_slab_dig, d_slab_row, n, bands, bin_bits, d_sorted_digests, d_sorted_rows);
+                       d_bin_start, d_slab_dig, d_slab_row, n, bands, bin_bits, d_sorted_digests, d_sorted_rows);
     MHX_HIP_CHECK(hipGetLastError());
     *done = true;
     return MHX_OK;
