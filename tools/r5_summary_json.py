@@ -14,8 +14,9 @@ from collections import defaultdict
 
 N, BANDS, K = 1_250_000, 32, 256
 ALG = {  # algorithmic bytes per launch (SURVEY.md section 8d / BASELINE.md section 4)
-    "lsh_bin_scatter_kernel<Digest64BM>": N * BANDS * (8 + 12),   # digest in, (digest, row) out
-    "lsh_bin_scatter_kernel<Digest64>": N * BANDS * (8 + 12),
+    "lsh_bin_scatter_kernel<Digest64BM": N * BANDS * (8 + 12),   # digest in, (digest, row) out
+    "lsh_bin_scatter_kernel<Digest64,": N * BANDS * (8 + 12),
+    "digests_to_band_major_kernel": N * BANDS * 16,
     "lsh_bin_sort_kernel": N * BANDS * (12 + 12),                 # (digest, row) in and out
     "bbit_digest_fused_kernel": N * (4 * K + K // 8 + 8 * BANDS),
     "band_digest_kernel": N * (4 * K + 8 * BANDS),
