@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -38,10 +39,13 @@ Rccl &rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+        // MHX_RCCL_LIBRARY: another library with RCCL's entry points (tests: tests/fake_rccl.c, which lets ranks share a device)
+        const char *override_path = getenv("MHX_RCCL_LIBRARY");
+        const char *names[] = {override_path && *override_path ? override_path : "librccl.so", "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
         for (const char *n : names) {
             r.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (r.handle) break;
+            if (override_path && *override_path) break;  // (an override that does not load is an error, not a reason to take the real one)
         }
         if (!r.handle) {
             r.error = std::string("cannot load librccl.so: ") + dlerror();

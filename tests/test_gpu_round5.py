@@ -216,6 +216,42 @@ def test_sharded_chain_with_ranks_sharing_one_gpu(ctx, tmp_path, world, scheme):
     assert np.array_equal(MinHash.bulk_signatures(tokens, num_perm=k, seed=3, hashfunc=prehashed, gpu_mode="always"), want)
 
 
+@pytest.fixture(scope="module")
+def fake_rccl(tmp_path_factory):
+    """tests/fake_rccl.c built next to the test run: RCCL's entry points for ranks that share one device (see its header)."""
+    out = str(tmp_path_factory.mktemp("fake_rccl") / "libfake_rccl.so")
+    p = subprocess.run(["/opt/rocm/bin/hipcc", "-x", "c", "-shared", "-fPIC", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                        os.path.join(ROOT, "tests", "fake_rccl.c"), "-o", out, "-L/opt/rocm/lib", "-lamdhip64"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    return out
+
+
+@pytest.mark.parametrize("world,scheme", [(2, "equal"), (8, "unequal")])
+def test_rccl_binding_with_world_above_one_through_the_stand_in_library(ctx, tmp_path, fake_rccl, monkeypatch, world, scheme):
+    """libmhx's RCCL binding (csrc/comm.hip) with world > 1 on one GPU: MHX_RCCL_LIBRARY points the dlopen at the stand-in, so
+    ncclCommInitRank / ncclAllGather (equal shards) and the grouped per-root ncclBroadcasts of mhx_comm_allgatherv_dev
+    (unequal shards, each written at its final offset) run for real from `world` processes.  What this pins is our marshalling
+    (unique-id exchange over the rendezvous, byte counts, offsets, group bracketing); RCCL itself is not in the picture."""
+    import rank_c3
+
+    monkeypatch.setenv("MHX_RCCL_LIBRARY", fake_rccl)
+    n, t, k, bands, r = 24_000, 64, 128, 16, 8
+    recs, arrays = _run_ranks(world, n, t, k, bands, r, scheme, tmp_path, transport="rccl")
+    assert all(rec["transport"] == "rccl" for rec in recs) and all(rec["sha"] == recs[0]["sha"] for rec in recs)
+    a, b = O.np_init_permutations(k, 3)
+    want = O.c_minhash_bulk_dense(rank_c3.corpus(n, t), a, b)
+    assert np.array_equal(arrays["sig"].astype(np.uint64), want)
+    assert np.array_equal(arrays["blocks"], O.c_bbit_pack(want, 1))
+
+
+def test_an_override_library_that_does_not_load_is_an_error(ctx):
+    """MHX_RCCL_LIBRARY naming a file that is not there does not fall back to the installed librccl.so."""
+    body = "import sys; sys.path.insert(0, %r); from datasketch_amd import _native\n" \
+           "try:\n    _native.Communicator.unique_id(); print('LOADED')\nexcept Exception as e:\n    print('REFUSED', e)" % ROOT
+    p = subprocess.run([sys.executable, "-c", body], env=dict(os.environ, MHX_RCCL_LIBRARY="/nonexistent/librccl.so"), capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "REFUSED" in p.stdout and "LOADED" not in p.stdout, p.stdout + p.stderr
+
+
 def test_host_transport_over_sockets_with_two_ranks(ctx, tmp_path, monkeypatch):
     """The same chain when the ranks do not share /dev/shm files (forced here): the shards travel through the rendezvous
     sockets in bounded pieces."""
