@@ -279,6 +279,8 @@ def main():
             "signature_dtype": "uint32" if args.u32 else "uint64",
             "parallelism": f"shard{world}" + ("+allgather" if gather is not None else ""),
             "allgather_transport": transport if world > 1 else None,
+            # (a library other than librccl.so behind the "rccl" transport -- tests/fake_rccl.c in the test suite -- is named, never silent)
+            **({"rccl_library_override": os.environ["MHX_RCCL_LIBRARY"]} if os.environ.get("MHX_RCCL_LIBRARY") else {}),
             "launcher": "torch.distributed.run env" if "TORCHELASTIC_RUN_ID" in os.environ else ("self-spawned ranks" if world > 1 else "single process"),
             "rendezvous": "datasketch_amd.rendezvous (TCP, no PyTorch)",
             "parity_rows_checked": int(check),
