@@ -870,7 +870,7 @@ template <bool VALS = false>
 __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list, int n_list, bool all_listed, int32_t dim, int32_t ch,
                                          int32_t my, int32_t sample_size, const float4 *__restrict__ walk_a,
                                          const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos, int32_t s_pad,
-                                         const float4 *cache_a, const uint32_t *cache_c, int32_t part, int32_t parts, bool staged = false) {
+                                         const float4 *cache_a, const uint32_t *cache_c, int32_t part, int32_t parts, bool staged = false, int32_t cached = kWalkCached) {
     Held held;
     int j = (int)((int64_t)n_list * part / parts);
     n_list = (int)((int64_t)n_list * (part + 1) / parts);
@@ -903,7 +903,7 @@ __device__ __forceinline__ Held walk_row(const float *row, const uint16_t *list,
         // the first positions of the lists are the same for every row: this workgroup keeps them in LDS (a load from the
         // L2 behind the rows' stream takes microseconds; most walks end inside the cached positions)
         constexpr int kU = 4;  // positions per round: evaluated side by side (independent division chains), then taken in order
-        const int32_t n_cached = cache_a ? (dim < kWalkCached ? dim : kWalkCached) / kU * kU : 0;
+        const int32_t n_cached = cache_a ? (dim < cached ? dim : cached) / kU * kU : 0;
         for (; k < n_cached; k += kU) {
             float4 e[kU];
             uint32_t c[kU];
@@ -1051,11 +1051,15 @@ __device__ __forceinline__ void walk_rescue(const float *row, int32_t dim, int32
 // still walks or not (a finished lane's are dropped), so a finished lane can at most cause the exact re-evaluation of a
 // round, never a different value.  The chunks ch0 .. ch0 + NC - 1 all have their first positions cached (cache_a /
 // cache_c: chunk ch0's, the others' behind it).
+#ifndef MHX_WALK_KU1
+#define MHX_WALK_KU1 4  // positions per round when one chunk is walked alone (A/B builds)
+#endif
 template <int NC, bool VALS = false>
 __device__ __forceinline__ void walk_chunks(const float *row, const uint16_t *list, int n_list, bool all_listed, int32_t dim, int32_t ch0,
                                             int lane, int32_t sample_size, const float4 *__restrict__ walk_a,
                                             const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos, int32_t s_pad,
-                                            const float4 *cache_a, const uint32_t *cache_c, int32_t rescue_lanes, Held (&held)[NC], bool staged = false) {
+                                            const float4 *cache_a, const uint32_t *cache_c, int32_t rescue_lanes, Held (&held)[NC], bool staged = false,
+                                            int32_t cached = kWalkCached) {  // (cached: list positions per chunk in cache_a / cache_c; NC = 1 only may differ from kWalkCached)
     int32_t my[NC];
 #pragma unroll
     for (int i = 0; i < NC; ++i) my[i] = (ch0 + i) * kWave + lane;
@@ -1106,8 +1110,8 @@ __device__ __forceinline__ void walk_chunks(const float *row, const uint16_t *li
         for (int i = 0; i < NC; ++i) w |= !done[i];
         return __any(w);
     };
-    constexpr int kU = 4;
-    const int32_t n_cached = (dim < kWalkCached ? dim : kWalkCached) / kU * kU;
+    constexpr int kU = NC == 1 ? MHX_WALK_KU1 : 4;
+    const int32_t n_cached = (dim < cached ? dim : cached) / kU * kU;
     int32_t k = 0;
     for (; k < n_cached; k += kU) {
         float4 e[NC][kU];
@@ -1436,29 +1440,48 @@ __global__ __launch_bounds__(256, 4) void weighted_walk_dense_kernel(const float
 // Same arithmetic, same rules, same helper (walk_row) as the kernel above; rows it does not take (dim > 4096 or not a
 // multiple of 4, fewer than two stripes fitting the LDS) stay with that kernel.
 // FETCH (A/B, option weighted.refill): bit 0 = the next row's loads go out right after staging instead of behind the walk, bit 1 = non-temporal loads
-template <bool LOGS, int NV, bool PAIRS, int FETCH = 0>  // NV: 16-byte loads per lane that hold a row (dim <= 256 NV); PAIRS: two chunks of samples walked as one instruction stream
-__global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__restrict__ x, int64_t n_rows, int32_t dim,
+// SPLIT (round 5): the waves of a workgroup come in pairs that share a stripe -- a FETCHER that streams rows from HBM through its
+// registers into the stripe and a WALKER that scans and walks them.  Vector loads of one wave complete in order, so a wave that does
+// both either has no row in flight while it walks or has its walk's table loads (L2 hits) queue behind a row's HBM latency: measured,
+// a row cost its wave the latency of a row PLUS the walk (5.6 + 2.7 us).  Two waves have two load queues: the fetcher's next row is
+// in flight for the whole of the walker's walk.  The pair hands the stripe back and forth through one LDS word (0: the fetcher's,
+// 1: the walker's), release / acquire at workgroup scope; a wait that outlasts kSpinLimit polls traps (a protocol error is loud).
+constexpr int kSplitHandWords = 32;        // SPLIT 1: four words per pair of waves, eight pairs
+constexpr int kHandWords = 8;              // SPLIT 2: per stripe {ready, done[0], done[1], scanned, what the fetcher found, n_stored, n_list, flags}
+constexpr int kSplitHandWords2 = 64;       // ... eight stripes at most
+constexpr uint32_t kSpinLimit = 1u << 24;  // polls (each ~100 cycles) a wave waits for its partner before it traps
+template <bool LOGS, int NV, bool PAIRS, int FETCH = 0, int SPLIT = 0>  // NV: 16-byte loads per lane that hold a row (dim <= 256 NV); PAIRS: two chunks of samples walked as one instruction stream
+__global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_kernel(const float *__restrict__ x, int64_t n_rows, int32_t dim,
                                                                  const WalkPlan *__restrict__ plan, const float4 *__restrict__ walk_a,
                                                                  const uint32_t *__restrict__ walk_c, const float4 *__restrict__ aos,
                                                                  int32_t sample_size, int32_t s_pad, int32_t list_cap, int32_t direct_permille,
                                                                  int32_t stripe_words, int32_t rescue_lanes, int64_t *__restrict__ out,
-                                                                 uint8_t *__restrict__ nonempty, int32_t debug) {
+                                                                 uint8_t *__restrict__ nonempty, int32_t debug, int32_t split_stripes) {
     extern __shared__ float lds[];  // cached list positions of the first n_cc chunks | per wave: row[dim] | list[list_cap] u16
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), n_waves = blockDim.x >> 6;
     const int32_t chunks = s_pad / kWave;
     const int32_t n_cc = chunks < kCachedChunks ? chunks : kCachedChunks;
+    const int32_t wcached = SPLIT == 2 ? split_stripes >> 8 & 255 : kWalkCached;
+    const bool split_rescue = (split_stripes >> 16 & 1) != 0;  // (A/B)  // list positions per chunk kept in LDS (SPLIT 2: the launcher's choice)
     float4 *s_cache_a = reinterpret_cast<float4 *>(lds);
-    uint32_t *s_cache_c = reinterpret_cast<uint32_t *>(s_cache_a + n_cc * kWalkCached * kWave);
-    for (int j = tid; j < n_cc * kWalkCached * kWave; j += blockDim.x) {
-        const int ch = j / (kWalkCached * kWave), k = j / kWave % kWalkCached;
+    uint32_t *s_cache_c = reinterpret_cast<uint32_t *>(s_cache_a + n_cc * wcached * kWave);
+    for (int j = tid; j < n_cc * wcached * kWave; j += blockDim.x) {
+        const int ch = j / (wcached * kWave), k = j / kWave % wcached;
         if (ch < chunks && k < dim) {
             s_cache_a[j] = walk_a[((int64_t)ch * dim + k) * kWave + (j & (kWave - 1))];
             s_cache_c[j] = walk_c[((int64_t)ch * dim + k) * kWave + (j & (kWave - 1))];
         }
     }
+    // SPLIT: wave w < n_pairs walks what wave w + n_pairs fetches (waves go round the four SIMDs: each gets walkers and fetchers alike)
+    const int n_pairs = SPLIT == 1 ? n_waves >> 1 : n_waves;
+    const bool fetcher = SPLIT == 1 && wave >= n_pairs;
+    const int pair = fetcher ? wave - n_pairs : wave;
+    uint32_t *s_hand = reinterpret_cast<uint32_t *>(lds + 5 * n_cc * wcached * kWave) + pair * 4;  // SPLIT: {whose turn, above the cut?, odd?, -}
+    if (SPLIT == 1 && tid < n_pairs * 4) reinterpret_cast<uint32_t *>(lds + 5 * n_cc * wcached * kWave)[tid] = 0;
+    if (SPLIT == 2 && tid < kSplitHandWords2) reinterpret_cast<uint32_t *>(lds + 5 * n_cc * wcached * kWave)[tid] = 0;
     __syncthreads();  // the only barrier of the kernel
-    float *row = lds + 5 * n_cc * kWalkCached * kWave + (int64_t)wave * stripe_words;
+    float *row = lds + 5 * n_cc * wcached * kWave + (SPLIT == 1 ? kSplitHandWords : 0) + (int64_t)pair * stripe_words;
     uint16_t *list = reinterpret_cast<uint16_t *>(row + ((dim + 3) & ~3));
     const float lcut = plan->lcut;
     // values in (LOGS = false): the stripe holds the VALUES and the log is taken of the entries a walk meets (row_log<true>), not
@@ -1467,7 +1490,7 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
     // log taken and compared
     // (below exp(-87) the values are denormal and a rounded exp is no bound: there every positive value has its log taken)
     const float vcut = LOGS ? 0.0f : (lcut >= 88.0f ? __FLT_MAX__ : lcut <= -87.0f ? 0.0f : expf(lcut - 1e-5f * fmaxf(1.0f, fabsf(lcut))));
-    const int64_t stride = (int64_t)gridDim.x * n_waves;
+    const int64_t stride = (int64_t)gridDim.x * n_pairs;
     // every lane always issues exactly NV loads per row (clamped to the matrix and to the row), so that the number of loads
     // in flight behind a row's is known at compile time and the wait for a row is not a wait for the one behind it
     const auto fetch = [&](float4 (&pre)[NV], int64_t d) {
@@ -1484,7 +1507,7 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
             }
         }
     };
-    const auto one_row = [&](float4 (&pre)[NV], int64_t d) {
+    const auto stage = [&](float4 (&pre)[NV], bool &lane_above, bool &lane_odd) {
         // stage + scan: the row's logs into the stripe (-inf: not stored).  What the scan looks for is rare, so it is kept
         // on the scalar unit: a lane's "seen one" flags are lane masks in scalar registers, OR-ed per element (s_or_b64; 128
         // explicit ballots instead made the compiler keep every mask alive: 440 spilled SGPRs), and only a row that has an
@@ -1507,18 +1530,16 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
             sum += (v.x + v.y) + (v.z + v.w);
             *reinterpret_cast<float4 *>(row + (c < dim ? c : dim - 4)) = v;
         }
-        const bool lane_above = LOGS ? mx > lcut : mx > vcut;                    // (+inf too; values: candidates, their logs are taken below)
-        const bool lane_odd = sum != sum || (LOGS ? mn == -__builtin_inff()      // a NaN, or an entry that is not stored: log -inf,
-                                                  : mn <= 0.0f);                 // a value that is zero (+-0) or negative (its log: NaN)
-        // (FETCH bit 0) the refill goes out as soon as the registers are free: two rows per wave are in flight for the whole
-        // of the scan and the walk, at the price of the walk's first table load waiting behind it
-        if constexpr ((FETCH & 1) != 0) fetch(pre, d + 2 * stride);
-        if (debug == 2) {  // profiling only (results are wrong): rows fetched and staged, nothing else
-            if (lane == 0) nonempty[d] = lane_above || lane_odd ? 1 : 0;
-            if constexpr ((FETCH & 1) == 0) fetch(pre, d + 2 * stride);
-            return;
-        }
-        const bool any_above = __any(lane_above), any_odd = __any(lane_odd);
+        lane_above = LOGS ? mx > lcut : mx > vcut;                               // (+inf too; values: candidates, their logs are taken below)
+        lane_odd = sum != sum || (LOGS ? mn == -__builtin_inff()                 // a NaN, or an entry that is not stored: log -inf,
+                                       : mn <= 0.0f);                            // a value that is zero (+-0) or negative (its log: NaN)
+    };
+    // everything behind the staging: what the scan found is looked at again from LDS, the lists are built, the chunks of samples walked
+    struct Scanned {
+        int n_stored, n_list;
+        bool has_nan, by_entry, listable, logs_staged;
+    };
+    const auto scan = [&](bool any_above, bool any_odd) -> Scanned {
         int n_stored = dim, n_out = 0;
         bool has_nan = false;
         if (any_odd) {  // (wave-uniform) count what is stored, look for NaNs
@@ -1577,19 +1598,20 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
             }
             n_list = n_stored;
         }
+        return Scanned{n_stored, n_list, has_nan, by_entry, listable, logs_staged};
+    };
+    // the chunks [ch_begin, ch_end) of samples of a scanned row
+    const auto walk = [&](int64_t d, const Scanned &sc, int32_t ch_begin, int32_t ch_end) {
+        const int n_stored = sc.n_stored, n_list = sc.n_list;
+        const bool has_nan = sc.has_nan, by_entry = sc.by_entry, listable = sc.listable, logs_staged = sc.logs_staged;
         const bool walked = n_stored > 0 && !has_nan && !(by_entry && !listable);
-        if (debug == 1) {  // profiling only (results are wrong): staged and scanned, not walked
-            if (lane == 0) nonempty[d] = walked ? 1 : 0;
-            if constexpr ((FETCH & 1) == 0) fetch(pre, d + 2 * stride);
-            return;
-        }
         {
             constexpr bool VALS = !LOGS;  // (values in: the stripe holds values unless this row's logs were taken in place: logs_staged)
-            for (int32_t ch = 0; ch < chunks; ++ch) {
-                if (PAIRS && walked && ch + 1 < n_cc) {  // (wave-uniform) two chunks of samples as one instruction stream
+            for (int32_t ch = ch_begin; ch < ch_end; ++ch) {
+                if (PAIRS && walked && ch + 1 < n_cc && ch + 1 < ch_end) {  // (wave-uniform) two chunks of samples as one instruction stream
                     Held held[2];
                     walk_chunks<2, VALS>(row, list, n_list, by_entry, dim, ch, lane, sample_size, walk_a, walk_c, aos, s_pad,
-                                         s_cache_a + ch * kWalkCached * kWave, s_cache_c + ch * kWalkCached * kWave, rescue_lanes, held, logs_staged);
+                                         s_cache_a + ch * wcached * kWave, s_cache_c + ch * wcached * kWave, rescue_lanes, held, logs_staged);
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const int32_t my = (ch + i) * kWave + lane;
@@ -1600,6 +1622,18 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
                         }
                     }
                     ++ch;
+                    continue;
+                }
+                if (SPLIT == 2 && split_rescue && walked && ch < n_cc) {  // one chunk, through the same stream as the pairs: the tail of a heavy-tailed row by the whole wave (walk_rescue)
+                    Held held[1];
+                    walk_chunks<1, VALS>(row, list, n_list, by_entry, dim, ch, lane, sample_size, walk_a, walk_c, aos, s_pad,
+                                         s_cache_a + ch * wcached * kWave, s_cache_c + ch * wcached * kWave, rescue_lanes, held, logs_staged, wcached);
+                    const int32_t my1 = ch * kWave + lane;
+                    if (my1 < sample_size) {
+                        int64_t *o = out + (d * sample_size + my1) * 2;
+                        o[0] = held[0].c;
+                        o[1] = (int64_t)held[0].t;
+                    }
                     continue;
                 }
                 const int32_t my = ch * kWave + lane;
@@ -1617,8 +1651,8 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
                     k_out = held.c, t_out = (int64_t)held.t;
                 } else {
                     const Held held = walk_row<VALS>(row, list, n_list, by_entry, dim, ch, my, sample_size, walk_a, walk_c, aos, s_pad,
-                                                     ch < n_cc ? s_cache_a + ch * kWalkCached * kWave : nullptr,
-                                                     ch < n_cc ? s_cache_c + ch * kWalkCached * kWave : nullptr, 0, 1, logs_staged);
+                                                     ch < n_cc ? s_cache_a + ch * wcached * kWave : nullptr,
+                                                     ch < n_cc ? s_cache_c + ch * wcached * kWave : nullptr, 0, 1, logs_staged, wcached);
                     k_out = held.c, t_out = (int64_t)held.t;
                 }
                 if (my < sample_size) {
@@ -1628,7 +1662,155 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
                 }
             }
         }
-        if (lane == 0) nonempty[d] = n_stored > 0 ? 1 : 0;
+    };
+    // (scan and walk are called where they are needed, not through a third lambda: a closure that captures closures has its captures
+    // materialised in scratch memory -- 504 bytes of it and a kernel 3.5 x slower, measured)
+#define MHX_SCAN_AND_WALK(d_, above_, odd_)                                                                   \
+    do {                                                                                                      \
+        const Scanned sc_ = scan(above_, odd_);                                                               \
+        if (debug != 1) walk(d_, sc_, 0, chunks); /* (debug 1, profiling only: staged and scanned, not walked) */ \
+        if (lane == 0) nonempty[d_] = sc_.n_stored > 0 ? 1 : 0;                                               \
+    } while (0)
+    if constexpr (SPLIT == 2) {
+        // Stripes with TWO walkers each (one per chunk of 64 samples; s_pad = 128) and a few fetchers that deposit rows into whichever
+        // stripe is next: n_stripes stripes, 2 n_stripes walkers, the remaining waves fetch.  The workgroup's i-th row goes to stripe
+        // i % n_stripes as that stripe's (i / n_stripes)-th row and is fetched by fetcher i % n_fetch.  Every hand-over is a counter
+        // with one writer: ready (the fetcher that deposited the stripe's k-th row stores k + 1), done[c] (walker c stores k + 1 when
+        // it has finished it), scanned (walker 0, only for rows the scan has to look at again).  A deposit waits for both walkers to
+        // be done with the row before; rows only ever wait for rows with a smaller i, so nobody waits in a circle.
+        const int n_stripes = split_stripes & 255, n_walk = 2 * n_stripes, n_fetch = n_waves - n_walk;
+        uint32_t *hands = reinterpret_cast<uint32_t *>(lds + 5 * n_cc * wcached * kWave);
+        const auto wait_at_least = [&](uint32_t *word, uint32_t want) {
+            for (uint32_t polls = 0; __hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want; ++polls) {
+                if (polls > kSpinLimit) __builtin_trap();
+                __builtin_amdgcn_s_sleep(2);
+            }
+        };
+        const auto post = [&](uint32_t *word, uint32_t value) { __hip_atomic_store(word, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); };
+        const int64_t gstride = gridDim.x;
+        const int64_t my_rows = n_rows > blockIdx.x ? (n_rows - blockIdx.x + gstride - 1) / gstride : 0;  // rows blockIdx.x + i * gridDim.x
+        float *stripes = lds + 5 * n_cc * wcached * kWave + kSplitHandWords2;
+        if (wave >= n_walk) {
+            const int f = wave - n_walk;
+            float4 pre[NV];
+            if (f < my_rows) fetch(pre, blockIdx.x + (int64_t)f * gstride);
+            for (int64_t i = f; i < my_rows; i += n_fetch) {
+                const int st = (int)(i % n_stripes);
+                const uint32_t k = (uint32_t)(i / n_stripes);
+                uint32_t *hand = hands + st * kHandWords;
+                float *dst = stripes + (int64_t)st * stripe_words;
+                float mx = -__builtin_inff(), mn = __builtin_inff(), sum = 0.0f;
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const float4 v = pre[u];
+                    mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fmaxf(v.x, v.y)), __builtin_fmaxf(v.z, v.w));
+                    mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fminf(v.x, v.y)), __builtin_fminf(v.z, v.w));
+                    sum += (v.x + v.y) + (v.z + v.w);
+                }
+                const bool any_above = __any(LOGS ? mx > lcut : mx > vcut);
+                const bool any_odd = __any(sum != sum || (LOGS ? mn == -__builtin_inff() : mn <= 0.0f));
+                wait_at_least(hand + 1, k);
+                wait_at_least(hand + 2, k);
+                if (debug != 4 || k == 0) {  // (debug 4, profiling only, results wrong: every stripe keeps its first row -- the walkers' side alone)
+#pragma unroll
+                    for (int u = 0; u < NV; ++u) {
+                        const int c = (u * kWave + lane) * 4;
+                        *reinterpret_cast<float4 *>(dst + (c < dim ? c : dim - 4)) = pre[u];
+                    }
+                    if (lane == 0) hand[4] = (any_above ? 1u : 0u) | (any_odd ? 2u : 0u);
+                }
+                post(hand, k + 1);
+                if (i + n_fetch < my_rows && (debug != 4 || i + n_fetch < n_stripes)) fetch(pre, blockIdx.x + (i + n_fetch) * gstride);
+            }
+        } else {
+            const int st = wave % n_stripes, c = wave / n_stripes;
+            uint32_t *hand = hands + st * kHandWords;
+            row = stripes + (int64_t)st * stripe_words;
+            list = reinterpret_cast<uint16_t *>(row + ((dim + 3) & ~3));
+            for (int64_t i = st; i < my_rows; i += n_stripes) {
+                const uint32_t k = (uint32_t)(i / n_stripes);
+                const int64_t d = blockIdx.x + i * gstride;
+                wait_at_least(hand, k + 1);
+                const uint32_t found = hand[4];
+                Scanned sc{dim, 0, false, false, false, LOGS};
+                if (found != 0 || (int64_t)dim * 1000 <= (int64_t)direct_permille * dim) {  // (wave-uniform) the scan has to look again: walker 0 does, and says what it saw
+                    if (c == 0) {
+                        sc = scan((found & 1) != 0, (found & 2) != 0);
+                        if (lane == 0) {
+                            hand[5] = (uint32_t)sc.n_stored, hand[6] = (uint32_t)sc.n_list;
+                            hand[7] = (sc.has_nan ? 1u : 0u) | (sc.by_entry ? 2u : 0u) | (sc.listable ? 4u : 0u) | (sc.logs_staged ? 8u : 0u);
+                        }
+                        post(hand + 3, k + 1);
+                    } else {
+                        wait_at_least(hand + 3, k + 1);
+                        const uint32_t bits = hand[7];
+                        sc = Scanned{(int)hand[5], (int)hand[6], (bits & 1) != 0, (bits & 2) != 0, (bits & 4) != 0, (bits & 8) != 0};
+                    }
+                }
+                if (debug != 1 && debug != 2) walk(d, sc, c, c + 1);
+                if (c == 0 && lane == 0) nonempty[d] = sc.n_stored > 0 ? 1 : 0;
+                post(hand + 1 + c, k + 1);
+            }
+        }
+        return;
+    }
+    if constexpr (SPLIT == 1) {
+        const auto wait_for = [&](uint32_t turn) {
+            for (uint32_t polls = 0; __hip_atomic_load(s_hand, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != turn; ++polls) {
+                if (polls > kSpinLimit) __builtin_trap();
+                __builtin_amdgcn_s_sleep(2);
+            }
+        };
+        const int64_t d0 = (int64_t)blockIdx.x * n_pairs + pair;
+        if (fetcher) {
+            float4 pre[NV];
+            fetch(pre, d0);
+            for (int64_t d = d0; d < n_rows; d += stride) {
+                // the row's three reductions first (they wait for the loads), then for the stripe, then the stores: the walker gets the
+                // stripe the moment the last of sixteen stores is out, and the next row's loads go out right behind them
+                float mx = -__builtin_inff(), mn = __builtin_inff(), sum = 0.0f;
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const float4 v = pre[u];
+                    mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fmaxf(v.x, v.y)), __builtin_fmaxf(v.z, v.w));
+                    mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fminf(v.x, v.y)), __builtin_fminf(v.z, v.w));
+                    sum += (v.x + v.y) + (v.z + v.w);
+                }
+                const bool any_above = __any(LOGS ? mx > lcut : mx > vcut);
+                const bool any_odd = __any(sum != sum || (LOGS ? mn == -__builtin_inff() : mn <= 0.0f));
+                if (debug < 3) wait_for(0);  // (debug 3 / 4, profiling only, results wrong: the two sides run free of each other / the walkers alone)
+#pragma unroll
+                for (int u = 0; u < NV; ++u) {
+                    const int c = (u * kWave + lane) * 4;
+                    *reinterpret_cast<float4 *>(row + (c < dim ? c : dim - 4)) = pre[u];
+                }
+                if (lane == 0) s_hand[1] = any_above ? 1u : 0u, s_hand[2] = any_odd ? 1u : 0u;
+                __hip_atomic_store(s_hand, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (debug == 4) break;
+                if (d + stride < n_rows) fetch(pre, d + stride);
+            }
+        } else {
+            for (int64_t d = d0; d < n_rows; d += stride) {
+                if (debug < 3 || d == d0) wait_for(1);
+                const bool any_above = s_hand[1] != 0, any_odd = s_hand[2] != 0;
+                if (debug != 2) MHX_SCAN_AND_WALK(d, any_above, any_odd);
+                else if (lane == 0) nonempty[d] = any_above || any_odd ? 1 : 0;
+                if (debug < 3) __hip_atomic_store(s_hand, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        return;
+    }
+    const auto one_row = [&](float4 (&pre)[NV], int64_t d) {
+        bool lane_above, lane_odd;
+        stage(pre, lane_above, lane_odd);
+        // (FETCH bit 0) the refill goes out as soon as the registers are free: two rows per wave are in flight for the whole
+        // of the scan and the walk, at the price of the walk's first table load waiting behind it
+        if constexpr ((FETCH & 1) != 0) fetch(pre, d + 2 * stride);
+        if (debug == 2) {  // profiling only (results are wrong): rows fetched and staged, nothing else
+            if (lane == 0) nonempty[d] = lane_above || lane_odd ? 1 : 0;
+        } else {
+            MHX_SCAN_AND_WALK(d, __any(lane_above), __any(lane_odd));
+        }
         // the refill goes out behind the walk (vector loads complete in order: a walk's own table load must not sit out
         // the HBM latency of a row that is not needed for two rows)
         if constexpr ((FETCH & 1) == 0) fetch(pre, d + 2 * stride);
@@ -1642,6 +1824,8 @@ __global__ __launch_bounds__(512) void weighted_walk_wave_kernel(const float *__
         if (d + stride < n_rows) one_row(pre1, d + stride);
     }
 }
+
+#undef MHX_SCAN_AND_WALK
 
 // ---- CSR rows ---------------------------------------------------------------------------------------
 // A row that stores few of the columns is evaluated entry by entry (weighted_csr_direct_kernel: one wave per row and
@@ -1907,13 +2091,15 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
             const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, per_cu * ctx->num_cus));
             const int nv = dim <= 1024 ? 4 : dim <= 2048 ? 8 : 16;
 #define MHX_WALK_WAVE(LOGS, NV_, ...)                                                                                                  \
-    hipLaunchKernelGGL((weighted_walk_wave_kernel<LOGS, NV_, __VA_ARGS__>), dim3(blocks), dim3(64 * waves), lds, ctx->stream, d_x, n_rows, dim, plan, walk_a, \
+    hipLaunchKernelGGL((weighted_walk_wave_kernel<LOGS, NV_, __VA_ARGS__>), dim3(split == 2 ? blocks2 : blocks), dim3(split == 2 ? 1024 : 64 * waves * (split ? 2 : 1)), split == 2 ? lds2 : lds + (split ? 4 * kSplitHandWords : 0), ctx->stream, d_x, n_rows, dim, plan, walk_a, \
                        gen->d_walk_c, reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, list_cap_w, direct_permille_w,  \
-                       (int32_t)(stripe_bytes / 4), rescue_lanes, d_out, d_nonempty, (int32_t)ctx->opt_weighted_debug)
+                       (int32_t)(stripe_bytes / 4), rescue_lanes, d_out, d_nonempty, (int32_t)ctx->opt_weighted_debug, split_stripes)
 #define MHX_WALK_WAVE_NV(LOGS, PAIRS_)            \
     do {                                          \
         if (nv == 4) MHX_WALK_WAVE(LOGS, 4, PAIRS_);      \
         else if (nv == 8) MHX_WALK_WAVE(LOGS, 8, PAIRS_); \
+        else if (split == 2) MHX_WALK_WAVE(LOGS, 16, false, 2, 2); \
+        else if (split == 1) MHX_WALK_WAVE(LOGS, 16, PAIRS_, 2, 1); \
         else if (fetch_mode == 2) MHX_WALK_WAVE(LOGS, 16, PAIRS_, 2); \
         else if (fetch_mode == 3) MHX_WALK_WAVE(LOGS, 16, PAIRS_, 3); \
         else MHX_WALK_WAVE(LOGS, 16, PAIRS_);             \
@@ -1922,7 +2108,17 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
             // logs in; with values in, chunk after chunk + the refill right after staging + non-temporal 0.526 -> 0.499 ms.  The early refill
             // alone gains nothing (0.427) and costs the chunk-pair walk 17-32 spilled VGPRs (0.489).  Option weighted.refill: 0 auto,
             // 1 = plain loads behind the walk (round 4), 2 / 3 = force that mode.
-            const bool auto_fetch = ctx->opt_weighted_refill == 0;
+            // weighted.refill 4: pairs of waves, a fetcher and a walker per stripe (SPLIT; 4096-column rows, room for the hand-over words)
+            // weighted.refill 5 / 6 / 7: six / five / seven stripes with two walkers each (one per chunk of samples; 128 samples), the other waves fetch (SPLIT 2)
+            const int64_t rf = ctx->opt_weighted_refill;  // 0 auto; 13: auto without the fetcher / walker split (round 5's first half; A/B)
+            const int32_t n_stripes2 = rf == 6 || rf == 9 ? 5 : rf == 7 ? 7 : 6;
+            const int32_t cached2 = rf == 0 || rf == 8 || rf == 10 ? 16 : rf == 9 ? 24 : rf == 11 ? 20 : rf == 12 ? 12 : kWalkCached;  // (8: six stripes, 16 positions; 9: five stripes, 24)
+            const int32_t split_stripes = n_stripes2 | cached2 << 8 | (rf == 0 || rf == 10 ? 1 << 16 : 0);
+            const size_t lds2 = 20 * (size_t)n_cc_w * cached2 * kWave + 4 * kSplitHandWords2 + stripe_bytes * (size_t)n_stripes2;
+            int split = rf == 4 && nv == 16 && lds + 4 * kSplitHandWords <= (size_t)ctx->lds_per_block && waves * 2 * 64 <= 1024 ? 1 : 0;
+            if ((rf == 0 || (rf >= 5 && rf <= 12)) && ctx->opt_weighted_kernel == 0 && nv == 16 && gen->s_pad == 2 * kWave && lds2 <= (size_t)ctx->lds_per_block) split = 2;
+            const unsigned blocks2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_rows, ctx->num_cus));  // (SPLIT 2: one workgroup of sixteen waves per CU, rows blockIdx.x + i * gridDim.x)
+            const bool auto_fetch = rf == 0 || rf == 13;
             const int fetch_mode = auto_fetch ? (values_are_logs ? 2 : 3) : ctx->opt_weighted_refill == 1 ? 0 : (int)(ctx->opt_weighted_refill & 3);
             const int32_t rescue_lanes = ctx->opt_weighted_rescue < 0 ? 0 : ctx->opt_weighted_rescue > 0 ? (int32_t)ctx->opt_weighted_rescue : 8;  // (lognormal rows at steady clocks: 2: 0.557, 4: 0.535, 8: 0.529, 16: 0.563, 32: 0.68 ms per 20k; config 4 the same for all)
             // two chunks of samples as one stream (0.424 -> 0.405 ms on config 4 with logs in); 2 = chunk after chunk, which values in take at NV = 16
