@@ -837,6 +837,13 @@ static int launch_walk_plan(mhx_wgen *gen, const float *d_v, bool logs, int64_t 
     return MHX_OK;
 }
 
+// A walk that went beyond the cached positions leaves the entries it fetched ahead for a round that never came on their way.
+// The compiler cannot know that most rows never get there: it puts its s_waitcnt vmcnt where those registers are next written
+// -- inside the first cached round of the NEXT row, where the wait also covers this row's result stores (vmcnt counts stores on
+// gfx9).  Waiting explicitly between the walk and the stores costs nothing on the common path (no load is out) and leaves
+// nothing but stores pending at the loop's back edge.
+__device__ __forceinline__ void drain_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0), the other counters untouched
+
 // what a lane holds for its sample: the smallest ln_a so far, its column (ties: the smaller one) and its t
 struct Held {
     float ln_a = __builtin_inff();
@@ -846,8 +853,10 @@ struct Held {
         if (a < ln_a || (a == ln_a && col < c)) ln_a = a, t = tt, c = col;
     }
     // the same as a select (no branch): inside the walk's rounds, where a branch per position costs more than the position
+    // (& and |, not && and ||: the short-circuit form came out of the compiler as three nested exec-mask regions per position --
+    // s_and_saveexec + s_cbranch_execz, ~20 instructions -- where three compares and three scalar mask operations do)
     __device__ __forceinline__ void take_if(bool ok, float a, float tt, uint32_t col) {
-        const bool better = ok && (a < ln_a || (a == ln_a && col < c));
+        const bool better = ok & ((a < ln_a) | ((a == ln_a) & (col < c)));
         ln_a = better ? a : ln_a, t = better ? tt : t, c = better ? col : c;
     }
     __device__ __forceinline__ void offer(float l, const float4 e, uint32_t col) {  // e = {r, ln_c, beta, .}
@@ -1612,6 +1621,7 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
                     Held held[2];
                     walk_chunks<2, VALS>(row, list, n_list, by_entry, dim, ch, lane, sample_size, walk_a, walk_c, aos, s_pad,
                                          s_cache_a + ch * wcached * kWave, s_cache_c + ch * wcached * kWave, rescue_lanes, held, logs_staged);
+                    if constexpr (SPLIT != 0) drain_loads();  // (a wave that also fetches has rows on their way: not there)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const int32_t my = (ch + i) * kWave + lane;
@@ -1628,6 +1638,7 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
                     Held held[1];
                     walk_chunks<1, VALS>(row, list, n_list, by_entry, dim, ch, lane, sample_size, walk_a, walk_c, aos, s_pad,
                                          s_cache_a + ch * wcached * kWave, s_cache_c + ch * wcached * kWave, rescue_lanes, held, logs_staged, wcached);
+                    drain_loads();
                     const int32_t my1 = ch * kWave + lane;
                     if (my1 < sample_size) {
                         int64_t *o = out + (d * sample_size + my1) * 2;
@@ -1723,6 +1734,9 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
                 if (i + n_fetch < my_rows && (debug != 4 || i + n_fetch < n_stripes)) fetch(pre, blockIdx.x + (i + n_fetch) * gstride);
             }
         } else {
+            drain_loads();  // (a walker has issued no load: this only tells the compiler so -- the structurised control flow runs from the fetchers' loop
+                            // into this branch, and with it the compiler's idea that sixteen loads may be out: its s_waitcnt vmcnt(2 / 1 / 0) in the
+                            // walkers' cached rounds waited for the walkers' own result stores)
             const int st = wave % n_stripes, c = wave / n_stripes;
             uint32_t *hand = hands + st * kHandWords;
             row = stripes + (int64_t)st * stripe_words;
@@ -1790,6 +1804,7 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
                 if (d + stride < n_rows) fetch(pre, d + stride);
             }
         } else {
+            drain_loads();  // (see SPLIT 2)
             for (int64_t d = d0; d < n_rows; d += stride) {
                 if (debug < 3 || d == d0) wait_for(1);
                 const bool any_above = s_hand[1] != 0, any_odd = s_hand[2] != 0;
