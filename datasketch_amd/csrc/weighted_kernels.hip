@@ -844,6 +844,21 @@ static int launch_walk_plan(mhx_wgen *gen, const float *d_v, bool logs, int64_t 
 // nothing but stores pending at the loop's back edge.
 __device__ __forceinline__ void drain_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0), the other counters untouched
 
+// The row scan's three running values over four more entries: six instructions (v_max3 / v_min3 / v_pk_add on the register pairs the
+// load delivered).  The C++ form -- fmaxf(fmaxf(mx, fmaxf(x, y)), fmaxf(z, w)) and so on -- came out as seventeen: maxnum must not
+// return a quieted signalling NaN, so the compiler canonicalises every loaded value first (v_max_f32 v, v, v), and the sum's
+// (x + y) + (z + w) shuffles registers into pairs.  Here a signalling NaN may poison mx or mn of its lane instead of being skipped;
+// the sum is NaN whenever any entry is, and a row with a NaN never looks at mx or mn again (scan: has_nan -> nan_row).
+typedef float float2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void scan4(const float4 v, float &mx, float &mn, float2v &sum) {
+    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(v.x), "v"(v.y));
+    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(mx) : "v"(v.z), "v"(v.w));
+    asm("v_min3_f32 %0, %0, %1, %2" : "+v"(mn) : "v"(v.x), "v"(v.y));
+    asm("v_min3_f32 %0, %0, %1, %2" : "+v"(mn) : "v"(v.z), "v"(v.w));
+    sum += float2v{v.x, v.y};
+    sum += float2v{v.z, v.w};
+}
+
 // what a lane holds for its sample: the smallest ln_a so far, its column (ties: the smaller one) and its t
 struct Held {
     float ln_a = __builtin_inff();
@@ -1122,19 +1137,37 @@ __device__ __forceinline__ void walk_chunks(const float *row, const uint16_t *li
     constexpr int kU = NC == 1 ? MHX_WALK_KU1 : 4;
     const int32_t n_cached = (dim < cached ? dim : cached) / kU * kU;
     int32_t k = 0;
-    for (; k < n_cached; k += kU) {
-        float4 e[NC][kU];
-        uint32_t c[NC][kU];
+    // One chunk walked alone (NC = 1: the walkers of the fetcher / walker kernel) reads a round's entries one round AHEAD: the stop test at
+    // the top of a round then waits for nothing, and a round is one LDS round trip (the row's entries) instead of three -- the compiler had
+    // sunk the round's other reads below the test, which needs only the first bound.  (Two chunks as one stream have no registers for it.)
+    constexpr bool kAheadCached = NC == 1;
+    float4 e_ahead[NC][kU];
+    uint32_t c_ahead[NC][kU];
+    const auto read_round = [&](int32_t at, float4 (&e)[NC][kU], uint32_t (&c)[NC][kU]) {
 #pragma unroll
         for (int i = 0; i < NC; ++i)
 #pragma unroll
             for (int u = 0; u < kU; ++u) {
-                e[i][u] = cache_a[(i * kWalkCached + k + u) * kWave + lane];
-                c[i][u] = cache_c[(i * kWalkCached + k + u) * kWave + lane];
+                e[i][u] = cache_a[(i * kWalkCached + at + u) * kWave + lane];
+                c[i][u] = cache_c[(i * kWalkCached + at + u) * kWave + lane];
             }
+    };
+    if (kAheadCached && n_cached > 0) read_round(0, e_ahead, c_ahead);
+    for (; k < n_cached; k += kU) {
+        float4 e[NC][kU];
+        uint32_t c[NC][kU];
+        if constexpr (kAheadCached) {
+#pragma unroll
+            for (int i = 0; i < NC; ++i)
+#pragma unroll
+                for (int u = 0; u < kU; ++u) e[i][u] = e_ahead[i][u], c[i][u] = c_ahead[i][u];
+        } else {
+            read_round(k, e, c);
+        }
 #pragma unroll
         for (int i = 0; i < NC; ++i) done[i] = done[i] || e[i][0].x > held[i].ln_a;  // an equal bound may still hide a tie at a smaller column
         if (!walking()) break;
+        if constexpr (kAheadCached) read_round(k + kU < n_cached ? k + kU : k, e_ahead, c_ahead);  // (the last round reads itself again: nobody looks)
         float l[NC][kU], t[NC][kU], a[NC][kU];
         bool open = false;
 #pragma unroll
@@ -1529,16 +1562,16 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
         // 0)? -- are asked of a maximum, a sum and a minimum over the lane's 64 entries (v_max3 / v_min3 / v_add: ~100 VALU
         // instructions, no scalar ones) instead of two compares and two scalar ORs per entry: max and min skip NaNs, the sum
         // carries them (and is NaN without one only for +inf and -inf together, a row the minimum flags anyway).
-        float mx = -__builtin_inff(), mn = __builtin_inff(), sum = 0.0f;
+        float mx = -__builtin_inff(), mn = __builtin_inff();
+        float2v sum2 = {0.0f, 0.0f};
 #pragma unroll
         for (int u = 0; u < NV; ++u) {
             const int c = (u * kWave + lane) * 4;
             const float4 v = pre[u];
-            mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fmaxf(v.x, v.y)), __builtin_fmaxf(v.z, v.w));
-            mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fminf(v.x, v.y)), __builtin_fminf(v.z, v.w));
-            sum += (v.x + v.y) + (v.z + v.w);
+            scan4(v, mx, mn, sum2);
             *reinterpret_cast<float4 *>(row + (c < dim ? c : dim - 4)) = v;
         }
+        const float sum = sum2.x + sum2.y;
         lane_above = LOGS ? mx > lcut : mx > vcut;                               // (+inf too; values: candidates, their logs are taken below)
         lane_odd = sum != sum || (LOGS ? mn == -__builtin_inff()                 // a NaN, or an entry that is not stored: log -inf,
                                        : mn <= 0.0f);                            // a value that is zero (+-0) or negative (its log: NaN)
@@ -1710,14 +1743,11 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
                 const uint32_t k = (uint32_t)(i / n_stripes);
                 uint32_t *hand = hands + st * kHandWords;
                 float *dst = stripes + (int64_t)st * stripe_words;
-                float mx = -__builtin_inff(), mn = __builtin_inff(), sum = 0.0f;
+                float mx = -__builtin_inff(), mn = __builtin_inff();
+                float2v sum2 = {0.0f, 0.0f};
 #pragma unroll
-                for (int u = 0; u < NV; ++u) {
-                    const float4 v = pre[u];
-                    mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fmaxf(v.x, v.y)), __builtin_fmaxf(v.z, v.w));
-                    mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fminf(v.x, v.y)), __builtin_fminf(v.z, v.w));
-                    sum += (v.x + v.y) + (v.z + v.w);
-                }
+                for (int u = 0; u < NV; ++u) scan4(pre[u], mx, mn, sum2);
+                const float sum = sum2.x + sum2.y;
                 const bool any_above = __any(LOGS ? mx > lcut : mx > vcut);
                 const bool any_odd = __any(sum != sum || (LOGS ? mn == -__builtin_inff() : mn <= 0.0f));
                 wait_at_least(hand + 1, k);
@@ -1782,14 +1812,11 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
             for (int64_t d = d0; d < n_rows; d += stride) {
                 // the row's three reductions first (they wait for the loads), then for the stripe, then the stores: the walker gets the
                 // stripe the moment the last of sixteen stores is out, and the next row's loads go out right behind them
-                float mx = -__builtin_inff(), mn = __builtin_inff(), sum = 0.0f;
+                float mx = -__builtin_inff(), mn = __builtin_inff();
+                float2v sum2 = {0.0f, 0.0f};
 #pragma unroll
-                for (int u = 0; u < NV; ++u) {
-                    const float4 v = pre[u];
-                    mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fmaxf(v.x, v.y)), __builtin_fmaxf(v.z, v.w));
-                    mn = __builtin_fminf(__builtin_fminf(mn, __builtin_fminf(v.x, v.y)), __builtin_fminf(v.z, v.w));
-                    sum += (v.x + v.y) + (v.z + v.w);
-                }
+                for (int u = 0; u < NV; ++u) scan4(pre[u], mx, mn, sum2);
+                const float sum = sum2.x + sum2.y;
                 const bool any_above = __any(LOGS ? mx > lcut : mx > vcut);
                 const bool any_odd = __any(sum != sum || (LOGS ? mn == -__builtin_inff() : mn <= 0.0f));
                 if (debug < 3) wait_for(0);  // (debug 3 / 4, profiling only, results wrong: the two sides run free of each other / the walkers alone)
