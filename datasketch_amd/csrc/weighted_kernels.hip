@@ -1482,16 +1482,15 @@ __global__ __launch_bounds__(256, 4) void weighted_walk_dense_kernel(const float
 // Same arithmetic, same rules, same helper (walk_row) as the kernel above; rows it does not take (dim > 4096 or not a
 // multiple of 4, fewer than two stripes fitting the LDS) stay with that kernel.
 // FETCH (A/B, option weighted.refill): bit 0 = the next row's loads go out right after staging instead of behind the walk, bit 1 = non-temporal loads
-// SPLIT (round 5): the waves of a workgroup come in pairs that share a stripe -- a FETCHER that streams rows from HBM through its
-// registers into the stripe and a WALKER that scans and walks them.  Vector loads of one wave complete in order, so a wave that does
-// both either has no row in flight while it walks or has its walk's table loads (L2 hits) queue behind a row's HBM latency: measured,
-// a row cost its wave the latency of a row PLUS the walk (5.6 + 2.7 us).  Two waves have two load queues: the fetcher's next row is
-// in flight for the whole of the walker's walk.  The pair hands the stripe back and forth through one LDS word (0: the fetcher's,
-// 1: the walker's), release / acquire at workgroup scope; a wait that outlasts kSpinLimit polls traps (a protocol error is loud).
-constexpr int kSplitHandWords = 32;        // SPLIT 1: four words per pair of waves, eight pairs
+// SPLIT (round 5): FETCHER waves stream rows from HBM through their registers into the stripes, WALKER waves scan and walk them.
+// Vector loads of one wave complete in order, so a wave that does both either has no row in flight while it walks or has its walk's
+// table loads (L2 hits) queue behind a row's HBM latency; and the walk itself is a chain of dependent LDS round trips that leaves the
+// SIMD idle (one-wave-per-row kernel: walkers alone take 0.35 ms for config 4 at two waves per SIMD, the rows' stream 0.26).  Split,
+// the walkers need no registers for rows in flight: sixteen waves of <= 128 VGPRs fit a CU instead of eight of 250 -- twelve walkers
+// (a row's two chunks of 64 samples go to two waves) and four fetchers.  See the SPLIT == 2 block below for the hand-over.
 constexpr int kHandWords = 8;              // SPLIT 2: per stripe {ready, done[0], done[1], scanned, what the fetcher found, n_stored, n_list, flags}
 constexpr int kSplitHandWords2 = 64;       // ... eight stripes at most
-constexpr uint32_t kSpinLimit = 1u << 24;  // polls (each ~100 cycles) a wave waits for its partner before it traps
+constexpr uint32_t kSpinLimit = 1u << 24;  // polls (each ~100 cycles) a wave waits for the other side before it traps
 template <bool LOGS, int NV, bool PAIRS, int FETCH = 0, int SPLIT = 0>  // NV: 16-byte loads per lane that hold a row (dim <= 256 NV); PAIRS: two chunks of samples walked as one instruction stream
 __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_kernel(const float *__restrict__ x, int64_t n_rows, int32_t dim,
                                                                  const WalkPlan *__restrict__ plan, const float4 *__restrict__ walk_a,
@@ -1504,8 +1503,7 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), n_waves = blockDim.x >> 6;
     const int32_t chunks = s_pad / kWave;
     const int32_t n_cc = chunks < kCachedChunks ? chunks : kCachedChunks;
-    const int32_t wcached = SPLIT == 2 ? split_stripes >> 8 & 255 : kWalkCached;
-    const bool split_rescue = (split_stripes >> 16 & 1) != 0;  // (A/B)  // list positions per chunk kept in LDS (SPLIT 2: the launcher's choice)
+    const int32_t wcached = SPLIT == 2 ? split_stripes >> 8 & 255 : kWalkCached;  // list positions per chunk kept in LDS (SPLIT 2: the launcher's choice)
     float4 *s_cache_a = reinterpret_cast<float4 *>(lds);
     uint32_t *s_cache_c = reinterpret_cast<uint32_t *>(s_cache_a + n_cc * wcached * kWave);
     for (int j = tid; j < n_cc * wcached * kWave; j += blockDim.x) {
@@ -1515,15 +1513,9 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
             s_cache_c[j] = walk_c[((int64_t)ch * dim + k) * kWave + (j & (kWave - 1))];
         }
     }
-    // SPLIT: wave w < n_pairs walks what wave w + n_pairs fetches (waves go round the four SIMDs: each gets walkers and fetchers alike)
-    const int n_pairs = SPLIT == 1 ? n_waves >> 1 : n_waves;
-    const bool fetcher = SPLIT == 1 && wave >= n_pairs;
-    const int pair = fetcher ? wave - n_pairs : wave;
-    uint32_t *s_hand = reinterpret_cast<uint32_t *>(lds + 5 * n_cc * wcached * kWave) + pair * 4;  // SPLIT: {whose turn, above the cut?, odd?, -}
-    if (SPLIT == 1 && tid < n_pairs * 4) reinterpret_cast<uint32_t *>(lds + 5 * n_cc * wcached * kWave)[tid] = 0;
     if (SPLIT == 2 && tid < kSplitHandWords2) reinterpret_cast<uint32_t *>(lds + 5 * n_cc * wcached * kWave)[tid] = 0;
     __syncthreads();  // the only barrier of the kernel
-    float *row = lds + 5 * n_cc * wcached * kWave + (SPLIT == 1 ? kSplitHandWords : 0) + (int64_t)pair * stripe_words;
+    float *row = lds + 5 * n_cc * wcached * kWave + (int64_t)wave * stripe_words;  // (SPLIT 2: set below)
     uint16_t *list = reinterpret_cast<uint16_t *>(row + ((dim + 3) & ~3));
     const float lcut = plan->lcut;
     // values in (LOGS = false): the stripe holds the VALUES and the log is taken of the entries a walk meets (row_log<true>), not
@@ -1532,7 +1524,7 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
     // log taken and compared
     // (below exp(-87) the values are denormal and a rounded exp is no bound: there every positive value has its log taken)
     const float vcut = LOGS ? 0.0f : (lcut >= 88.0f ? __FLT_MAX__ : lcut <= -87.0f ? 0.0f : expf(lcut - 1e-5f * fmaxf(1.0f, fabsf(lcut))));
-    const int64_t stride = (int64_t)gridDim.x * n_pairs;
+    const int64_t stride = (int64_t)gridDim.x * n_waves;
     // every lane always issues exactly NV loads per row (clamped to the matrix and to the row), so that the number of loads
     // in flight behind a row's is known at compile time and the wait for a row is not a wait for the one behind it
     const auto fetch = [&](float4 (&pre)[NV], int64_t d) {
@@ -1654,7 +1646,6 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
                     Held held[2];
                     walk_chunks<2, VALS>(row, list, n_list, by_entry, dim, ch, lane, sample_size, walk_a, walk_c, aos, s_pad,
                                          s_cache_a + ch * wcached * kWave, s_cache_c + ch * wcached * kWave, rescue_lanes, held, logs_staged);
-                    if constexpr (SPLIT != 0) drain_loads();  // (a wave that also fetches has rows on their way: not there)
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const int32_t my = (ch + i) * kWave + lane;
@@ -1667,7 +1658,7 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
                     ++ch;
                     continue;
                 }
-                if (SPLIT == 2 && split_rescue && walked && ch < n_cc) {  // one chunk, through the same stream as the pairs: the tail of a heavy-tailed row by the whole wave (walk_rescue)
+                if (SPLIT == 2 && walked && ch < n_cc) {  // one chunk, through the same stream as the pairs: the tail of a heavy-tailed row by the whole wave (walk_rescue)
                     Held held[1];
                     walk_chunks<1, VALS>(row, list, n_list, by_entry, dim, ch, lane, sample_size, walk_a, walk_c, aos, s_pad,
                                          s_cache_a + ch * wcached * kWave, s_cache_c + ch * wcached * kWave, rescue_lanes, held, logs_staged, wcached);
@@ -1794,50 +1785,6 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
                 if (debug != 1 && debug != 2) walk(d, sc, c, c + 1);
                 if (c == 0 && lane == 0) nonempty[d] = sc.n_stored > 0 ? 1 : 0;
                 post(hand + 1 + c, k + 1);
-            }
-        }
-        return;
-    }
-    if constexpr (SPLIT == 1) {
-        const auto wait_for = [&](uint32_t turn) {
-            for (uint32_t polls = 0; __hip_atomic_load(s_hand, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != turn; ++polls) {
-                if (polls > kSpinLimit) __builtin_trap();
-                __builtin_amdgcn_s_sleep(2);
-            }
-        };
-        const int64_t d0 = (int64_t)blockIdx.x * n_pairs + pair;
-        if (fetcher) {
-            float4 pre[NV];
-            fetch(pre, d0);
-            for (int64_t d = d0; d < n_rows; d += stride) {
-                // the row's three reductions first (they wait for the loads), then for the stripe, then the stores: the walker gets the
-                // stripe the moment the last of sixteen stores is out, and the next row's loads go out right behind them
-                float mx = -__builtin_inff(), mn = __builtin_inff();
-                float2v sum2 = {0.0f, 0.0f};
-#pragma unroll
-                for (int u = 0; u < NV; ++u) scan4(pre[u], mx, mn, sum2);
-                const float sum = sum2.x + sum2.y;
-                const bool any_above = __any(LOGS ? mx > lcut : mx > vcut);
-                const bool any_odd = __any(sum != sum || (LOGS ? mn == -__builtin_inff() : mn <= 0.0f));
-                if (debug < 3) wait_for(0);  // (debug 3 / 4, profiling only, results wrong: the two sides run free of each other / the walkers alone)
-#pragma unroll
-                for (int u = 0; u < NV; ++u) {
-                    const int c = (u * kWave + lane) * 4;
-                    *reinterpret_cast<float4 *>(row + (c < dim ? c : dim - 4)) = pre[u];
-                }
-                if (lane == 0) s_hand[1] = any_above ? 1u : 0u, s_hand[2] = any_odd ? 1u : 0u;
-                __hip_atomic_store(s_hand, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (debug == 4) break;
-                if (d + stride < n_rows) fetch(pre, d + stride);
-            }
-        } else {
-            drain_loads();  // (see SPLIT 2)
-            for (int64_t d = d0; d < n_rows; d += stride) {
-                if (debug < 3 || d == d0) wait_for(1);
-                const bool any_above = s_hand[1] != 0, any_odd = s_hand[2] != 0;
-                if (debug != 2) MHX_SCAN_AND_WALK(d, any_above, any_odd);
-                else if (lane == 0) nonempty[d] = any_above || any_odd ? 1 : 0;
-                if (debug < 3) __hip_atomic_store(s_hand, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         return;
@@ -2133,7 +2080,7 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
             const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(groups, per_cu * ctx->num_cus));
             const int nv = dim <= 1024 ? 4 : dim <= 2048 ? 8 : 16;
 #define MHX_WALK_WAVE(LOGS, NV_, ...)                                                                                                  \
-    hipLaunchKernelGGL((weighted_walk_wave_kernel<LOGS, NV_, __VA_ARGS__>), dim3(split == 2 ? blocks2 : blocks), dim3(split == 2 ? 1024 : 64 * waves * (split ? 2 : 1)), split == 2 ? lds2 : lds + (split ? 4 * kSplitHandWords : 0), ctx->stream, d_x, n_rows, dim, plan, walk_a, \
+    hipLaunchKernelGGL((weighted_walk_wave_kernel<LOGS, NV_, __VA_ARGS__>), dim3(split == 2 ? blocks2 : blocks), dim3(split == 2 ? 1024 : 64 * waves), split == 2 ? lds2 : lds, ctx->stream, d_x, n_rows, dim, plan, walk_a, \
                        gen->d_walk_c, reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, list_cap_w, direct_permille_w,  \
                        (int32_t)(stripe_bytes / 4), rescue_lanes, d_out, d_nonempty, (int32_t)ctx->opt_weighted_debug, split_stripes)
 #define MHX_WALK_WAVE_NV(LOGS, PAIRS_)            \
@@ -2141,7 +2088,6 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
         if (nv == 4) MHX_WALK_WAVE(LOGS, 4, PAIRS_);      \
         else if (nv == 8) MHX_WALK_WAVE(LOGS, 8, PAIRS_); \
         else if (split == 2) MHX_WALK_WAVE(LOGS, 16, false, 2, 2); \
-        else if (split == 1) MHX_WALK_WAVE(LOGS, 16, PAIRS_, 2, 1); \
         else if (fetch_mode == 2) MHX_WALK_WAVE(LOGS, 16, PAIRS_, 2); \
         else if (fetch_mode == 3) MHX_WALK_WAVE(LOGS, 16, PAIRS_, 3); \
         else MHX_WALK_WAVE(LOGS, 16, PAIRS_);             \
@@ -2150,15 +2096,15 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
             // logs in; with values in, chunk after chunk + the refill right after staging + non-temporal 0.526 -> 0.499 ms.  The early refill
             // alone gains nothing (0.427) and costs the chunk-pair walk 17-32 spilled VGPRs (0.489).  Option weighted.refill: 0 auto,
             // 1 = plain loads behind the walk (round 4), 2 / 3 = force that mode.
-            // weighted.refill 4: pairs of waves, a fetcher and a walker per stripe (SPLIT; 4096-column rows, room for the hand-over words)
-            // weighted.refill 5 / 6 / 7: six / five / seven stripes with two walkers each (one per chunk of samples; 128 samples), the other waves fetch (SPLIT 2)
-            const int64_t rf = ctx->opt_weighted_refill;  // 0 auto; 13: auto without the fetcher / walker split (round 5's first half; A/B)
-            const int32_t n_stripes2 = rf == 6 || rf == 9 ? 5 : rf == 7 ? 7 : 6;
-            const int32_t cached2 = rf == 0 || rf == 8 || rf == 10 ? 16 : rf == 9 ? 24 : rf == 11 ? 20 : rf == 12 ? 12 : kWalkCached;  // (8: six stripes, 16 positions; 9: five stripes, 24)
-            const int32_t split_stripes = n_stripes2 | cached2 << 8 | (rf == 0 || rf == 10 ? 1 << 16 : 0);
+            // weighted.refill 0 (auto): 4096-column rows and 128 samples go to the fetcher / walker split -- six stripes with two walkers each (one per
+            // chunk of samples), four fetchers, 16 cached list positions per chunk (SPLIT 2).  5: the same with 8 cached positions, 6: five stripes
+            // and six fetchers, 13: auto without the split (the one-wave-per-row kernel of this round's first half; A/B).
+            const int64_t rf = ctx->opt_weighted_refill;
+            const int32_t n_stripes2 = rf == 6 ? 5 : 6;
+            const int32_t cached2 = rf == 5 ? kWalkCached : 16;
+            const int32_t split_stripes = n_stripes2 | cached2 << 8;
             const size_t lds2 = 20 * (size_t)n_cc_w * cached2 * kWave + 4 * kSplitHandWords2 + stripe_bytes * (size_t)n_stripes2;
-            int split = rf == 4 && nv == 16 && lds + 4 * kSplitHandWords <= (size_t)ctx->lds_per_block && waves * 2 * 64 <= 1024 ? 1 : 0;
-            if ((rf == 0 || (rf >= 5 && rf <= 12)) && ctx->opt_weighted_kernel == 0 && nv == 16 && gen->s_pad == 2 * kWave && lds2 <= (size_t)ctx->lds_per_block) split = 2;
+            const int split = (rf == 0 || rf == 5 || rf == 6) && ctx->opt_weighted_kernel == 0 && nv == 16 && gen->s_pad == 2 * kWave && lds2 <= (size_t)ctx->lds_per_block ? 2 : 0;
             const unsigned blocks2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_rows, ctx->num_cus));  // (SPLIT 2: one workgroup of sixteen waves per CU, rows blockIdx.x + i * gridDim.x)
             const bool auto_fetch = rf == 0 || rf == 13;
             const int fetch_mode = auto_fetch ? (values_are_logs ? 2 : 3) : ctx->opt_weighted_refill == 1 ? 0 : (int)(ctx->opt_weighted_refill & 3);

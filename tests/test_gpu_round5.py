@@ -381,3 +381,52 @@ def test_minhash_mode_word_is_readable_follows_the_corpus_and_resets(ctx):
     assert np.array_equal(ctx.minhash_bulk((a, b), clean.reshape(-1), None, t, n), want_clean)   # first launch chosen for the dirty corpus: same result
     assert ctx.minhash_mode(reset=True) in (0, 1, 2) and ctx.minhash_mode() == 0
     assert np.array_equal(ctx.minhash_bulk((a, b), dirty.reshape(-1), None, t, n), want_dirty)
+
+
+# ------------------------------------------------------------------ config 4: fetcher and walker waves
+@pytest.mark.parametrize("values", [False, True])
+@pytest.mark.parametrize("n", [1, 3, 5, 7, 13, 255, 257, 3000])
+def test_weighted_fetcher_walker_kernel_with_few_and_odd_row_counts(ctx, n, values):
+    """The kernel that splits a workgroup into four fetcher and twelve walker waves (4096 columns, 128 samples: config 4's shape) with
+    fewer rows than fetchers, than stripes, than workgroups, and a ragged last round; rows of every kind in one call (dense, sparse,
+    empty, NaN, inf, heavy-tailed).  Every row against the C oracle, and against the one-wave-per-row kernel it replaced
+    (weighted.refill 13) and the 8-cached-positions / five-stripe settings (5, 6)."""
+    from datasketch_amd import WeightedMinHashGenerator
+
+    dim, s = 4096, 128
+    rng = np.random.RandomState(1000 + n)
+    x = rng.uniform(0, 1, (n, dim)).astype(np.float32)
+    kinds = rng.randint(0, 8, n)
+    for i, kind in enumerate(kinds):
+        if kind == 1:
+            x[i, rng.random_sample(dim) >= 0.05] = 0          # few stored: entry by entry
+        elif kind == 2:
+            x[i] = rng.lognormal(0, 2.0, dim)                  # heavy tail: entries above the cut, long walks
+        elif kind == 3 and n > 4:
+            x[i] = 0                                           # stores nothing
+        elif kind == 4:
+            x[i, rng.random_sample(dim) >= 0.5] = 0
+    if n >= 7:
+        x[5, 17] = np.nan
+        x[6, 4000] = np.inf
+    g = WeightedMinHashGenerator(dim, s, seed=5, gpu_mode="always", device_log=values)
+    wctx, _ = g._device_handle()
+    out, ne = g.minhash_many_arrays(x)
+    ref = WeightedMinHashGenerator(dim, s, seed=5, gpu_mode="disable")
+    for i in range(n):
+        if not x[i].any():
+            assert not ne[i] and not out[i].any()
+            continue
+        assert ne[i]
+        if np.isnan(x[i]).any() or np.isinf(x[i]).any():
+            continue  # (floor(NaN / inf) cast to int64 differs platform by platform: compared between the kernels below)
+        if not values and i % max(1, n // 40) == 0:  # (values in: the device's log, compared between kernels; logs in: the oracle)
+            want = ref.minhash(x[i]).hashvalues
+            assert np.array_equal(out[i], want), i
+    for code in (13, 5, 6):
+        wctx.set_option("weighted.refill", code)
+        try:
+            o2, n2 = g.minhash_many_arrays(x)
+        finally:
+            wctx.set_option("weighted.refill", 0)
+        assert np.array_equal(n2, ne) and np.array_equal(o2[ne.astype(bool)], out[ne.astype(bool)]), code

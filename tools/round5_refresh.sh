@@ -25,7 +25,9 @@ for n in 2 8; do
   timeout 900 python bench.py --gpus ${n} --share-devices --allgather-transport host --check-rows 1024 > "${OUT}/bench_n${n}_host.log" 2>&1; echo "bench n=${n} rc=$?"
   grep "^{" "${OUT}/bench_n${n}_host.log" | tail -1 > "${OUT}/bench_n${n}_host.json"; cut -c1-200 "${OUT}/bench_n${n}_host.json"
 done
-{ echo "## config 4: logs in, the walk's fetch modes (weighted.refill: 1 = round 4, 0 = auto)"; timeout 200 python tools/bench_weighted.py --check 2048 --reps 5 --variants "refill=0;refill=1;refill=0";
-  echo "## config 4, values in"; timeout 200 python tools/bench_weighted.py --values --check 0 --reps 5 --variants "refill=0;refill=1;kernel=2,refill=3;refill=0"; } > "${OUT}/bench_weighted.txt" 2>&1; echo "weighted rc=$?"
+{ echo "## config 4: logs in (weighted.refill: 0 = auto: fetcher / walker waves, 13 = the one-wave-per-row kernel, 1 = round 4's; debug 1: rows staged and scanned, not walked; debug 4: the walkers alone)"; timeout 200 python tools/bench_weighted.py --check 2048 --reps 5 --variants "refill=0;refill=13;refill=1;refill=0,debug=1;refill=0,debug=4;refill=5;refill=6;refill=0";
+  echo "## config 4, values in"; timeout 200 python tools/bench_weighted.py --values --check 2048 --reps 5 --variants "refill=0;refill=13;refill=0";
+  echo "## lognormal weights (sigma 2), 20k rows, logs in / values in"; timeout 200 python tools/bench_weighted.py --check 1024 --rows 20000 --dist lognormal --reps 3 --variants "refill=0;refill=13";
+  timeout 200 python tools/bench_weighted.py --values --check 1024 --rows 20000 --dist lognormal --reps 3 --variants "refill=0;refill=13"; } > "${OUT}/bench_weighted.txt" 2>&1; echo "weighted rc=$?"
 { echo "# after the run:"; rocm-smi --showrasinfo all 2>&1 | head -60; dmesg 2>/dev/null | grep -iE "amdgpu|gpu fault|page fault" | tail -20; } >> "${OUT}/box.txt" 2>&1
 find gpurun_out -name "*.db" -delete 2>/dev/null; find gpurun_out -type f -size +8M -delete 2>/dev/null; du -sh gpurun_out | tail -1
