@@ -81,8 +81,10 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * permutations per lane, lane groups share a last slot that holds at most 32 permutations -- num_perm 129..160, 193..224 --, 1 = off),
  * ("minhash.adapt", 0 auto: the context remembers on the device whether the last call's sets mostly defeated the one-candidate proof and
  * starts the next call with the tie-tolerant one, 1 = off),
- * ("weighted.kernel", 0 auto: dense rows of 1024..4096 columns through the one-wave-per-row kernel, 1 = the workgroup-per-row kernel, 2 = one wave
- * per row, sample chunks one after the other), ("weighted.plan", 1 = plan and tables in two launches), ("weighted.rescue", n: a walk's last n lanes
+ * ("weighted.kernel", 0 auto: dense rows of 2052..4096 columns with 65..128 samples through the fetcher / walker kernel, other dense rows of 1024..4096
+ * columns through the one-wave-per-row kernel, 1 = the workgroup-per-row kernel, 2 = one wave per row, sample chunks one after the other),
+ * ("weighted.refill", 0 auto; 13 = auto without the fetcher / walker split, 5 = the split with 8 cached list positions, 6 = with five stripes and six
+ * fetchers, 1 = round 4's plain loads behind the walk, 2 / 3 = the one-wave-per-row kernel's fetch modes; A/B), ("weighted.plan", 1 = plan and tables in two launches), ("weighted.rescue", n: a walk's last n lanes
  * are taken over by the whole wave, 0 auto = 8, < 0 never),
  * ("weighted.path", 0 auto: dense rows through the bound-ordered walk, CSR rows through the row-block kernels,
  * 1 IEEE division for every element, 2 = every element evaluated: dense rows compacted to CSR first),
@@ -90,7 +92,7 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * instead of walked, default 100), ("weighted.split", 0 auto: the waves of a workgroup that share 64 samples split the list of a
  * dense row that is evaluated entry by entry, 1 = one wave per 64 samples), ("weighted.tail", profiling: 1 .. 5 force the share of a call's logs that
  * counts as "above the cut" to 0.5, 1, 2, 4, 8 %; 0 = the cheapest by the plan's estimate), ("weighted.debug", profiling only: 1 = stage and scan the rows without walking them,
- * 2 = skip the scan; results are meaningless),
+ * 2 = skip the scan, 4 = (fetcher / walker kernel) every stripe keeps its first row: the walkers alone; results are meaningless),
  * ("host.chunk_bytes", see
  * mhx_minhash_bulk), ("lsh.sort_bits", bits of (band, digest) mhx_lsh_sort_bands hands to the radix sort,
  * 0 = chosen from n; the order is exact for any value, fewer bits leave more to the clean-up pass),
