@@ -844,6 +844,14 @@ static int launch_walk_plan(mhx_wgen *gen, const float *d_v, bool logs, int64_t 
 // nothing but stores pending at the loop's back edge.
 __device__ __forceinline__ void drain_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }  // vmcnt(0), the other counters untouched
 
+// A walked result's t as the int64 the reference stores (ref: weighted_minhash.py:244, astype(int)).  float -> int64 has no instruction
+// (fifteen VALU ones); when every lane's t fits an int32 -- always, for weights a float32 log can come from -- one v_cvt_i32_f32 and a
+// sign extension do, and give the same integer.  A NaN or a huge t sends the wave down the general conversion.
+__device__ __forceinline__ int64_t t_as_int64(float t) {
+    if (__builtin_expect(__all(__builtin_fabsf(t) < 2147483520.0f), 1)) return (int64_t)(int32_t)t;
+    return (int64_t)t;
+}
+
 // The row scan's three running values over four more entries: six instructions (v_max3 / v_min3 / v_pk_add on the register pairs the
 // load delivered).  The C++ form -- fmaxf(fmaxf(mx, fmaxf(x, y)), fmaxf(z, w)) and so on -- came out as seventeen: maxnum must not
 // return a quieted signalling NaN, so the compiler canonicalises every loaded value first (v_max_f32 v, v, v), and the sum's
@@ -1652,7 +1660,7 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
                         if (my < sample_size) {
                             int64_t *o = out + (d * sample_size + my) * 2;
                             o[0] = held[i].c;
-                            o[1] = (int64_t)held[i].t;
+                            o[1] = t_as_int64(held[i].t);
                         }
                     }
                     ++ch;
@@ -1667,7 +1675,7 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
                     if (my1 < sample_size) {
                         int64_t *o = out + (d * sample_size + my1) * 2;
                         o[0] = held[0].c;
-                        o[1] = (int64_t)held[0].t;
+                        o[1] = t_as_int64(held[0].t);
                     }
                     continue;
                 }
@@ -1713,7 +1721,9 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
         // with one writer: ready (the fetcher that deposited the stripe's k-th row stores k + 1), done[c] (walker c stores k + 1 when
         // it has finished it), scanned (walker 0, only for rows the scan has to look at again).  A deposit waits for both walkers to
         // be done with the row before; rows only ever wait for rows with a smaller i, so nobody waits in a circle.
-        const int n_stripes = split_stripes & 255, n_walk = 2 * n_stripes, n_fetch = n_waves - n_walk;
+        // (more stripes than pairs of walkers: the extra ones hold rows that wait -- the fetchers' and the walkers' rates are close, and with
+        // nothing between them each side's variance stalls the other)
+        const int n_stripes = split_stripes & 255, n_fetch = split_stripes >> 16 & 15, n_walk = n_waves - n_fetch, n_pairs = n_walk >> 1;
         uint32_t *hands = reinterpret_cast<uint32_t *>(lds + 5 * n_cc * wcached * kWave);
         const auto wait_at_least = [&](uint32_t *word, uint32_t want) {
             for (uint32_t polls = 0; __hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want; ++polls) {
@@ -1729,9 +1739,9 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
             const int f = wave - n_walk;
             float4 pre[NV];
             if (f < my_rows) fetch(pre, blockIdx.x + (int64_t)f * gstride);
+            int st = f % n_stripes;
+            uint32_t k = (uint32_t)(f / n_stripes);  // row i is stripe i % n_stripes' (i / n_stripes)-th: kept by counting
             for (int64_t i = f; i < my_rows; i += n_fetch) {
-                const int st = (int)(i % n_stripes);
-                const uint32_t k = (uint32_t)(i / n_stripes);
                 uint32_t *hand = hands + st * kHandWords;
                 float *dst = stripes + (int64_t)st * stripe_words;
                 float mx = -__builtin_inff(), mn = __builtin_inff();
@@ -1753,17 +1763,20 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
                 }
                 post(hand, k + 1);
                 if (i + n_fetch < my_rows && (debug != 4 || i + n_fetch < n_stripes)) fetch(pre, blockIdx.x + (i + n_fetch) * gstride);
+                st += n_fetch;
+                while (st >= n_stripes) st -= n_stripes, ++k;
             }
         } else {
             drain_loads();  // (a walker has issued no load: this only tells the compiler so -- the structurised control flow runs from the fetchers' loop
                             // into this branch, and with it the compiler's idea that sixteen loads may be out: its s_waitcnt vmcnt(2 / 1 / 0) in the
                             // walkers' cached rounds waited for the walkers' own result stores)
-            const int st = wave % n_stripes, c = wave / n_stripes;
-            uint32_t *hand = hands + st * kHandWords;
-            row = stripes + (int64_t)st * stripe_words;
-            list = reinterpret_cast<uint16_t *>(row + ((dim + 3) & ~3));
-            for (int64_t i = st; i < my_rows; i += n_stripes) {
-                const uint32_t k = (uint32_t)(i / n_stripes);
+            const int pair = wave % n_pairs, c = wave / n_pairs;  // the pair's rows: pair, pair + n_pairs, ... -- row i in stripe i % n_stripes
+            int st = pair % n_stripes;
+            uint32_t k = (uint32_t)(pair / n_stripes);  // (counted, not i / n_stripes: a 64-bit division by a run-time value is ~60 scalar instructions per row)
+            for (int64_t i = pair; i < my_rows; i += n_pairs) {
+                uint32_t *hand = hands + st * kHandWords;
+                row = stripes + (int64_t)st * stripe_words;
+                list = reinterpret_cast<uint16_t *>(row + ((dim + 3) & ~3));
                 const int64_t d = blockIdx.x + i * gstride;
                 wait_at_least(hand, k + 1);
                 const uint32_t found = hand[4];
@@ -1785,6 +1798,8 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
                 if (debug != 1 && debug != 2) walk(d, sc, c, c + 1);
                 if (c == 0 && lane == 0) nonempty[d] = sc.n_stored > 0 ? 1 : 0;
                 post(hand + 1 + c, k + 1);
+                st += n_pairs;
+                while (st >= n_stripes) st -= n_stripes, ++k;
             }
         }
         return;
@@ -2096,15 +2111,17 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
             // logs in; with values in, chunk after chunk + the refill right after staging + non-temporal 0.526 -> 0.499 ms.  The early refill
             // alone gains nothing (0.427) and costs the chunk-pair walk 17-32 spilled VGPRs (0.489).  Option weighted.refill: 0 auto,
             // 1 = plain loads behind the walk (round 4), 2 / 3 = force that mode.
-            // weighted.refill 0 (auto): 4096-column rows and 128 samples go to the fetcher / walker split -- six stripes with two walkers each (one per
-            // chunk of samples), four fetchers, 16 cached list positions per chunk (SPLIT 2).  5: the same with 8 cached positions, 6: five stripes
-            // and six fetchers, 13: auto without the split (the one-wave-per-row kernel of this round's first half; A/B).
+            // weighted.refill 0 (auto): 4096-column rows and 128 samples go to the fetcher / walker split (SPLIT 2) -- four fetchers, six pairs of
+            // walkers (one walker per chunk of samples), SEVEN stripes (one holds a row that waits) and 12 cached list positions per chunk.
+            // A/B: 9 = six stripes + 16 positions, 5 = six + 8, 8 = eight + 8, 6 = five stripes, six fetchers, 16 positions; 13 = auto without
+            // the split (the one-wave-per-row kernel of this round's first half).  profiles/r05_ab_weighted_split.txt
             const int64_t rf = ctx->opt_weighted_refill;
-            const int32_t n_stripes2 = rf == 6 ? 5 : 6;
-            const int32_t cached2 = rf == 5 ? kWalkCached : 16;
-            const int32_t split_stripes = n_stripes2 | cached2 << 8;
+            const int32_t n_stripes2 = rf == 6 ? 5 : rf == 8 ? 8 : rf == 5 || rf == 9 ? 6 : 7;
+            const int32_t cached2 = rf == 5 || rf == 8 ? kWalkCached : rf == 6 || rf == 9 ? 16 : 12;
+            const int32_t n_fetch2 = rf == 6 ? 6 : 4;
+            const int32_t split_stripes = n_stripes2 | cached2 << 8 | n_fetch2 << 16;
             const size_t lds2 = 20 * (size_t)n_cc_w * cached2 * kWave + 4 * kSplitHandWords2 + stripe_bytes * (size_t)n_stripes2;
-            const int split = (rf == 0 || rf == 5 || rf == 6) && ctx->opt_weighted_kernel == 0 && nv == 16 && gen->s_pad == 2 * kWave && lds2 <= (size_t)ctx->lds_per_block ? 2 : 0;
+            const int split = (rf == 0 || (rf >= 5 && rf <= 9)) && ctx->opt_weighted_kernel == 0 && nv == 16 && gen->s_pad == 2 * kWave && lds2 <= (size_t)ctx->lds_per_block ? 2 : 0;
             const unsigned blocks2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_rows, ctx->num_cus));  // (SPLIT 2: one workgroup of sixteen waves per CU, rows blockIdx.x + i * gridDim.x)
             const bool auto_fetch = rf == 0 || rf == 13;
             const int fetch_mode = auto_fetch ? (values_are_logs ? 2 : 3) : ctx->opt_weighted_refill == 1 ? 0 : (int)(ctx->opt_weighted_refill & 3);

@@ -83,8 +83,8 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * starts the next call with the tie-tolerant one, 1 = off),
  * ("weighted.kernel", 0 auto: dense rows of 2052..4096 columns with 65..128 samples through the fetcher / walker kernel, other dense rows of 1024..4096
  * columns through the one-wave-per-row kernel, 1 = the workgroup-per-row kernel, 2 = one wave per row, sample chunks one after the other),
- * ("weighted.refill", 0 auto; 13 = auto without the fetcher / walker split, 5 = the split with 8 cached list positions, 6 = with five stripes and six
- * fetchers, 1 = round 4's plain loads behind the walk, 2 / 3 = the one-wave-per-row kernel's fetch modes; A/B), ("weighted.plan", 1 = plan and tables in two launches), ("weighted.rescue", n: a walk's last n lanes
+ * ("weighted.refill", 0 auto; 13 = auto without the fetcher / walker split, 5 / 6 / 8 / 9 = the split with other stripe counts and cached list positions,
+ * 1 = round 4's plain loads behind the walk, 2 / 3 = the one-wave-per-row kernel's fetch modes; A/B), ("weighted.plan", 1 = plan and tables in two launches), ("weighted.rescue", n: a walk's last n lanes
  * are taken over by the whole wave, 0 auto = 8, < 0 never),
  * ("weighted.path", 0 auto: dense rows through the bound-ordered walk, CSR rows through the row-block kernels,
  * 1 IEEE division for every element, 2 = every element evaluated: dense rows compacted to CSR first),

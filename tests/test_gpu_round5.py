@@ -390,7 +390,7 @@ def test_weighted_fetcher_walker_kernel_with_few_and_odd_row_counts(ctx, n, valu
     """The kernel that splits a workgroup into four fetcher and twelve walker waves (4096 columns, 128 samples: config 4's shape) with
     fewer rows than fetchers, than stripes, than workgroups, and a ragged last round; rows of every kind in one call (dense, sparse,
     empty, NaN, inf, heavy-tailed).  Every row against the C oracle, and against the one-wave-per-row kernel it replaced
-    (weighted.refill 13) and the 8-cached-positions / five-stripe settings (5, 6)."""
+    (weighted.refill 13) and the other stripe / cache settings (5, 6, 8, 9)."""
     from datasketch_amd import WeightedMinHashGenerator
 
     dim, s = 4096, 128
@@ -423,7 +423,7 @@ def test_weighted_fetcher_walker_kernel_with_few_and_odd_row_counts(ctx, n, valu
         if not values and i % max(1, n // 40) == 0:  # (values in: the device's log, compared between kernels; logs in: the oracle)
             want = ref.minhash(x[i]).hashvalues
             assert np.array_equal(out[i], want), i
-    for code in (13, 5, 6):
+    for code in (13, 5, 6, 8, 9):
         wctx.set_option("weighted.refill", code)
         try:
             o2, n2 = g.minhash_many_arrays(x)
