@@ -2100,9 +2100,11 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
                        (int32_t)(stripe_bytes / 4), rescue_lanes, d_out, d_nonempty, (int32_t)ctx->opt_weighted_debug, split_stripes)
 #define MHX_WALK_WAVE_NV(LOGS, PAIRS_)            \
     do {                                          \
-        if (nv == 4) MHX_WALK_WAVE(LOGS, 4, PAIRS_);      \
+        if (split == 2 && nv == 4) MHX_WALK_WAVE(LOGS, 4, false, 2, 2);       \
+        else if (split == 2 && nv == 8) MHX_WALK_WAVE(LOGS, 8, false, 2, 2);  \
+        else if (split == 2) MHX_WALK_WAVE(LOGS, 16, false, 2, 2);            \
+        else if (nv == 4) MHX_WALK_WAVE(LOGS, 4, PAIRS_);      \
         else if (nv == 8) MHX_WALK_WAVE(LOGS, 8, PAIRS_); \
-        else if (split == 2) MHX_WALK_WAVE(LOGS, 16, false, 2, 2); \
         else if (fetch_mode == 2) MHX_WALK_WAVE(LOGS, 16, PAIRS_, 2); \
         else if (fetch_mode == 3) MHX_WALK_WAVE(LOGS, 16, PAIRS_, 3); \
         else MHX_WALK_WAVE(LOGS, 16, PAIRS_);             \
@@ -2121,7 +2123,7 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
             const int32_t n_fetch2 = rf == 6 ? 6 : 4;
             const int32_t split_stripes = n_stripes2 | cached2 << 8 | n_fetch2 << 16;
             const size_t lds2 = 20 * (size_t)n_cc_w * cached2 * kWave + 4 * kSplitHandWords2 + stripe_bytes * (size_t)n_stripes2;
-            const int split = (rf == 0 || (rf >= 5 && rf <= 9)) && ctx->opt_weighted_kernel == 0 && nv == 16 && gen->s_pad == 2 * kWave && lds2 <= (size_t)ctx->lds_per_block ? 2 : 0;
+            const int split = (rf == 0 || (rf >= 5 && rf <= 9)) && ctx->opt_weighted_kernel == 0 && gen->s_pad == 2 * kWave && lds2 <= (size_t)ctx->lds_per_block ? 2 : 0;
             const unsigned blocks2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_rows, ctx->num_cus));  // (SPLIT 2: one workgroup of sixteen waves per CU, rows blockIdx.x + i * gridDim.x)
             const bool auto_fetch = rf == 0 || rf == 13;
             const int fetch_mode = auto_fetch ? (values_are_logs ? 2 : 3) : ctx->opt_weighted_refill == 1 ? 0 : (int)(ctx->opt_weighted_refill & 3);

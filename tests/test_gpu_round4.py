@@ -86,8 +86,8 @@ def _case_id(dim, s):
 # ... and dims the one-wave-per-row kernel takes (1024 <= dim <= 4096, a multiple of 4): both kernels, every row
 _CASES = [(d, s) for d in _DIMS for s in _SAMPLES] + [(1024, 300), (1024, 513), (4096, 300), (4096, 513), (4096, 128), (2048, 128), (1500, 65), (4092, 129),
                                                        (3000, 1),
-                                                       # round 5: 2048 < dim <= 4096 with 65 .. 128 samples is the fetcher / walker kernel's
-                                                       (4092, 128), (2052, 100), (3000, 65), (4096, 127)]
+                                                       # round 5: 1024 <= dim <= 4096 (a multiple of 4) with 65 .. 128 samples is the fetcher / walker kernel's
+                                                       (4092, 128), (2052, 100), (3000, 65), (4096, 127), (1024, 128), (1028, 100)]
 
 
 def _wave_kernel_takes(dim):

@@ -385,15 +385,15 @@ def test_minhash_mode_word_is_readable_follows_the_corpus_and_resets(ctx):
 
 # ------------------------------------------------------------------ config 4: fetcher and walker waves
 @pytest.mark.parametrize("values", [False, True])
-@pytest.mark.parametrize("n", [1, 3, 5, 7, 13, 255, 257, 3000])
-def test_weighted_fetcher_walker_kernel_with_few_and_odd_row_counts(ctx, n, values):
-    """The kernel that splits a workgroup into four fetcher and twelve walker waves (4096 columns, 128 samples: config 4's shape) with
+@pytest.mark.parametrize("n,dim", [(1, 4096), (3, 4096), (5, 4096), (7, 4096), (13, 4096), (255, 4096), (257, 4096), (3000, 4096), (6, 1536), (777, 1536), (9, 1024), (1500, 2048)])
+def test_weighted_fetcher_walker_kernel_with_few_and_odd_row_counts(ctx, n, dim, values):
+    """The kernel that splits a workgroup into four fetcher and twelve walker waves (1024 .. 4096 columns, 128 samples; config 4's shape first) with
     fewer rows than fetchers, than stripes, than workgroups, and a ragged last round; rows of every kind in one call (dense, sparse,
     empty, NaN, inf, heavy-tailed).  Every row against the C oracle, and against the one-wave-per-row kernel it replaced
     (weighted.refill 13) and the other stripe / cache settings (5, 6, 8, 9)."""
     from datasketch_amd import WeightedMinHashGenerator
 
-    dim, s = 4096, 128
+    s = 128
     rng = np.random.RandomState(1000 + n)
     x = rng.uniform(0, 1, (n, dim)).astype(np.float32)
     kinds = rng.randint(0, 8, n)
@@ -408,7 +408,7 @@ def test_weighted_fetcher_walker_kernel_with_few_and_odd_row_counts(ctx, n, valu
             x[i, rng.random_sample(dim) >= 0.5] = 0
     if n >= 7:
         x[5, 17] = np.nan
-        x[6, 4000] = np.inf
+        x[6, dim - 96] = np.inf
     g = WeightedMinHashGenerator(dim, s, seed=5, gpu_mode="always", device_log=values)
     wctx, _ = g._device_handle()
     out, ne = g.minhash_many_arrays(x)
