@@ -4,6 +4,7 @@
   else the numpy path, never an error) -- with one RuntimeWarning when the host has an AMD GPU but libmhx does not load;
   `gpu_mode='always'` stays strict (ref :272-275).
 """
+import os
 import warnings
 
 import numpy as np
@@ -11,6 +12,8 @@ import pytest
 
 from datasketch_amd import MinHash, WeightedMinHashGenerator, _native, lsh_bulk
 from datasketch_amd.b_bit_minhash import pack_matrix
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture
@@ -156,3 +159,23 @@ def test_cpu_baseline_times_the_real_reference_when_it_is_named(monkeypatch):
     ref = bench.cpu_baseline(tokens, a, b, 2000, 16, 64, None, seed=1)
     assert ref["kind"] == "reference" and ref["reference_over_port_measured"] == "in this run" and ref["cores"] >= 1
     assert 0.5 < ref["reference_over_port_time"] < 5 and "DATASKETCH_REFERENCE" in ref["sample"]
+
+
+def test_the_rccl_stand_in_exports_every_entry_point_the_binding_resolves(tmp_path):
+    """tests/fake_rccl.c (what the GPU tests load through MHX_RCCL_LIBRARY to run the RCCL binding with world > 1 on one device) must
+    keep up with csrc/comm.hip: every "nccl..." name the binding hands to dlsym is exported by the stand-in.  Compiles without a GPU."""
+    import re
+    import shutil
+    import subprocess
+
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if not hipcc:
+        pytest.skip("no hipcc here")
+    wanted = set(re.findall(r'"(nccl[A-Za-z]+)"', open(os.path.join(ROOT, "datasketch_amd", "csrc", "comm.hip")).read()))
+    assert {"ncclAllGather", "ncclBroadcast", "ncclGroupStart", "ncclGroupEnd", "ncclCommInitRank"} <= wanted
+    out = str(tmp_path / "libfake_rccl.so")
+    p = subprocess.run([hipcc, "-x", "c", "-shared", "-fPIC", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", os.path.join(ROOT, "tests", "fake_rccl.c"),
+                        "-o", out, "-L/opt/rocm/lib", "-lamdhip64"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    exported = set(re.findall(r" T (nccl[A-Za-z]+)", subprocess.run(["nm", "-D", out], capture_output=True, text=True).stdout))
+    assert wanted <= exported, wanted - exported
