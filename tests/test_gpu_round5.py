@@ -310,6 +310,22 @@ def test_bench_ranks_share_one_gpu_and_run_config_3_end_to_end(world):
         assert len(c3["per_rank_ms"][stage]) == world and all(v > 0 for v in c3["per_rank_ms"][stage]), stage
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_bench_rccl_branch_runs_to_the_end_through_the_stand_in(fake_rccl, world):
+    """The command line the driver uses on an 8-GPU node, with the one thing a 1-GPU box cannot give it -- RCCL across devices -- replaced
+    by the stand-in library (MHX_RCCL_LIBRARY; named in the line): transport "rccl", the all-gather probe, extra.c3_sharded with its in-place
+    gather and parity gates.  What runs is every line of bench.py and libmhx the multi-GPU run will run, except RCCL itself."""
+    line = _line(_bench(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--sets", "20000", "--c3-rows", "30000", "--check-rows", "256",
+                         "--share-devices", "--clock-warmup", "0"], env={"MHX_RCCL_LIBRARY": fake_rccl}))
+    assert line["n_gpus"] == world and line["config"]["allgather_transport"] == "rccl" and line["config"]["rccl_library_override"] == fake_rccl
+    ag = line["allgather"]
+    assert "error" not in ag and ag["transport"] == "rccl" and ag["rccl_ranks_seen"] == [world] * world
+    c3 = line["extra"]["c3_sharded"]
+    assert "error" not in c3, c3
+    assert c3["rows_total"] == world * 30000 and c3["allgather"]["transport"] == "rccl"
+    assert c3["allgather"]["bytes_received_per_gpu"] == (world - 1) * 30000 * 256 * 4
+
+
 def test_bench_allgather_inside_every_step_over_the_host_transport():
     line = _line(_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--sets", "20000", "--check-rows", "128", "--share-devices", "--allgather",
                          "--allgather-transport", "host", "--no-c3-sharded"]))
