@@ -1496,8 +1496,9 @@ __global__ __launch_bounds__(256, 4) void weighted_walk_dense_kernel(const float
 // SIMD idle (one-wave-per-row kernel: walkers alone take 0.35 ms for config 4 at two waves per SIMD, the rows' stream 0.26).  Split,
 // the walkers need no registers for rows in flight: sixteen waves of <= 128 VGPRs fit a CU instead of eight of 250 -- twelve walkers
 // (a row's two chunks of 64 samples go to two waves) and four fetchers.  See the SPLIT == 2 block below for the hand-over.
-constexpr int kHandWords = 8;              // SPLIT 2: per stripe {ready, done[0], done[1], scanned, what the fetcher found, n_stored, n_list, flags}
-constexpr int kSplitHandWords2 = 64;       // ... eight stripes at most
+constexpr int kHandWords = 12;             // SPLIT 2: per stripe {ready, scanned, what the fetcher found, n_stored, n_list, flags, done[0 .. 5] (one per chunk of samples)}
+constexpr int kHandDone = 6;
+constexpr int kSplitHandWords2 = 128;      // ... eight stripes at most
 constexpr uint32_t kSpinLimit = 1u << 24;  // polls (each ~100 cycles) a wave waits for the other side before it traps
 template <bool LOGS, int NV, bool PAIRS, int FETCH = 0, int SPLIT = 0>  // NV: 16-byte loads per lane that hold a row (dim <= 256 NV); PAIRS: two chunks of samples walked as one instruction stream
 __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_kernel(const float *__restrict__ x, int64_t n_rows, int32_t dim,
@@ -1723,7 +1724,8 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
         // be done with the row before; rows only ever wait for rows with a smaller i, so nobody waits in a circle.
         // (more stripes than pairs of walkers: the extra ones hold rows that wait -- the fetchers' and the walkers' rates are close, and with
         // nothing between them each side's variance stalls the other)
-        const int n_stripes = split_stripes & 255, n_fetch = split_stripes >> 16 & 15, n_walk = n_waves - n_fetch, n_pairs = n_walk >> 1;
+        const int n_stripes = split_stripes & 255, n_fetch = split_stripes >> 16 & 15, n_walk = n_waves - n_fetch;
+        const int n_group = chunks, n_pairs = n_walk / n_group;  // (a group: the `chunks` walkers of one row; chunks divides n_walk -- the launcher's rule)
         uint32_t *hands = reinterpret_cast<uint32_t *>(lds + 5 * n_cc * wcached * kWave);
         const auto wait_at_least = [&](uint32_t *word, uint32_t want) {
             for (uint32_t polls = 0; __hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want; ++polls) {
@@ -1751,15 +1753,14 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
                 const float sum = sum2.x + sum2.y;
                 const bool any_above = __any(LOGS ? mx > lcut : mx > vcut);
                 const bool any_odd = __any(sum != sum || (LOGS ? mn == -__builtin_inff() : mn <= 0.0f));
-                wait_at_least(hand + 1, k);
-                wait_at_least(hand + 2, k);
+                for (int w = 0; w < n_group; ++w) wait_at_least(hand + kHandDone + w, k);
                 if (debug != 4 || k == 0) {  // (debug 4, profiling only, results wrong: every stripe keeps its first row -- the walkers' side alone)
 #pragma unroll
                     for (int u = 0; u < NV; ++u) {
                         const int c = (u * kWave + lane) * 4;
                         *reinterpret_cast<float4 *>(dst + (c < dim ? c : dim - 4)) = pre[u];
                     }
-                    if (lane == 0) hand[4] = (any_above ? 1u : 0u) | (any_odd ? 2u : 0u);
+                    if (lane == 0) hand[2] = (any_above ? 1u : 0u) | (any_odd ? 2u : 0u);
                 }
                 post(hand, k + 1);
                 if (i + n_fetch < my_rows && (debug != 4 || i + n_fetch < n_stripes)) fetch(pre, blockIdx.x + (i + n_fetch) * gstride);
@@ -1779,25 +1780,25 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
                 list = reinterpret_cast<uint16_t *>(row + ((dim + 3) & ~3));
                 const int64_t d = blockIdx.x + i * gstride;
                 wait_at_least(hand, k + 1);
-                const uint32_t found = hand[4];
+                const uint32_t found = hand[2];
                 Scanned sc{dim, 0, false, false, false, LOGS};
                 if (found != 0 || (int64_t)dim * 1000 <= (int64_t)direct_permille * dim) {  // (wave-uniform) the scan has to look again: walker 0 does, and says what it saw
                     if (c == 0) {
                         sc = scan((found & 1) != 0, (found & 2) != 0);
                         if (lane == 0) {
-                            hand[5] = (uint32_t)sc.n_stored, hand[6] = (uint32_t)sc.n_list;
-                            hand[7] = (sc.has_nan ? 1u : 0u) | (sc.by_entry ? 2u : 0u) | (sc.listable ? 4u : 0u) | (sc.logs_staged ? 8u : 0u);
+                            hand[3] = (uint32_t)sc.n_stored, hand[4] = (uint32_t)sc.n_list;
+                            hand[5] = (sc.has_nan ? 1u : 0u) | (sc.by_entry ? 2u : 0u) | (sc.listable ? 4u : 0u) | (sc.logs_staged ? 8u : 0u);
                         }
-                        post(hand + 3, k + 1);
+                        post(hand + 1, k + 1);
                     } else {
-                        wait_at_least(hand + 3, k + 1);
-                        const uint32_t bits = hand[7];
-                        sc = Scanned{(int)hand[5], (int)hand[6], (bits & 1) != 0, (bits & 2) != 0, (bits & 4) != 0, (bits & 8) != 0};
+                        wait_at_least(hand + 1, k + 1);
+                        const uint32_t bits = hand[5];
+                        sc = Scanned{(int)hand[3], (int)hand[4], (bits & 1) != 0, (bits & 2) != 0, (bits & 4) != 0, (bits & 8) != 0};
                     }
                 }
                 if (debug != 1 && debug != 2) walk(d, sc, c, c + 1);
                 if (c == 0 && lane == 0) nonempty[d] = sc.n_stored > 0 ? 1 : 0;
-                post(hand + 1 + c, k + 1);
+                post(hand + kHandDone + c, k + 1);
                 st += n_pairs;
                 while (st >= n_stripes) st -= n_stripes, ++k;
             }
@@ -2118,12 +2119,17 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
             // A/B: 9 = six stripes + 16 positions, 5 = six + 8, 8 = eight + 8, 6 = five stripes, six fetchers, 16 positions; 13 = auto without
             // the split (the one-wave-per-row kernel of this round's first half).  profiles/r05_ab_weighted_split.txt
             const int64_t rf = ctx->opt_weighted_refill;
-            const int32_t n_stripes2 = rf == 6 ? 5 : rf == 8 ? 8 : rf == 5 || rf == 9 ? 6 : 7;
+            // sample counts: a row's chunks of 64 samples go to as many walkers -- 2, 3, 4 or 6 chunks (65 .. 256 and 321 .. 384 samples) share out twelve
+            // walkers as 6, 4, 3 or 2 rows at a time, with one stripe more than rows being walked
+            const int32_t chunks_w = gen->s_pad / kWave;
+            const bool chunks_ok = chunks_w == 2 || chunks_w == 3 || chunks_w == 4 || chunks_w == 6;
+            const int32_t groups2 = chunks_ok ? 12 / chunks_w : 1;
+            const int32_t n_stripes2 = chunks_w != 2 ? groups2 + 1 : rf == 6 ? 5 : rf == 8 ? 8 : rf == 5 || rf == 9 ? 6 : 7;
             const int32_t cached2 = rf == 5 || rf == 8 ? kWalkCached : rf == 6 || rf == 9 ? 16 : 12;
-            const int32_t n_fetch2 = rf == 6 ? 6 : 4;
+            const int32_t n_fetch2 = rf == 6 && chunks_w == 2 ? 6 : 4;
             const int32_t split_stripes = n_stripes2 | cached2 << 8 | n_fetch2 << 16;
             const size_t lds2 = 20 * (size_t)n_cc_w * cached2 * kWave + 4 * kSplitHandWords2 + stripe_bytes * (size_t)n_stripes2;
-            const int split = (rf == 0 || (rf >= 5 && rf <= 9)) && ctx->opt_weighted_kernel == 0 && gen->s_pad == 2 * kWave && lds2 <= (size_t)ctx->lds_per_block ? 2 : 0;
+            const int split = (rf == 0 || (rf >= 5 && rf <= 9)) && ctx->opt_weighted_kernel == 0 && chunks_ok && lds2 <= (size_t)ctx->lds_per_block ? 2 : 0;
             const unsigned blocks2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_rows, ctx->num_cus));  // (SPLIT 2: one workgroup of sixteen waves per CU, rows blockIdx.x + i * gridDim.x)
             const bool auto_fetch = rf == 0 || rf == 13;
             const int fetch_mode = auto_fetch ? (values_are_logs ? 2 : 3) : ctx->opt_weighted_refill == 1 ? 0 : (int)(ctx->opt_weighted_refill & 3);

@@ -81,7 +81,7 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * permutations per lane, lane groups share a last slot that holds at most 32 permutations -- num_perm 129..160, 193..224 --, 1 = off),
  * ("minhash.adapt", 0 auto: the context remembers on the device whether the last call's sets mostly defeated the one-candidate proof and
  * starts the next call with the tie-tolerant one, 1 = off),
- * ("weighted.kernel", 0 auto: dense rows of 1024..4096 columns with 65..128 samples through the fetcher / walker kernel, other dense rows of 1024..4096
+ * ("weighted.kernel", 0 auto: dense rows of 1024..4096 columns with 65..256 or 321..384 samples through the fetcher / walker kernel, other dense rows of 1024..4096
  * columns through the one-wave-per-row kernel, 1 = the workgroup-per-row kernel, 2 = one wave per row, sample chunks one after the other),
  * ("weighted.refill", 0 auto; 13 = auto without the fetcher / walker split, 5 / 6 / 8 / 9 = the split with other stripe counts and cached list positions,
  * 1 = round 4's plain loads behind the walk, 2 / 3 = the one-wave-per-row kernel's fetch modes; A/B), ("weighted.plan", 1 = plan and tables in two launches), ("weighted.rescue", n: a walk's last n lanes

@@ -86,8 +86,10 @@ def _case_id(dim, s):
 # ... and dims the one-wave-per-row kernel takes (1024 <= dim <= 4096, a multiple of 4): both kernels, every row
 _CASES = [(d, s) for d in _DIMS for s in _SAMPLES] + [(1024, 300), (1024, 513), (4096, 300), (4096, 513), (4096, 128), (2048, 128), (1500, 65), (4092, 129),
                                                        (3000, 1),
-                                                       # round 5: 1024 <= dim <= 4096 (a multiple of 4) with 65 .. 128 samples is the fetcher / walker kernel's
-                                                       (4092, 128), (2052, 100), (3000, 65), (4096, 127), (1024, 128), (1028, 100)]
+                                                       # round 5: 1024 <= dim <= 4096 (a multiple of 4) with 65 .. 256 or 321 .. 384 samples is the fetcher / walker kernel's
+                                                       (4092, 128), (2052, 100), (3000, 65), (4096, 127), (1024, 128), (1028, 100),
+                                                       # ... and with 3, 4 or 6 chunks of 64 samples (three, four, six walkers per row)
+                                                       (4096, 192), (4096, 256), (2048, 384), (1024, 200)]
 
 
 def _wave_kernel_takes(dim):
