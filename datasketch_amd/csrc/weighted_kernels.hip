@@ -1716,16 +1716,15 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
         if (lane == 0) nonempty[d_] = sc_.n_stored > 0 ? 1 : 0;                                               \
     } while (0)
     if constexpr (SPLIT == 2) {
-        // Stripes with TWO walkers each (one per chunk of 64 samples; s_pad = 128) and a few fetchers that deposit rows into whichever
-        // stripe is next: n_stripes stripes, 2 n_stripes walkers, the remaining waves fetch.  The workgroup's i-th row goes to stripe
-        // i % n_stripes as that stripe's (i / n_stripes)-th row and is fetched by fetcher i % n_fetch.  Every hand-over is a counter
-        // with one writer: ready (the fetcher that deposited the stripe's k-th row stores k + 1), done[c] (walker c stores k + 1 when
-        // it has finished it), scanned (walker 0, only for rows the scan has to look at again).  A deposit waits for both walkers to
-        // be done with the row before; rows only ever wait for rows with a smaller i, so nobody waits in a circle.
-        // (more stripes than pairs of walkers: the extra ones hold rows that wait -- the fetchers' and the walkers' rates are close, and with
-        // nothing between them each side's variance stalls the other)
+        // n_walk walkers in GROUPS of `chunks` (one walker per chunk of 64 samples; a group walks one row at a time), n_fetch fetchers, n_stripes
+        // stripes.  The workgroup's i-th row (blockIdx.x + i * gridDim.x) goes to stripe i % n_stripes as that stripe's (i / n_stripes)-th row, is
+        // fetched by fetcher i % n_fetch and walked by group i % n_groups.  Every hand-over is a counter in LDS with one writer at a time:
+        // ready (the fetcher that deposited the stripe's k-th row stores k + 1), done[c] (the walker of chunk c stores k + 1 when it has finished
+        // it), scanned (the walker of chunk 0, only for rows the scan has to look at again).  A deposit waits for every chunk's walker to be done
+        // with the stripe's row before; rows only ever wait for rows with a smaller i, so nobody waits in a circle.  One stripe more than
+        // groups: a row that waits in LDS (the fetchers' and the walkers' rates are close; 3 % on values in and on heavy-tailed rows).
         const int n_stripes = split_stripes & 255, n_fetch = split_stripes >> 16 & 15, n_walk = n_waves - n_fetch;
-        const int n_group = chunks, n_pairs = n_walk / n_group;  // (a group: the `chunks` walkers of one row; chunks divides n_walk -- the launcher's rule)
+        const int n_group = chunks, n_pairs = n_walk / n_group;  // (n_pairs: the number of groups -- pairs at 128 samples; chunks divides n_walk: the launcher's rule)
         uint32_t *hands = reinterpret_cast<uint32_t *>(lds + 5 * n_cc * wcached * kWave);
         const auto wait_at_least = [&](uint32_t *word, uint32_t want) {
             for (uint32_t polls = 0; __hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want; ++polls) {
@@ -1771,7 +1770,7 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
             drain_loads();  // (a walker has issued no load: this only tells the compiler so -- the structurised control flow runs from the fetchers' loop
                             // into this branch, and with it the compiler's idea that sixteen loads may be out: its s_waitcnt vmcnt(2 / 1 / 0) in the
                             // walkers' cached rounds waited for the walkers' own result stores)
-            const int pair = wave % n_pairs, c = wave / n_pairs;  // the pair's rows: pair, pair + n_pairs, ... -- row i in stripe i % n_stripes
+            const int pair = wave % n_pairs, c = wave / n_pairs;  // group `pair`, chunk c; the group's rows: pair, pair + n_pairs, ... -- row i in stripe i % n_stripes
             int st = pair % n_stripes;
             uint32_t k = (uint32_t)(pair / n_stripes);  // (counted, not i / n_stripes: a 64-bit division by a run-time value is ~60 scalar instructions per row)
             for (int64_t i = pair; i < my_rows; i += n_pairs) {
