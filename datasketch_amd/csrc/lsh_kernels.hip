@@ -893,6 +893,12 @@ int launch_lsh_sort_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_
             hipLaunchKernelGGL(digests_to_band_major_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)ctx->num_cus * 16))), dim3(256), 0, ctx->stream,
                                (const uint64_t *)d_sig, n, __builtin_ctz((unsigned)bands), (uint64_t *)ctx->scratch[4]);
             if (hipGetLastError() == hipSuccess) d_in = ctx->scratch[4], in_dtype = kSigDigestsBM;
+        } else if ((sig_dtype == MHX_U32 || sig_dtype == MHX_U64) && ctx->opt_lsh_prehash != 1 && bands >= 2 && bands <= 64 && (bands & (bands - 1)) == 0 &&
+                   ctx->ensure_scratch(4, sizeof(uint64_t) * (size_t)n * (size_t)bands) == MHX_OK) {
+            // a signature matrix: its band digests first, band-major (band_digest_bm_kernel: one read of the matrix at the stream's rate), then the
+            // bucketing of the digests -- hashing r values inside the scatter pass's load loop cost more than the extra 8 bytes per key written and
+            // read again (1.25M x 256 uint32, 32 x 8: 0.90 ms against 0.31 + 0.48).  Option lsh.prehash 1: hash inside the scatter pass.
+            if (launch_band_digests(ctx, d_sig, sig_dtype, n, k, bands, r, (uint64_t *)ctx->scratch[4], MHX_BAND_MAJOR) == MHX_OK) d_in = ctx->scratch[4], in_dtype = kSigDigestsBM;
         }
         if (int rc = launch_lsh_bucket_bands(ctx, d_in, in_dtype, n, k, bands, r, d_sorted_digests, d_sorted_rows, &done)) return rc;
         if (done) return MHX_OK;

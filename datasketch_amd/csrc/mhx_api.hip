@@ -384,6 +384,7 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "lsh.chunk")) ctx->opt_lsh_chunk = value;
     else if (!strcmp(key, "pack.fused")) ctx->opt_pack_fused = value;
     else if (!strcmp(key, "weighted.refill")) ctx->opt_weighted_refill = value;
+    else if (!strcmp(key, "lsh.prehash")) ctx->opt_lsh_prehash = value;
     else return fail(MHX_ERR_INVALID, "unknown option '%s'", key);
     return MHX_OK;
 }

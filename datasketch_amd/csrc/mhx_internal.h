@@ -88,6 +88,7 @@ struct mhx_ctx {
     int64_t opt_lsh_sort = 0;       // mhx_lsh_sort_bands: 0 auto (two-pass bucketing, radix sort when a bin would overflow), 1 radix sort
     int64_t opt_lsh_gather = 0;     // mhx_lsh_sort_bands: 1 = gather the full digests after the sort (the fallback path) even when they could ride along
     int64_t opt_lsh_sort_bits = 0;  // mhx_lsh_sort_bands: bits of (band, digest) the radix sort orders by; 0 = from n
+    int64_t opt_lsh_prehash = 0;    // mhx_lsh_sort_bands on a signature matrix: 0 auto (band digests first, then the bucketing), 1 = hash inside the scatter pass (A/B)
     int64_t opt_lsh_chunk = 0;      // bucketing: rows per thread of a scatter pass over a unit-stride source: 0 auto (16), 8 = eight (A/B)
     int64_t opt_lsh_levels = 0;     // bucketing: 0 auto (two scatter levels beyond 2^10 bins per band), 2 = two levels whenever there are at least 4 bins
     int64_t opt_pack_fused = 0;     // mhx_bbit_pack_band_digests_dev: 0 auto (one read of the matrix where the shape allows), 1 = always the two kernels

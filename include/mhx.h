@@ -97,6 +97,8 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * mhx_minhash_bulk), ("lsh.sort_bits", bits of (band, digest) mhx_lsh_sort_bands hands to the radix sort,
  * 0 = chosen from n; the order is exact for any value, fewer bits leave more to the clean-up pass),
  * ("lsh.gather", 1 = gather the full digests after the sort instead of letting them ride through it),
+ * ("lsh.prehash", mhx_lsh_sort_bands on a signature matrix: 0 auto = band digests first (one pass at the stream's rate), then the bucketing; 1 = hash inside
+ * the bucketing's first pass),
  * ("lsh.sort", 0 auto: mhx_lsh_sort_bands buckets the bands in two passes and falls back to the radix sort when a bin
  * overflows or n > 12M, 1 = radix sort always). */
 MHX_API int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value);

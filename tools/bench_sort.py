@@ -22,8 +22,9 @@ def main():
     d_sig = ctx.to_device(sig)
     d_dig, d_rows = ctx.alloc(n * b * 8), ctx.alloc(n * b * 4)
     first = None
-    for mode in (0, 1, 0, 1):
+    for mode, prehash in ((0, 0), (0, 1), (1, 0), (0, 0), (0, 1)):
         ctx.set_option("lsh.sort", mode)
+        ctx.set_option("lsh.prehash", prehash)
         run = lambda: _native.check(ctx.lib.mhx_lsh_sort_bands_dev_typed(ctx.handle, d_sig.ptr, _native.MHX_U32, n, k, b, r, d_dig.ptr, d_rows.ptr))
         run()
         ctx.synchronize()
@@ -37,7 +38,7 @@ def main():
             ctx.synchronize()
             ms.append(e0.elapsed_ms(e1))
         dig, rows = d_dig.download((b, n), np.uint64), d_rows.download((b, n), np.uint32)
-        rec = {"lsh.sort": mode, "ms_min": round(min(ms), 4), "ms": [round(x, 4) for x in ms], "keys_per_s": n * b / (min(ms) * 1e-3)}
+        rec = {"lsh.sort": mode, "lsh.prehash": prehash, "ms_min": round(min(ms), 4), "ms": [round(x, 4) for x in ms], "keys_per_s": n * b / (min(ms) * 1e-3)}
         if first is None:
             first = (dig, rows)
             rec["sorted"] = bool((dig[:, 1:] >= dig[:, :-1]).all())  # uint64 compared as uint64 (an int64 view turns digests >= 2^63 negative)
@@ -45,6 +46,7 @@ def main():
             rec["equal_to_first"] = bool(np.array_equal(dig, first[0]) and np.array_equal(rows, first[1]))
         print(json.dumps(rec), flush=True)
     ctx.set_option("lsh.sort", 0)
+    ctx.set_option("lsh.prehash", 0)
 
 
 if __name__ == "__main__":
