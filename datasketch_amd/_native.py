@@ -109,6 +109,8 @@ _PROTOTYPES = {
     "mhx_comm_info": [_vp, ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int), ctypes.POINTER(_int)],
     "mhx_comm_allgather_dev": [_vp, _vp, _vp, _sz],
     "mhx_comm_allgatherv_dev": [_vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)],
+    "mhx_comm_exchange_dev": [_vp, _vp, _vp, _i32, ctypes.POINTER(_i32), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                              _i32, ctypes.POINTER(_i32), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)],
 }
 _RESTYPE = {"mhx_last_error": ctypes.c_char_p, "mhx_version": ctypes.c_char_p}
 
@@ -856,6 +858,18 @@ class Communicator:
         off = (ctypes.c_uint64 * n)(*[int(v) for v in offsets])
         siz = (ctypes.c_uint64 * n)(*[int(v) for v in sizes])
         check(self.ctx.lib.mhx_comm_allgatherv_dev(self.handle, _vp(d_send), _vp(d_recv), off, siz))
+
+    def exchange_dev(self, d_send: int, d_recv: int, sends, recvs) -> None:
+        """One grouped launch of ncclSend / ncclRecv (mhx_comm_exchange_dev): ``sends`` = [(peer, offset, bytes)] out of
+        ``d_send``, ``recvs`` = [(peer, offset, bytes)] into ``d_recv``; between two ranks messages match in list order."""
+        def lists(msgs):
+            n = len(msgs)
+            return (n, (_i32 * max(n, 1))(*[int(m[0]) for m in msgs]), (ctypes.c_uint64 * max(n, 1))(*[int(m[1]) for m in msgs]),
+                    (ctypes.c_uint64 * max(n, 1))(*[int(m[2]) for m in msgs]))
+
+        ns, sp, so, sb = lists(sends)
+        nr, rp, ro, rb = lists(recvs)
+        check(self.ctx.lib.mhx_comm_exchange_dev(self.handle, _vp(d_send), _vp(d_recv), ns, sp, so, sb, nr, rp, ro, rb))
 
     def close(self) -> None:
         if getattr(self, "handle", None):

@@ -25,6 +25,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
@@ -59,6 +61,8 @@ Rccl &rccl() {
         MHX_SYM(CommDestroy, "ncclCommDestroy")
         MHX_SYM(AllGather, "ncclAllGather")
         MHX_SYM(Broadcast, "ncclBroadcast")
+        MHX_SYM(Send, "ncclSend")
+        MHX_SYM(Recv, "ncclRecv")
         MHX_SYM(GroupStart, "ncclGroupStart")
         MHX_SYM(GroupEnd, "ncclGroupEnd")
         MHX_SYM(GetErrorString, "ncclGetErrorString")
@@ -188,6 +192,69 @@ int mhx_comm_allgatherv_dev(mhx_comm *comm, const void *d_send, void *d_recv, co
     }
     const ncclResult_t end = rccl().GroupEnd();  // always closed: an open group would swallow the next call
     if (first != ncclSuccess) return mhx::fail(MHX_ERR_COMM, "ncclBroadcast failed: %s", rccl().GetErrorString(first));
+    if (end != ncclSuccess) return mhx::fail(MHX_ERR_COMM, "ncclGroupEnd failed: %s", rccl().GetErrorString(end));
+    return MHX_OK;
+}
+
+// A grouped point-to-point exchange -- the by-band exchange of band digests (dist.py: exchange_band_digests_dev): rank p keeps its
+// rows' digests band-major [bands, n_p]; rank q, which builds the hashtables of bands [lo_q, hi_q) (ref: datasketch/lsh.py:199 -- one
+// independent table per band), receives from every p the runs of those bands and places them at [band - lo_q][begin_p ...) of its
+// [hi_q - lo_q, N] matrix.  One ncclSend / ncclRecv per run inside ONE group call (RCCL fuses them into one launch and pairs the k-th
+// send of p to q with the k-th receive of q from p); a run a rank owes itself is a device copy on the same stream; runs of zero bytes
+// are dropped (sizes are common knowledge, so both ends drop the same ones).
+int mhx_comm_exchange_dev(mhx_comm *comm, const void *d_send, void *d_recv, int32_t n_send, const int32_t *send_peers,
+                          const uint64_t *send_offsets, const uint64_t *send_bytes, int32_t n_recv, const int32_t *recv_peers,
+                          const uint64_t *recv_offsets, const uint64_t *recv_bytes) {
+    if (!comm) return mhx::fail(MHX_ERR_INVALID, "comm is NULL");
+    MHX_REQUIRE(n_send >= 0 && n_recv >= 0, "negative message count");
+    MHX_REQUIRE(n_send == 0 || (send_peers && send_offsets && send_bytes), "NULL send list");
+    MHX_REQUIRE(n_recv == 0 || (recv_peers && recv_offsets && recv_bytes), "NULL receive list");
+    uint64_t out_bytes = 0, in_bytes = 0;
+    for (int i = 0; i < n_send; ++i) {
+        MHX_REQUIRE(send_peers[i] >= 0 && send_peers[i] < comm->world, "send %d: peer %d outside the communicator of %d ranks", i, send_peers[i], comm->world);
+        out_bytes += send_bytes[i];
+    }
+    for (int i = 0; i < n_recv; ++i) {
+        MHX_REQUIRE(recv_peers[i] >= 0 && recv_peers[i] < comm->world, "receive %d: peer %d outside the communicator of %d ranks", i, recv_peers[i], comm->world);
+        in_bytes += recv_bytes[i];
+    }
+    MHX_REQUIRE((d_send || out_bytes == 0) && (d_recv || in_bytes == 0), "NULL device pointer");
+    // what this rank owes itself: the k-th such send goes to the k-th such receive, sizes must agree
+    {
+        int r = 0;
+        for (int i = 0; i < n_send; ++i) {
+            if (send_peers[i] != comm->rank || send_bytes[i] == 0) continue;
+            while (r < n_recv && (recv_peers[r] != comm->rank || recv_bytes[r] == 0)) ++r;
+            MHX_REQUIRE(r < n_recv && recv_bytes[r] == send_bytes[i], "send %d to this rank itself has no receive of the same size", i);
+            ++r;
+        }
+        for (; r < n_recv; ++r) MHX_REQUIRE(recv_peers[r] != comm->rank || recv_bytes[r] == 0, "receive %d from this rank itself has no send", r);
+    }
+    if (out_bytes == 0 && in_bytes == 0) return MHX_OK;
+    MHX_GUARD(comm->ctx);
+    if (int rc = comm->ctx->activate()) return rc;
+    const char *src = static_cast<const char *>(d_send);
+    char *dst = static_cast<char *>(d_recv);
+    for (int i = 0, r = 0; i < n_send; ++i) {
+        if (send_peers[i] != comm->rank || send_bytes[i] == 0) continue;
+        while (recv_peers[r] != comm->rank || recv_bytes[r] == 0) ++r;
+        MHX_HIP_CHECK(hipMemcpyAsync(dst + recv_offsets[r], src + send_offsets[i], send_bytes[i], hipMemcpyDeviceToDevice, comm->ctx->stream));
+        ++r;
+    }
+    MHX_RCCL_CHECK(rccl().GroupStart());
+    ncclResult_t first = ncclSuccess;
+    for (int i = 0; i < n_send; ++i) {
+        if (send_peers[i] == comm->rank || send_bytes[i] == 0) continue;
+        const ncclResult_t r = rccl().Send(src + send_offsets[i], send_bytes[i], ncclUint8, send_peers[i], comm->comm, comm->ctx->stream);
+        if (r != ncclSuccess && first == ncclSuccess) first = r;
+    }
+    for (int i = 0; i < n_recv; ++i) {
+        if (recv_peers[i] == comm->rank || recv_bytes[i] == 0) continue;
+        const ncclResult_t r = rccl().Recv(dst + recv_offsets[i], recv_bytes[i], ncclUint8, recv_peers[i], comm->comm, comm->ctx->stream);
+        if (r != ncclSuccess && first == ncclSuccess) first = r;
+    }
+    const ncclResult_t end = rccl().GroupEnd();  // always closed: an open group would swallow the next call
+    if (first != ncclSuccess) return mhx::fail(MHX_ERR_COMM, "ncclSend / ncclRecv failed: %s", rccl().GetErrorString(first));
     if (end != ncclSuccess) return mhx::fail(MHX_ERR_COMM, "ncclGroupEnd failed: %s", rccl().GetErrorString(end));
     return MHX_OK;
 }

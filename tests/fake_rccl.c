@@ -2,7 +2,7 @@
  *
  * RCCL refuses two ranks on one device, so on a 1-GPU box nothing of libmhx's RCCL binding (datasketch_amd/csrc/comm.hip) beyond a
  * communicator of one rank could ever execute.  This library implements the entry points comm.hip binds -- ncclGetUniqueId,
- * ncclCommInitRank, ncclAllGather, ncclBroadcast, ncclGroupStart / ncclGroupEnd, ncclCommDestroy, ncclCommCount, ncclCommUserRank,
+ * ncclCommInitRank, ncclAllGather, ncclBroadcast, ncclSend / ncclRecv (inside a group), ncclGroupStart / ncclGroupEnd, ncclCommDestroy, ncclCommCount, ncclCommUserRank,
  * ncclCommCuDevice, ncclGetVersion, ncclGetErrorString -- with their documented semantics, for ranks that are processes of ONE
  * node sharing ONE device: data travels device -> a /dev/shm file per rank -> device, ranks meet at a sense-reversing barrier in a
  * shared page named after the unique id.  Collectives block (the stream is synchronised first), which the semantics allow.
@@ -44,6 +44,13 @@ typedef struct { const void *send; void *recv; size_t bytes; int root; ncclComm_
 static __thread int g_group = 0;
 static __thread int g_queued = 0;
 static __thread Bcast g_queue[MAX_QUEUED];
+/* point-to-point messages of the open group: sends are laid out in this rank's file behind a directory (count, then peer /
+ * file offset / bytes per message); a receive takes the k-th directory entry its peer addressed to this rank */
+#define MAX_P2P 4096
+#define P2P_DIR_BYTES (16 + 24 * (size_t)MAX_P2P)
+typedef struct { int is_send; const void *send; void *recv; size_t bytes; int peer; ncclComm_t comm; hipStream_t stream; } P2p;
+static __thread int g_p2p_n = 0;
+static __thread P2p g_p2p[MAX_P2P];
 
 static size_t dtype_size(ncclDataType_t t) {
     switch (t) { case ncclInt8: case ncclUint8: return 1; case ncclFloat16: return 2; case ncclInt32: case ncclUint32: case ncclFloat32: return 4; default: return 8; }
@@ -177,6 +184,74 @@ ncclResult_t ncclBroadcast(const void *send, void *recv, size_t count, ncclDataT
     return ncclSuccess;
 }
 
+static ncclResult_t p2p_queue(int is_send, const void *send, void *recv, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t stream) {
+    if (peer < 0 || peer >= c->world) return ncclInvalidArgument;
+    if (!g_group) return ncclInvalidUsage; /* (comm.hip only ever sends and receives inside one group call) */
+    if (g_p2p_n >= MAX_P2P) return ncclInvalidUsage;
+    P2p m = {is_send, send, recv, count * dtype_size(t), peer, c, stream};
+    g_p2p[g_p2p_n++] = m;
+    return ncclSuccess;
+}
+ncclResult_t ncclSend(const void *send, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t stream) { return p2p_queue(1, send, NULL, count, t, peer, c, stream); }
+ncclResult_t ncclRecv(void *recv, size_t count, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t stream) { return p2p_queue(0, NULL, recv, count, t, peer, c, stream); }
+
+static ncclResult_t run_p2p(void) {
+    if (g_p2p_n == 0) return ncclSuccess;
+    ncclComm_t c = g_p2p[0].comm;
+    ncclResult_t r = ncclSuccess;
+    if (hipStreamSynchronize(g_p2p[0].stream) != hipSuccess) return ncclUnhandledCudaError;
+    size_t total = P2P_DIR_BYTES;
+    int n_send = 0;
+    for (int i = 0; i < g_p2p_n; ++i) if (g_p2p[i].is_send) total += g_p2p[i].bytes, ++n_send;
+    if (total > c->cap) {
+        if (ftruncate(c->fd, (off_t)total) != 0) r = ncclSystemError; else c->cap = total;
+    }
+    char *mine = r == ncclSuccess ? (char *)mmap(NULL, total, PROT_READ | PROT_WRITE, MAP_SHARED, c->fd, 0) : (char *)MAP_FAILED;
+    if (mine == (char *)MAP_FAILED) r = ncclSystemError;
+    if (r == ncclSuccess) {
+        uint64_t *dir = (uint64_t *)mine;
+        size_t at = P2P_DIR_BYTES;
+        int k = 0;
+        dir[0] = (uint64_t)n_send;
+        for (int i = 0; i < g_p2p_n && r == ncclSuccess; ++i) {
+            if (!g_p2p[i].is_send) continue;
+            dir[2 + 3 * k] = (uint64_t)g_p2p[i].peer, dir[3 + 3 * k] = at, dir[4 + 3 * k] = g_p2p[i].bytes;
+            if (g_p2p[i].bytes && hipMemcpy(mine + at, g_p2p[i].send, g_p2p[i].bytes, hipMemcpyDeviceToHost) != hipSuccess) r = ncclUnhandledCudaError;
+            at += g_p2p[i].bytes, ++k;
+        }
+        munmap(mine, total);
+    }
+    barrier(c); /* every rank's sends are in its file */
+    for (int i = 0; i < g_p2p_n && r == ncclSuccess; ++i) {
+        if (g_p2p[i].is_send) continue;
+        int nth = 0; /* how many earlier receives of this group came from the same peer */
+        for (int j = 0; j < i; ++j) if (!g_p2p[j].is_send && g_p2p[j].peer == g_p2p[i].peer) ++nth;
+        char path[128];
+        data_path(c, g_p2p[i].peer, path, sizeof path);
+        int fd = open(path, O_RDONLY);
+        struct stat st;
+        if (fd < 0 || fstat(fd, &st) != 0 || (size_t)st.st_size < P2P_DIR_BYTES) { if (fd >= 0) close(fd); r = ncclSystemError; break; }
+        char *theirs = (char *)mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_SHARED, fd, 0);
+        close(fd);
+        if (theirs == (char *)MAP_FAILED) { r = ncclSystemError; break; }
+        const uint64_t *dir = (const uint64_t *)theirs;
+        int found = 0;
+        for (uint64_t k = 0; k < dir[0]; ++k) {
+            if (dir[2 + 3 * k] != (uint64_t)c->rank) continue;
+            if (nth-- > 0) continue;
+            found = 1;
+            if (dir[4 + 3 * k] != g_p2p[i].bytes) r = ncclInvalidArgument; /* the two ends disagree about a message's size */
+            else if (g_p2p[i].bytes && hipMemcpy(g_p2p[i].recv, theirs + dir[3 + 3 * k], g_p2p[i].bytes, hipMemcpyHostToDevice) != hipSuccess) r = ncclUnhandledCudaError;
+            break;
+        }
+        if (!found && r == ncclSuccess) r = ncclInvalidUsage; /* a receive without a send: real RCCL would hang here */
+        munmap(theirs, (size_t)st.st_size);
+    }
+    barrier(c); /* nobody overwrites its file before everybody has read it */
+    g_p2p_n = 0;
+    return r;
+}
+
 ncclResult_t ncclGroupStart(void) { ++g_group; return ncclSuccess; }
 ncclResult_t ncclGroupEnd(void) {
     if (g_group <= 0) return ncclInvalidUsage;
@@ -187,5 +262,6 @@ ncclResult_t ncclGroupEnd(void) {
         if (r == ncclSuccess) r = ri;
     }
     g_queued = 0;
-    return r;
+    const ncclResult_t rp = run_p2p();
+    return r == ncclSuccess ? rp : r;
 }

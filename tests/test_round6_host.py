@@ -1,0 +1,222 @@
+"""Round 6, host side (no GPU): the by-band exchange of band digests, ragged shards through the sharded path, the host-staged
+transport's error agreement.  World-2 runs use a torch.distributed gloo group wrapped as the three-member protocol dist.py needs."""
+import glob
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from datasketch_amd import dist, rendezvous
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_dist_cpu import _FakeBuffer, _FakeContext, _free_port  # noqa: E402  (stand-in device buffers over a bytearray)
+
+
+def test_band_partition_covers_every_band_once():
+    for bands in (1, 4, 5, 32, 33):
+        for world in (1, 2, 3, 8, 40):
+            part = dist.band_partition(bands, world)
+            assert len(part) == world and part[0][0] == 0 and part[-1][1] == bands
+            assert all(part[q][1] == part[q + 1][0] for q in range(world - 1))
+            sizes = [hi - lo for lo, hi in part]
+            assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("counts,bands", [([3, 5], 4), ([4, 4, 4], 5), ([1, 0, 7, 2], 9), ([2] * 8, 32), ([6, 1], 1)])
+def test_the_runs_of_the_by_band_exchange_match_pairwise_and_tile_every_destination(counts, bands):
+    """What mhx_comm_exchange_dev is handed: between any two ranks the send list of one and the receive list of the other
+    have the same sizes in the same order (RCCL pairs them by order), and executing the runs on numpy buffers gives every
+    rank the [its bands, N] matrix of the concatenated rows."""
+    world, total = len(counts), sum(counts)
+    rng = np.random.RandomState(1)
+    local = [rng.randint(0, 2**63, (bands, c), dtype=np.uint64) for c in counts]
+    want = np.concatenate(local, axis=1)
+    runs = [dist._band_runs(counts, bands, r) for r in range(world)]
+    part = dist.band_partition(bands, world)
+    for q in range(world):
+        lo, hi = part[q]
+        out = np.zeros((hi - lo) * total, dtype=np.uint64).view(np.uint8)
+        covered = np.zeros(out.size, dtype=np.int32)
+        for p in range(world):
+            sends = [(off, size) for peer, off, size in runs[p][0] if peer == q]
+            recvs = [(off, size) for peer, off, size in runs[q][1] if peer == p]
+            assert [s for _, s in sends] == [s for _, s in recvs]
+            src = local[p].view(np.uint8).reshape(-1)
+            for (so, size), (ro, _) in zip(sends, recvs):
+                out[ro: ro + size] = src[so: so + size]
+                covered[ro: ro + size] += 1
+        assert np.all(covered == 1)
+        assert np.array_equal(out.view(np.uint64).reshape(hi - lo, total), want[lo:hi])
+
+
+@pytest.mark.parametrize("force_tcp", [False, True])
+@pytest.mark.parametrize("counts,bands", [([5, 5, 5], 6), ([7, 0, 3], 5), ([1, 9, 4], 2)])
+def test_host_staged_by_band_exchange_places_every_run(force_tcp, counts, bands, monkeypatch):
+    """Three ranks (threads) over /dev/shm files and over the sockets in pieces smaller than a run: every rank ends up with
+    [its bands, N] in rank order of the rows; no staging file is left behind.  bands = 2 < world leaves a rank without bands."""
+    monkeypatch.setattr(dist, "_FORCE_TCP", force_tcp)
+    monkeypatch.setattr(dist, "_HOST_PIECE", 40)
+    world, port = 3, _free_port()
+    local = [np.random.RandomState(50 + r).randint(0, 2**63, (bands, counts[r]), dtype=np.uint64) for r in range(world)]
+    want = np.concatenate(local, axis=1)
+    before = set(glob.glob("/dev/shm/mhx_gather_*"))
+    res, errors = {}, []
+
+    def run(rank):
+        try:
+            with rendezvous.Group(rank, world, "127.0.0.1", port, timeout=30) as g:
+                ctx = _FakeContext()
+                d_local = ctx.alloc(max(1, local[rank].nbytes)).upload(local[rank])
+                got = dist.exchange_band_digests_dev(ctx, d_local, counts[rank], bands, counts, g, transport="host")
+                res[rank] = (got.transport, got.lo_band, got.hi_band, got.bytes_received, got.to_host())
+        except Exception as e:  # noqa: BLE001
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(60)
+    assert not errors, errors
+    for r in range(world):
+        transport, lo, hi, received, m = res[r]
+        assert (lo, hi) == dist.band_partition(bands, world)[r]
+        assert transport == ("host-tcp" if force_tcp else "host-shm")
+        assert received == (hi - lo) * (sum(counts) - counts[r]) * 8
+        assert np.array_equal(m, want[lo:hi])
+    assert set(glob.glob("/dev/shm/mhx_gather_*")) == before
+
+
+def test_a_rank_that_fails_inside_the_host_transport_fails_every_rank_instead_of_hanging_them(monkeypatch):
+    """an upload error on one rank used to skip that rank's closing barrier only.  Now every phase ends in a status
+    all-gather: the failing rank's message reaches all of them, nobody waits for the rendezvous timeout, nothing is left in /dev/shm."""
+    world, port, counts, k = 3, _free_port(), [4, 4, 4], 3
+    before = set(glob.glob("/dev/shm/mhx_gather_*"))
+    outcome = {}
+
+    class _Broken(_FakeBuffer):
+        def upload(self, arr, offset=0):
+            raise RuntimeError("device upload failed (injected)")
+
+    def run(rank):
+        try:
+            with rendezvous.Group(rank, world, "127.0.0.1", port, timeout=20) as g:
+                ctx = _FakeContext()
+                shard = np.full((counts[rank], k), rank, dtype=np.uint32)
+                d_local = ctx.alloc(shard.nbytes).upload(shard)
+                if rank == 1:
+                    ctx.alloc = lambda n: _Broken(ctx, n)  # this rank's gathered buffer cannot be written
+                dist.allgather_signatures_dev(ctx, d_local, counts[rank], k, counts, g, transport="host")
+                outcome[rank] = "returned"
+        except OSError as e:
+            outcome[rank] = str(e)
+        except Exception as e:  # noqa: BLE001
+            outcome[rank] = "other: " + repr(e)
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(15)
+    assert all(not t.is_alive() for t in threads), "a rank is still waiting"
+    assert all("rank 1" in outcome[r] and "injected" in outcome[r] for r in range(world)), outcome
+    assert set(glob.glob("/dev/shm/mhx_gather_*")) == before
+
+
+def test_shard_csr_balances_a_heavy_tailed_corpus_by_tokens():
+    rng = np.random.RandomState(3)
+    lens = np.minimum(5000, (rng.pareto(1.2, 4000) * 20).astype(np.int64))
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    values = rng.randint(0, 2**32, int(offsets[-1]), dtype=np.uint64)
+    seen_rows, tokens = 0, []
+    for rank in range(4):
+        v, o, (b, e) = dist.shard_csr(values, offsets, 4, rank)
+        assert b == seen_rows and o[0] == 0 and o[-1] == v.size and np.array_equal(np.diff(o), lens[b:e])
+        assert np.array_equal(v, values[offsets[b]: offsets[e]])
+        seen_rows = e
+        tokens.append(v.size)
+    assert seen_rows == 4000
+    assert max(tokens) - min(tokens) <= 2 * 5000  # within one longest row of each other, where equal ROW counts would not be
+    by_rows = [int(offsets[dist.shard_rows(4000, 4, r)[1]] - offsets[dist.shard_rows(4000, 4, r)[0]]) for r in range(4)]
+    assert max(tokens) - min(tokens) <= max(by_rows) - min(by_rows)
+    with pytest.raises(ValueError):
+        dist.shard_csr(values, offsets, 4, 0, balance="weight")
+
+
+_RANK_BODY = r"""
+import os, sys, pickle
+import numpy as np
+sys.path.insert(0, {root!r})
+from datasketch_amd import dist, lsh_bulk
+import torch.distributed as tdist
+tdist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+class GlooGroup:                 # the three members dist.py needs, on top of a gloo process group
+    rank, world = tdist.get_rank(), tdist.get_world_size()
+    def allgather(self, payload):
+        box = [None] * self.world
+        tdist.all_gather_object(box, bytes(payload))
+        return box
+group = GlooGroup()
+rng = np.random.RandomState(11)
+lens = np.minimum(400, (rng.pareto(1.1, 301) * 6).astype(np.int64))     # heavy-tailed, with empty sets
+offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+values = rng.randint(0, 2**32, int(offsets[-1]), dtype=np.uint64)
+K, BANDS, R = 24, 6, 4
+v, o, (b, e) = dist.shard_csr(values, offsets, group.world, group.rank)
+counts = dist.gather_counts(e - b, group)
+full = dist.bulk_signatures_sharded(lambda: (v, o), num_perm=K, seed=3, gpu_mode="disable", group=group)
+# the index partitioned by band: digests of the local rows, band-major, exchanged by band, bucketed per band
+mine = lsh_bulk.band_digests(full[b:e], BANDS, R, gpu_mode="disable")
+shard = dist.exchange_band_digests(np.ascontiguousarray(mine.T), group=group, counts=counts)
+lo, hi = dist.band_partition(BANDS, group.world)[group.rank]
+order = np.stack([np.argsort(shard[j], kind="stable") for j in range(hi - lo)]) if hi > lo else np.zeros((0, full.shape[0]), dtype=np.int64)
+with open({out!r} + str(group.rank), "wb") as f:
+    pickle.dump((full, counts, (lo, hi), shard, order), f)
+tdist.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_ragged_shards_and_the_by_band_exchange_equal_the_single_process_results(tmp_path):
+    """World 2 over gloo: a heavy-tailed ragged corpus cut by token count, hashed per rank through the CSR form, all-gathered;
+    then the by-band exchange of the band digests.  Equal to the single-process CSR call and to the digests / stable order of the
+    whole matrix."""
+    pytest.importorskip("torch")
+    import pickle
+
+    from datasketch_amd import MinHash, lsh_bulk, prehashed
+
+    out = str(tmp_path / "rank")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, "-c", _RANK_BODY.format(root=ROOT, out=out)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    for p in procs:
+        text, _ = p.communicate(timeout=240)
+        assert p.returncode == 0, text.decode()
+    rng = np.random.RandomState(11)
+    lens = np.minimum(400, (rng.pareto(1.1, 301) * 6).astype(np.int64))
+    offsets = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    values = rng.randint(0, 2**32, int(offsets[-1]), dtype=np.uint64)
+    assert (lens == 0).any() and lens.max() > 20 * np.median(lens)
+    want = MinHash.bulk_signatures((values, offsets), num_perm=24, seed=3, hashfunc=prehashed, gpu_mode="disable")
+    dig = lsh_bulk.band_digests(want, 6, 4, gpu_mode="disable")  # [N, bands]
+    tokens_per_rank = []
+    for rank in range(2):
+        with open(out + str(rank), "rb") as f:
+            full, counts, (lo, hi), shard, order = pickle.load(f)
+        assert np.array_equal(full, want)
+        assert sum(counts) == 301 and (lo, hi) == (3 * rank, 3 * rank + 3)
+        assert np.array_equal(shard, dig[:, lo:hi].T)
+        for j in range(lo, hi):
+            assert np.array_equal(order[j - lo], np.argsort(dig[:, j], kind="stable"))
+        b = sum(counts[:rank])
+        tokens_per_rank.append(int(offsets[b + counts[rank]] - offsets[b]))
+    assert abs(tokens_per_rank[0] - tokens_per_rank[1]) <= 400  # balanced by tokens, within one longest row

@@ -20,3 +20,5 @@ rocprofv3 --kernel-trace --stats -d "${OUT}/trace" -o trace -- "${CMD[@]}" > "${
 echo "trace rc=$?"
 python tools/rocpd_summary.py "${OUT}" > "${OUT}/summary.txt" 2>&1
 wc -l "${OUT}/summary.txt"
+# gpurun copies back at most 64 MiB: keep the summary and the logs, drop rocprofv3's databases
+find "${OUT}" -mindepth 1 -maxdepth 1 -type d -exec rm -rf {} +
