@@ -39,6 +39,7 @@ _PROTOTYPES = {
     "mhx_ctx_set_option": [_vp, ctypes.c_char_p, _i64],
     "mhx_ctx_counters": [_vp, _int, ctypes.POINTER(ctypes.c_uint64)],
     "mhx_ctx_minhash_mode": [_vp, _int, ctypes.POINTER(_int)],
+    "mhx_ctx_minhash_flags": [_vp, _i64, _vp],
     "mhx_dev_alloc": [_vp, _sz, ctypes.POINTER(_vp)],
     "mhx_dev_free": [_vp, _vp],
     "mhx_debug_guard_alloc": [_int, ctypes.POINTER(_i64), ctypes.POINTER(_i64)],
@@ -103,6 +104,11 @@ _PROTOTYPES = {
     "mhx_bbit_jaccard_pairs": [_vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp],
     "mhx_lean_serialize_dev": [_vp, _vp, _i64, _i32, _i64, _vp],
     "mhx_lean_serialize": [_vp, _vp, _i64, _i32, _i64, _vp],
+    "mhx_lean_serialize_dev_typed": [_vp, _vp, _int, _i64, _i32, _i64, _int, _vp],
+    "mhx_lean_deserialize_dev": [_vp, _vp, _i64, _i32, _int, _int, _vp, _vp, _vp],
+    "mhx_lean_deserialize": [_vp, _vp, _i64, _i32, _int, _vp, _vp],
+    "mhx_bbit_unpack_dev": [_vp, _vp, _i64, _i32, _i32, _vp],
+    "mhx_bbit_unpack": [_vp, _vp, _i64, _i32, _i32, _vp],
     "mhx_comm_unique_id": [_vp],
     "mhx_comm_create": [_vp, _vp, _int, _int, ctypes.POINTER(_vp)],
     "mhx_comm_destroy": [_vp],
@@ -407,6 +413,13 @@ class Context:
         mode = _int(0)
         check(self.lib.mhx_ctx_minhash_mode(self.handle, 1 if reset else 0, ctypes.byref(mode)))
         return mode.value
+
+    def minhash_flags(self, n_sets: int) -> np.ndarray:
+        """uint8[n_sets]: which launch produced each set of the LAST ``minhash_bulk_dev`` call (0 first launch's proof held,
+        1 second launch, 2 pairwise launch; mhx_ctx_minhash_flags).  Results are exact either way: a parity audit's index."""
+        out = np.empty(int(n_sets), dtype=np.uint8)
+        check(self.lib.mhx_ctx_minhash_flags(self.handle, int(n_sets), out.ctypes.data_as(_vp)))
+        return out
 
     def synchronize(self) -> None:
         check(self.lib.mhx_ctx_synchronize(self.handle))
@@ -781,6 +794,25 @@ class Context:
         n, k = sig.shape
         out = np.zeros((n, 12 + 4 * k), dtype=np.uint8)
         check(self.lib.mhx_lean_serialize(self.handle, _ptr(sig), n, k, int(seed), _ptr(out)))
+        return out
+
+    def lean_deserialize(self, records: np.ndarray, num_perm: int, big_endian: bool = False):
+        """(seeds int64[n], hashvalues uint64[n, K]) of n LeanMinHash records laid back to back (mhx_lean_deserialize);
+        ValueError when a record's length field is not ``num_perm``."""
+        records = np.ascontiguousarray(records, dtype=np.uint8).reshape(-1)
+        rec = 12 + 4 * int(num_perm)
+        if records.size % rec:
+            raise ValueError("the buffer is not a whole number of %d-byte records" % rec)
+        n = records.size // rec
+        sig, seeds = np.empty((n, int(num_perm)), dtype=np.uint64), np.empty(n, dtype=np.int64)
+        check(self.lib.mhx_lean_deserialize(self.handle, _ptr(records), n, int(num_perm), 1 if big_endian else 0, _ptr(sig), _ptr(seeds)))
+        return seeds, sig
+
+    def bbit_unpack(self, blocks: np.ndarray, num_perm: int, b: int) -> np.ndarray:
+        """uint32[n, num_perm]: the b-bit values of packed rows (mhx_bbit_unpack, the inverse of :meth:`bbit_pack`)."""
+        blocks = np.ascontiguousarray(blocks, dtype=np.uint64)
+        out = np.empty((blocks.shape[0], int(num_perm)), dtype=np.uint32)
+        check(self.lib.mhx_bbit_unpack(self.handle, _ptr(blocks), blocks.shape[0], int(num_perm), int(b), _ptr(out)))
         return out
 
     # -- device-resident entry points (pointers are DeviceBuffer.ptr + byte offsets) -----------

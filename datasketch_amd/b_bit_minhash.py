@@ -144,6 +144,23 @@ def pack_matrix(signatures: np.ndarray, b: int, gpu_mode: str = "always") -> np.
     return _pack_rows(masked, _slot_size(b))
 
 
+def unpack_matrix(blocks: np.ndarray, num_perm: int, b: int, gpu_mode: str = "always") -> np.ndarray:
+    """The inverse of :func:`pack_matrix`: ``bBitMinHash.__setstate__`` (ref: datasketch/b_bit_minhash.py:103-125) of every
+    row of a uint64 ``[N, num_blocks]`` block matrix -- the b-bit values as uint32 ``[N, num_perm]``, what N restored
+    ``bBitMinHash`` objects would hold as ``hashvalues``."""
+    b = int(b)
+    if b > 32 or b < 0:
+        raise ValueError("b must be an integer in [0, 32]")
+    blocks = np.ascontiguousarray(blocks, dtype=np.uint64)
+    slot = _slot_size(b)
+    nb = -(-int(num_perm) // (64 // slot))
+    if blocks.ndim != 2 or blocks.shape[1] != nb:
+        raise ValueError("blocks must be [n, %d] for num_perm=%d, b=%d" % (nb, num_perm, b))
+    if gpu_mode != "disable" and (gpu_mode == "always" or _native.gpu_detected()):
+        return _native.context().bbit_unpack(blocks, num_perm, b)
+    return _unpack_rows(blocks, slot, int(num_perm)).astype(np.uint32)
+
+
 def jaccard_pairs(blocks: np.ndarray, pairs, num_perm: int, b: int, r: float = 0.0, gpu_mode: str = "always") -> np.ndarray:
     """``bBitMinHash.jaccard`` (ref: datasketch/b_bit_minhash.py:53-72) for rows ``pairs[:, 0]`` and ``pairs[:, 1]`` of a
     packed matrix (:func:`pack_matrix` output): float64 estimates ``(agreeing / num_perm - C1) / (1 - C2)`` with the

@@ -405,6 +405,21 @@ int mhx_ctx_minhash_mode(mhx_ctx *ctx, int reset, int *mode) {
     return MHX_OK;
 }
 
+// Which sets of the last MinHash call left the fast path (see mhx.h).  The flags are the launches' own hand-over bytes: the sieve
+// launch writes 0 / 1 for every set, the second launch turns the 1 of a set it could not certify either into 2.
+int mhx_ctx_minhash_flags(mhx_ctx *ctx, int64_t n_sets, uint8_t *flags) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    if (int rc = ctx->activate()) return rc;
+    MHX_REQUIRE(n_sets >= 0 && (flags || n_sets == 0), "NULL flags");
+    if (ctx->redo_sets != n_sets || (n_sets > 0 && !ctx->d_redo))
+        return fail(MHX_ERR_INVALID, "the last MinHash call on this context kept flags for %lld sets, not %lld (one huge set split over waves and "
+                    "minhash.path != 0 keep none)", (long long)ctx->redo_sets, (long long)n_sets);
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (n_sets > 0) MHX_HIP_CHECK(hipMemcpy(flags, ctx->d_redo, (size_t)n_sets, hipMemcpyDeviceToHost));
+    return MHX_OK;
+}
+
 int mhx_ctx_counters(mhx_ctx *ctx, int enable, uint64_t out[MHX_NUM_COUNTERS]) {
     if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
     MHX_GUARD(ctx);
@@ -1136,7 +1151,45 @@ int mhx_lean_serialize_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32
     if (n == 0) return MHX_OK;
     MHX_REQUIRE(d_sig && d_out, "NULL device pointer");
     if (int rc = ctx->activate()) return rc;
-    return mhx::launch_lean_serialize(ctx, d_sig, n, k, seed, d_out);
+    return mhx::launch_lean_serialize(ctx, d_sig, MHX_U64, n, k, seed, 0, d_out);
+}
+
+int mhx_lean_serialize_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int64_t seed, int byteorder,
+                                 uint8_t *d_out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    MHX_REQUIRE(k > 0 && n >= 0, "bad shape");
+    MHX_REQUIRE(sig_dtype == MHX_U64 || sig_dtype == MHX_U32, "unknown sig_dtype %d", sig_dtype);
+    MHX_REQUIRE(byteorder == MHX_LITTLE_ENDIAN || byteorder == MHX_BIG_ENDIAN, "unknown byte order %d", byteorder);
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(d_sig && d_out, "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_lean_serialize(ctx, d_sig, sig_dtype, n, k, seed, byteorder, d_out);
+}
+
+int mhx_lean_deserialize_dev(mhx_ctx *ctx, const uint8_t *d_records, int64_t n, int32_t k, int byteorder, int sig_dtype, void *d_sig,
+                             int64_t *d_seeds, uint32_t *d_bad) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    MHX_REQUIRE(k > 0 && n >= 0, "bad shape");
+    MHX_REQUIRE(sig_dtype == MHX_U64 || sig_dtype == MHX_U32, "unknown sig_dtype %d", sig_dtype);
+    MHX_REQUIRE(byteorder == MHX_LITTLE_ENDIAN || byteorder == MHX_BIG_ENDIAN, "unknown byte order %d", byteorder);
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(d_records && d_sig, "NULL device pointer");
+    MHX_REQUIRE(((uintptr_t)d_records & 3) == 0, "records must be 4-byte aligned");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_lean_deserialize(ctx, d_records, n, k, byteorder, sig_dtype, d_sig, d_seeds, d_bad);
+}
+
+int mhx_bbit_unpack_dev(mhx_ctx *ctx, const uint64_t *d_blocks, int64_t n, int32_t k, int32_t b, uint32_t *d_out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    MHX_REQUIRE(k > 0 && n >= 0, "bad shape");
+    MHX_REQUIRE(b >= 0 && b <= 32, "b must be in [0, 32]");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(d_blocks && d_out, "NULL device pointer");
+    if (int rc = ctx->activate()) return rc;
+    return mhx::launch_bbit_unpack(ctx, d_blocks, n, k, b, d_out);
 }
 
 // host wrappers: stage signature matrix in scratch[0], result in scratch[2]
@@ -1401,9 +1454,55 @@ int mhx_lean_serialize(mhx_ctx *ctx, const uint64_t *sig, int64_t n, int32_t k, 
     MHX_REQUIRE(sig && out, "NULL host pointer");
     const size_t out_bytes = (size_t)n * (12 + 4 * (size_t)k);
     if (int rc = stage_sig(ctx, sig, n, k, out_bytes)) return rc;
-    if (int rc = mhx::launch_lean_serialize(ctx, (const uint64_t *)ctx->scratch[0], n, k, seed,
-                                            (uint8_t *)ctx->scratch[2]))
+    if (int rc = mhx::launch_lean_serialize(ctx, ctx->scratch[0], MHX_U64, n, k, seed, 0, (uint8_t *)ctx->scratch[2]))
         return rc;
+    return fetch_out(ctx, out, out_bytes);
+}
+
+// records (host) -> [n, k] uint64 hashvalues + seeds; a record whose length field is not k: MHX_ERR_INVALID, nothing written
+int mhx_lean_deserialize(mhx_ctx *ctx, const uint8_t *records, int64_t n, int32_t k, int byteorder, uint64_t *sig, int64_t *seeds) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    MHX_REQUIRE(k > 0 && n >= 0, "bad shape");
+    MHX_REQUIRE(byteorder == MHX_LITTLE_ENDIAN || byteorder == MHX_BIG_ENDIAN, "unknown byte order %d", byteorder);
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(records && sig, "NULL host pointer");
+    if (int rc = ctx->activate()) return rc;
+    const size_t rec_bytes = (size_t)n * (12 + 4 * (size_t)k), sig_bytes = sizeof(uint64_t) * (size_t)n * k;
+    const size_t seeds_at = (sig_bytes + 255) & ~(size_t)255, bad_at = seeds_at + (((size_t)n * 8 + 255) & ~(size_t)255);
+    if (int rc = ctx->ensure_scratch(0, rec_bytes)) return rc;
+    if (int rc = ctx->ensure_scratch(2, bad_at + 256)) return rc;
+    char *base = (char *)ctx->scratch[2];
+    unsigned int *d_bad = (unsigned int *)(base + bad_at);
+    MHX_HIP_CHECK(hipMemcpyAsync(ctx->scratch[0], records, rec_bytes, hipMemcpyHostToDevice, ctx->stream));
+    MHX_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(unsigned int), ctx->stream));
+    if (int rc = mhx::launch_lean_deserialize(ctx, (const uint8_t *)ctx->scratch[0], n, k, byteorder, MHX_U64, base, (int64_t *)(base + seeds_at), d_bad))
+        return rc;
+    unsigned int bad = 0;
+    MHX_HIP_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (bad) return fail(MHX_ERR_INVALID, "%u of %lld records do not hold %d hash values (length field)", bad, (long long)n, k);
+    MHX_HIP_CHECK(hipMemcpyAsync(sig, base, sig_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (seeds) MHX_HIP_CHECK(hipMemcpyAsync(seeds, base + seeds_at, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MHX_OK;
+}
+
+int mhx_bbit_unpack(mhx_ctx *ctx, const uint64_t *blocks, int64_t n, int32_t k, int32_t b, uint32_t *out) {
+    if (!ctx) return fail(MHX_ERR_INVALID, "ctx is NULL");
+    MHX_GUARD(ctx);
+    MHX_REQUIRE(k > 0 && n >= 0, "bad shape");
+    MHX_REQUIRE(b >= 0 && b <= 32, "b must be in [0, 32]");
+    if (n == 0) return MHX_OK;
+    MHX_REQUIRE(blocks && out, "NULL host pointer");
+    if (int rc = ctx->activate()) return rc;
+    int32_t nb = 0;
+    if (int rc = mhx_bbit_num_blocks(k, b, &nb)) return rc;
+    const size_t in_bytes = sizeof(uint64_t) * (size_t)n * nb, out_bytes = sizeof(uint32_t) * (size_t)n * k;
+    if (int rc = ctx->ensure_scratch(0, in_bytes)) return rc;
+    if (int rc = ctx->ensure_scratch(2, out_bytes)) return rc;
+    MHX_HIP_CHECK(hipMemcpyAsync(ctx->scratch[0], blocks, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (int rc = mhx::launch_bbit_unpack(ctx, (const uint64_t *)ctx->scratch[0], n, k, b, (uint32_t *)ctx->scratch[2])) return rc;
     return fetch_out(ctx, out, out_bytes);
 }
 

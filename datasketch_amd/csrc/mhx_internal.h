@@ -105,6 +105,7 @@ struct mhx_ctx {
     // redo flags of the wave-per-set MinHash launches: one byte per set (grow-only)
     uint8_t *d_redo = nullptr;
     int64_t redo_capacity = 0;
+    int64_t redo_sets = 0;          // sets whose flags the last MinHash launch sequence wrote (0: that call kept no flags)
     int ensure_redo(int64_t n_sets);
     // the sieve launch's running failure counts ([0], [1]), the number of sets left to the pairwise launch ([4]) -- zeroed
     // per call -- and, from word 16 on, the list of those sets (kPairListCap entries)
@@ -187,8 +188,11 @@ int launch_lsh_query(mhx_ctx *ctx, const uint64_t *d_sorted_digests, const uint3
                      int64_t *d_pairs, int64_t capacity, int64_t *n_pairs);
 int launch_bbit_jaccard(mhx_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, int32_t k, int32_t b, const int64_t *d_pairs,
                         int64_t m, int32_t *d_counts);
-int launch_lean_serialize(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int64_t seed,
+int launch_lean_serialize(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int64_t seed, int big_endian,
                           uint8_t *d_out);
+int launch_lean_deserialize(mhx_ctx *ctx, const uint8_t *d_records, int64_t n, int32_t k, int big_endian, int sig_dtype, void *d_sig,
+                            int64_t *d_seeds, unsigned int *d_bad);
+int launch_bbit_unpack(mhx_ctx *ctx, const uint64_t *d_blocks, int64_t n, int32_t k, int32_t b, uint32_t *d_out);
 
 int bbit_slot_size(int b);
 

@@ -1692,9 +1692,11 @@ int launch_minhash_bulk(mhx_perm *perm, const void *d_hv, int hv_dtype, const in
     bool split = n_sets < waves_avail && total_tokens > n_sets * 128 && total_tokens >= 1024;
     if (ctx->opt_minhash_split == 1) split = false;
     if (ctx->opt_minhash_split == 2) split = total_tokens > 0;
+    ctx->redo_sets = 0;
     if (!split && args.path == 0) {
         if (int rc = ctx->ensure_redo(n_sets)) return rc;
         args.redo = ctx->d_redo;
+        ctx->redo_sets = n_sets;  // (mhx_ctx_minhash_flags)
     }
     if (hv_dtype == MHX_U64 && out_dtype == MHX_U64) return launch_p<uint64_t, uint64_t>(ctx, args, first_token, total_tokens, split);
     if (hv_dtype == MHX_U64 && out_dtype == MHX_U32) return launch_p<uint64_t, uint32_t>(ctx, args, first_token, total_tokens, split);

@@ -195,9 +195,11 @@ __global__ __launch_bounds__(256) void bswap_flat_kernel(const ulonglong2 *__res
 }
 
 // ---- LeanMinHash wire format ----------------------------------------------------------------
-// ref: datasketch/lean_minhash.py:174-175: struct "<qi{K}I" = seed(int64) K(int32) K x uint32.
-// A record is (3 + K) 32-bit words; records are only 4-byte aligned, so stores are dword-wide.
-__global__ __launch_bounds__(256) void lean_serialize_kernel(const uint64_t *__restrict__ sig, int64_t n,
+// ref: datasketch/lean_minhash.py:174-175: struct "<byteorder>qi{K}I" = seed(int64) K(int32) K x uint32 -- no padding in any of
+// the byte orders the reference accepts ('@' and '=' are this host's little-endian, '<'; '>' and '!' big-endian).
+// A record is (3 + K) 32-bit words; records are only 4-byte aligned, so loads and stores are dword-wide.
+template <typename SigT, bool BIG>
+__global__ __launch_bounds__(256) void lean_serialize_kernel(const SigT *__restrict__ sig, int64_t n,
                                                              int32_t k, int64_t seed,
                                                              uint32_t *__restrict__ out) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -206,14 +208,72 @@ __global__ __launch_bounds__(256) void lean_serialize_kernel(const uint64_t *__r
     const int rec = 3 + k;
     for (int64_t row = (int64_t)blockIdx.x * waves_per_block + wave; row < n;
          row += (int64_t)gridDim.x * waves_per_block) {
-        const uint64_t *src = sig + row * k;
+        const SigT *src = sig + row * k;
         uint32_t *dst = out + row * rec;
         if (lane == 0) {
-            dst[0] = (uint32_t)seed;
-            dst[1] = (uint32_t)((uint64_t)seed >> 32);
-            dst[2] = (uint32_t)k;
+            const uint32_t lo = (uint32_t)seed, hi = (uint32_t)((uint64_t)seed >> 32);
+            dst[0] = BIG ? __builtin_bswap32(hi) : lo;
+            dst[1] = BIG ? __builtin_bswap32(lo) : hi;
+            dst[2] = BIG ? __builtin_bswap32((uint32_t)k) : (uint32_t)k;
         }
-        for (int c = lane; c < k; c += kWave) dst[3 + c] = (uint32_t)src[c];
+        for (int c = lane; c < k; c += kWave) dst[3 + c] = BIG ? __builtin_bswap32((uint32_t)src[c]) : (uint32_t)src[c];
+    }
+}
+
+// LeanMinHash.deserialize of n records (ref: datasketch/lean_minhash.py:177-214): hashvalues widened to SigT, the record's seed to
+// seeds[row]; a record whose length field is not k is counted in *bad (its k values are decoded all the same: the caller decides).
+template <typename SigT, bool BIG>
+__global__ __launch_bounds__(256) void lean_deserialize_kernel(const uint32_t *__restrict__ records, int64_t n, int32_t k,
+                                                               SigT *__restrict__ sig, int64_t *__restrict__ seeds,
+                                                               unsigned int *__restrict__ bad) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int waves_per_block = blockDim.x >> 6;
+    const int rec = 3 + k;
+    for (int64_t row = (int64_t)blockIdx.x * waves_per_block + wave; row < n;
+         row += (int64_t)gridDim.x * waves_per_block) {
+        const uint32_t *src = records + row * rec;
+        SigT *dst = sig + row * k;
+        if (lane == 0) {
+            const uint32_t w0 = src[0], w1 = src[1], w2 = src[2];
+            const uint64_t seed = BIG ? ((uint64_t)__builtin_bswap32(w0) << 32) | __builtin_bswap32(w1) : ((uint64_t)w1 << 32) | w0;
+            if (seeds) seeds[row] = (int64_t)seed;
+            if (bad && (BIG ? __builtin_bswap32(w2) : w2) != (uint32_t)k) atomicAdd(bad, 1u);
+        }
+        for (int c = lane; c < k; c += kWave) dst[c] = (SigT)(BIG ? __builtin_bswap32(src[3 + c]) : src[3 + c]);
+    }
+}
+
+// bBitMinHash.__setstate__ of every row (ref: datasketch/b_bit_minhash.py:103-125): value j of block i is
+// (block >> (n - 1 - j) * slot) & (2^slot - 1), n = 64 / slot; out[row, i * n + j] as uint32.  A thread produces four
+// consecutive values (one 16-byte store when the rows allow it); the blocks of a row are a few cache lines read by all.
+template <bool WIDE>
+__global__ __launch_bounds__(256) void bbit_unpack_kernel(const uint64_t *__restrict__ blocks, int64_t n, int32_t k, int32_t slot,
+                                                          int32_t nb, uint32_t *__restrict__ out) {
+    const int per_log2 = 6 - (31 - __builtin_clz((unsigned)slot));  // values per block = 64 / slot, a power of two
+    const int per = 1 << per_log2;
+    const uint64_t mask = slot >= 64 ? ~0ull : ((1ull << slot) - 1ull);
+    const int groups = (k + 3) >> 2;  // groups of four values per row
+    const int64_t total = n * (int64_t)groups;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = idx / groups;
+        const int kk = (int)(idx - row * groups) << 2;
+        const uint64_t *src = blocks + row * nb;
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int at = kk + u < k ? kk + u : k - 1;
+            const uint64_t blk = src[at >> per_log2];
+            v[u] = (uint32_t)((blk >> ((per - 1 - (at & (per - 1))) * slot)) & mask);
+        }
+        uint32_t *dst = out + row * k + kk;
+        if (WIDE) {
+            *reinterpret_cast<uint4 *>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (kk + u < k) dst[u] = v[u];
+        }
     }
 }
 
@@ -615,10 +675,46 @@ int launch_bbit_jaccard(mhx_ctx *ctx, const uint64_t *d_a, const uint64_t *d_b, 
     return MHX_OK;
 }
 
-int launch_lean_serialize(mhx_ctx *ctx, const uint64_t *d_sig, int64_t n, int32_t k, int64_t seed,
+int launch_lean_serialize(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n, int32_t k, int64_t seed, int big_endian,
                           uint8_t *d_out) {
-    hipLaunchKernelGGL(lean_serialize_kernel, row_grid(ctx, n), dim3(256), 0, ctx->stream, d_sig, n, k, seed,
-                       (uint32_t *)d_out);
+    const dim3 g = row_grid(ctx, n);
+    uint32_t *out = (uint32_t *)d_out;
+    if (sig_dtype == MHX_U32) {
+        if (big_endian) hipLaunchKernelGGL((lean_serialize_kernel<uint32_t, true>), g, dim3(256), 0, ctx->stream, (const uint32_t *)d_sig, n, k, seed, out);
+        else hipLaunchKernelGGL((lean_serialize_kernel<uint32_t, false>), g, dim3(256), 0, ctx->stream, (const uint32_t *)d_sig, n, k, seed, out);
+    } else {
+        if (big_endian) hipLaunchKernelGGL((lean_serialize_kernel<uint64_t, true>), g, dim3(256), 0, ctx->stream, (const uint64_t *)d_sig, n, k, seed, out);
+        else hipLaunchKernelGGL((lean_serialize_kernel<uint64_t, false>), g, dim3(256), 0, ctx->stream, (const uint64_t *)d_sig, n, k, seed, out);
+    }
+    MHX_HIP_CHECK(hipGetLastError());
+    return MHX_OK;
+}
+
+int launch_lean_deserialize(mhx_ctx *ctx, const uint8_t *d_records, int64_t n, int32_t k, int big_endian, int sig_dtype, void *d_sig,
+                            int64_t *d_seeds, unsigned int *d_bad) {
+    const dim3 g = row_grid(ctx, n);
+    const uint32_t *in = (const uint32_t *)d_records;
+    if (sig_dtype == MHX_U32) {
+        if (big_endian) hipLaunchKernelGGL((lean_deserialize_kernel<uint32_t, true>), g, dim3(256), 0, ctx->stream, in, n, k, (uint32_t *)d_sig, d_seeds, d_bad);
+        else hipLaunchKernelGGL((lean_deserialize_kernel<uint32_t, false>), g, dim3(256), 0, ctx->stream, in, n, k, (uint32_t *)d_sig, d_seeds, d_bad);
+    } else {
+        if (big_endian) hipLaunchKernelGGL((lean_deserialize_kernel<uint64_t, true>), g, dim3(256), 0, ctx->stream, in, n, k, (uint64_t *)d_sig, d_seeds, d_bad);
+        else hipLaunchKernelGGL((lean_deserialize_kernel<uint64_t, false>), g, dim3(256), 0, ctx->stream, in, n, k, (uint64_t *)d_sig, d_seeds, d_bad);
+    }
+    MHX_HIP_CHECK(hipGetLastError());
+    return MHX_OK;
+}
+
+int launch_bbit_unpack(mhx_ctx *ctx, const uint64_t *d_blocks, int64_t n, int32_t k, int32_t b, uint32_t *d_out) {
+    const int slot = bbit_slot_size(b);
+    const int per = 64 / slot;
+    const int nb = (k + per - 1) / per;
+    const int64_t total = n * (int64_t)((k + 3) / 4);
+    const dim3 g((unsigned)std::max<int64_t>(1, std::min<int64_t>((total + 255) / 256, (int64_t)ctx->num_cus * 32)));
+    if (k % 4 == 0 && ((uintptr_t)d_out & 15) == 0)
+        hipLaunchKernelGGL(bbit_unpack_kernel<true>, g, dim3(256), 0, ctx->stream, d_blocks, n, k, slot, nb, d_out);
+    else
+        hipLaunchKernelGGL(bbit_unpack_kernel<false>, g, dim3(256), 0, ctx->stream, d_blocks, n, k, slot, nb, d_out);
     MHX_HIP_CHECK(hipGetLastError());
     return MHX_OK;
 }

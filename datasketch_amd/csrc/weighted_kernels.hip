@@ -653,8 +653,16 @@ template <bool LOGS>
 __global__ __launch_bounds__(1024) void walk_plan_build_kernel(const float *__restrict__ v, int64_t total, int32_t seg_len, int32_t n_seg, float per_row,
                                                                int32_t forced, const WalkPlan *__restrict__ cur, WalkPlan *__restrict__ next,
                                                                const float4 *__restrict__ aos, int32_t dim, int32_t p2, int32_t s_pad,
-                                                               float4 *__restrict__ walk_a, uint32_t *__restrict__ walk_c) {
+                                                               float4 *__restrict__ walk_a, uint32_t *__restrict__ walk_c, const unsigned int *__restrict__ gate) {
     extern __shared__ unsigned long long keys[];  // p2 sort keys (the build), behind them the histogram
+    if (gate && *gate == 0) {  // (uniform) a CSR call none of whose rows is walked: the standing plan and tables stay as they are
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            const WalkPlan was = *cur;
+            *next = was;
+            next->rebuild = 0;
+        }
+        return;
+    }
     uint32_t *hist = reinterpret_cast<uint32_t *>(keys + p2);
     __shared__ uint32_t wave_sum[16];
     __shared__ uint32_t part_above[1024];  // per thread: the sampled values in bins above the thread's own
@@ -802,7 +810,9 @@ __global__ __launch_bounds__(1024) void walk_plan_build_kernel(const float *__re
 }
 
 // plan (and tables, where the standing ones do not fit) for a call's logs; returns the plan the row kernels read
-static int launch_walk_plan(mhx_wgen *gen, const float *d_v, bool logs, int64_t total, int32_t seg_len, int32_t n_seg, float per_row, WalkPlan **plan_out) {
+// (gate: device word, may be NULL -- a CSR call whose entry-by-entry launch kept every row leaves it 0 and the launch does nothing)
+static int launch_walk_plan(mhx_wgen *gen, const float *d_v, bool logs, int64_t total, int32_t seg_len, int32_t n_seg, float per_row, WalkPlan **plan_out,
+                            const unsigned int *gate = nullptr) {
     mhx_ctx *ctx = gen->ctx;
     const int32_t dim = gen->dim;
     WalkPlan *plans = reinterpret_cast<WalkPlan *>(gen->d_walk_plan);
@@ -827,10 +837,10 @@ static int launch_walk_plan(mhx_wgen *gen, const float *d_v, bool logs, int64_t 
     WalkPlan *next = plans + (gen->plan_index ^ 1);
     if (logs)
         hipLaunchKernelGGL(walk_plan_build_kernel<true>, dim3((unsigned)gen->sample_size), dim3(1024), lds, ctx->stream, d_v, total, seg_len, n_seg, per_row,
-                           (int32_t)ctx->opt_weighted_tail, cur, next, reinterpret_cast<const float4 *>(gen->d_aos), dim, p2, gen->s_pad, walk_a, gen->d_walk_c);
+                           (int32_t)ctx->opt_weighted_tail, cur, next, reinterpret_cast<const float4 *>(gen->d_aos), dim, p2, gen->s_pad, walk_a, gen->d_walk_c, gate);
     else
         hipLaunchKernelGGL(walk_plan_build_kernel<false>, dim3((unsigned)gen->sample_size), dim3(1024), lds, ctx->stream, d_v, total, seg_len, n_seg, per_row,
-                           (int32_t)ctx->opt_weighted_tail, cur, next, reinterpret_cast<const float4 *>(gen->d_aos), dim, p2, gen->s_pad, walk_a, gen->d_walk_c);
+                           (int32_t)ctx->opt_weighted_tail, cur, next, reinterpret_cast<const float4 *>(gen->d_aos), dim, p2, gen->s_pad, walk_a, gen->d_walk_c, gate);
     MHX_HIP_CHECK(hipGetLastError());
     gen->plan_index ^= 1;
     *plan_out = next;
@@ -1836,8 +1846,15 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
 // 64 samples, four table entries in flight); a row that stores many is spread out in LDS (-inf where nothing is stored)
 // and walked like a dense row (weighted_walk_csr_kernel: one workgroup per row).  The two kernels share the rows out by
 // the same test on the row's length.
-__device__ __forceinline__ bool csr_row_is_walked(int64_t nnz, int32_t dim, int32_t direct_permille) {
-    return nnz * 1000 > (int64_t)direct_permille * dim;
+// `mode` > 0: option weighted.direct, a fixed share of the columns in per mille (A/B runs); 0: by cost.  Measured on an MI355X over
+// densities 0.02 .. 0.5 of (1024 columns, 64 samples), (4096, 128), (1024, 256) -- profiles/r06_sweep_weighted_csr.txt --, per
+// 20 000 rows: entry by entry 0.74 us x stored entries x chunks of 64 samples; walked (0.07 + 3e-5 dim) ms for clearing and
+// spreading the row + (0.018 + 0.0092 chunks) ms / density for the positions a walk passes before it meets stored columns.  The
+// fixed 10 % of rounds 3-5 sat on the crossover of (4096, 128) only: 1024 columns x 64 samples at 10 % ran 0.30 ms where entry by
+// entry takes 0.115.  Only speed depends on the choice: both kernels produce the reference's (k, t) for any row.
+__host__ __device__ __forceinline__ bool csr_row_is_walked(int64_t nnz, int32_t dim, int32_t chunks, int32_t mode) {
+    if (mode > 0) return nnz * 1000 > (int64_t)mode * dim;
+    return 74 * (int64_t)chunks * nnz * nnz > (7000 + 3 * (int64_t)dim) * nnz + (1800 + 920 * (int64_t)chunks) * dim;
 }
 
 // every stored entry of a CSR row with numpy's argmin (first minimum in storage order; the first NaN wins); entries come
@@ -1902,7 +1919,7 @@ __global__ __launch_bounds__(256) void weighted_csr_direct_kernel(const int64_t 
                                                                   const float *__restrict__ logs_, int64_t n_rows, int32_t dim,
                                                                   int32_t direct_permille, const float4 *__restrict__ aos,
                                                                   int32_t sample_size, int32_t s_pad, int64_t *__restrict__ out,
-                                                                  uint8_t *__restrict__ nonempty) {
+                                                                  uint8_t *__restrict__ nonempty, unsigned int *__restrict__ n_walked) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_block = blockDim.x >> 6;
@@ -1912,11 +1929,15 @@ __global__ __launch_bounds__(256) void weighted_csr_direct_kernel(const int64_t 
     const int64_t MHX_CONST_AS *indptr = (const int64_t MHX_CONST_AS *)indptr_;
     const int32_t MHX_CONST_AS *indices = (const int32_t MHX_CONST_AS *)indices_;
     const float MHX_CONST_AS *logs = (const float MHX_CONST_AS *)logs_;
+    unsigned int left = 0;  // rows this wave leaves to the walk kernel (counted once per row: by chunk 0)
     for (int64_t row = (int64_t)(blockIdx.x / chunks) * waves_per_block + wave; row < n_rows;
          row += (int64_t)(gridDim.x / chunks) * waves_per_block) {
         const int64_t beg = indptr[row], end = indptr[row + 1];
         if (ch == 0 && lane == 0) nonempty[row] = end > beg ? 1 : 0;
-        if (direct_permille >= 0 && csr_row_is_walked(end - beg, dim, direct_permille)) continue;  // the walk kernel's row
+        if (direct_permille >= 0 && csr_row_is_walked(end - beg, dim, (int32_t)chunks, direct_permille)) {  // the walk kernel's row
+            left += ch == 0 ? 1u : 0u;
+            continue;
+        }
         int64_t k = 0, t = 0;
         if (end > beg) csr_row_by_entry(indices, logs, logs_, beg, end, aos, s_pad, my, k, t);
         if (my < sample_size) {
@@ -1925,6 +1946,8 @@ __global__ __launch_bounds__(256) void weighted_csr_direct_kernel(const int64_t 
             o[1] = t;
         }
     }
+    // the plan and walk launches behind this one do nothing at all when no row is theirs (a corpus of short rows: 15 % of the call)
+    if (n_walked && left && lane == 0) atomicAdd(n_walked, left);
 }
 
 __global__ __launch_bounds__(256) void weighted_walk_csr_kernel(const int64_t *__restrict__ indptr_, const int32_t *__restrict__ indices_,
@@ -1932,8 +1955,9 @@ __global__ __launch_bounds__(256) void weighted_walk_csr_kernel(const int64_t *_
                                                                 int32_t direct_permille, const WalkPlan *__restrict__ plan,
                                                                 const float4 *__restrict__ walk_a, const uint32_t *__restrict__ walk_c,
                                                                 const float4 *__restrict__ aos, int32_t sample_size, int32_t s_pad,
-                                                                int32_t list_cap, int64_t *__restrict__ out) {
+                                                                int32_t list_cap, int64_t *__restrict__ out, const unsigned int *__restrict__ n_walked) {
     extern __shared__ float row[];                                             // dim logs of the row (-inf: not stored)
+    if (n_walked && *n_walked == 0) return;  // (uniform) the entry-by-entry launch kept every row
     uint16_t *list = reinterpret_cast<uint16_t *>(row + ((dim + 3) & ~3));    // columns above the cut (list_cap of them)
     __shared__ int s_nout, s_odd;
     const int tid = threadIdx.x, lane = tid & (kWave - 1);
@@ -1953,7 +1977,7 @@ __global__ __launch_bounds__(256) void weighted_walk_csr_kernel(const int64_t *_
     const int64_t MHX_CONST_AS *indptr = (const int64_t MHX_CONST_AS *)indptr_;
     for (int64_t d = blockIdx.x; d < n_rows; d += gridDim.x) {
         const int64_t beg = indptr[d], end = indptr[d + 1];
-        if (!csr_row_is_walked(end - beg, dim, direct_permille)) continue;  // the direct kernel's row
+        if (!csr_row_is_walked(end - beg, dim, chunks, direct_permille)) continue;  // the direct kernel's row
         if (tid == 0) s_nout = 0, s_odd = 0;
         for (int c = tid; c < dim; c += blockDim.x) row[c] = -__builtin_inff();
         __syncthreads();
@@ -2235,31 +2259,37 @@ static int launch_weighted_csr_walk(mhx_wgen *gen, const int64_t *d_indptr, cons
             if (int rc = launch_weighted_log(ctx, d_values, nnz, (float *)ctx->scratch[3])) return rc;
         d_logs = (const float *)ctx->scratch[3];
     }
-    const int32_t direct_permille = ctx->opt_weighted_direct > 0 ? (int32_t)ctx->opt_weighted_direct : 100;
+    const int32_t direct_mode = ctx->opt_weighted_direct > 0 ? (int32_t)ctx->opt_weighted_direct : 0;  // 0: by cost (csr_row_is_walked)
     WalkPlan *plan = reinterpret_cast<WalkPlan *>(gen->d_walk_plan) + gen->plan_index;
     float4 *walk_a = reinterpret_cast<float4 *>(gen->d_walk_a);
-    const bool any_walk = nnz * 1000 > (int64_t)direct_permille * dim;  // some row may be long enough
-    if (any_walk) {
-        const int32_t seg = (int32_t)std::min<int64_t>(nnz, 1024);
-        if (int rc = launch_walk_plan(gen, d_logs, true, nnz, seg, (int32_t)std::min<int64_t>(16, nnz / seg),
-                                      (float)std::min<double>((double)dim, (double)nnz / (double)std::max<int64_t>(n_rows, 1)), &plan))
-            return rc;
-    }
     const int64_t chunks = gen->s_pad / kWave;
+    const bool any_walk = csr_row_is_walked(std::min<int64_t>(nnz, dim), dim, (int32_t)chunks, direct_mode);  // the longest row there can be
+    // The entry-by-entry launch goes first and counts the rows it leaves to the walk (d_work word 12); the plan and walk launches
+    // read the count and return at once when it is 0.  The two-launch plan (dim > 8192) has no gate: it always runs.
+    unsigned int *d_gate = nullptr;
+    if (any_walk) {
+        if (int rc = ctx->ensure_work()) return rc;
+        d_gate = ctx->d_work + 12;
+        MHX_HIP_CHECK(hipMemsetAsync(d_gate, 0, sizeof(unsigned int), ctx->stream));
+    }
     const int64_t want = (n_rows + 3) / 4;
     const int64_t groups = std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * (ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu : 16) / chunks));
     hipLaunchKernelGGL(weighted_csr_direct_kernel, dim3((unsigned)(groups * chunks)), dim3(256), 0,
-                       ctx->stream, d_indptr, d_indices, d_logs, n_rows, dim, any_walk ? direct_permille : -1,
-                       reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, d_out, d_nonempty);
+                       ctx->stream, d_indptr, d_indices, d_logs, n_rows, dim, any_walk ? direct_mode : -1,
+                       reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, d_out, d_nonempty, d_gate);
     MHX_HIP_CHECK(hipGetLastError());
     if (any_walk) {
+        const int32_t seg = (int32_t)std::min<int64_t>(nnz, 1024);
+        if (int rc = launch_walk_plan(gen, d_logs, true, nnz, seg, (int32_t)std::min<int64_t>(16, nnz / seg),
+                                      (float)std::min<double>((double)dim, (double)nnz / (double)std::max<int64_t>(n_rows, 1)), &plan, d_gate))
+            return rc;
         const int32_t list_cap = std::max(64, dim / 4);
         const int32_t n_cc = std::min<int32_t>(gen->s_pad / kWave, kCachedChunks);
         const size_t lds = sizeof(float) * (size_t)((dim + 3) & ~3) + sizeof(uint16_t) * (size_t)((list_cap + 7) & ~7) + 20 * (size_t)n_cc * kWalkCached * kWave;
         const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(8, (int64_t)((160 << 10) / (lds + 64))));
         const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(n_rows, per_cu * ctx->num_cus));
-        hipLaunchKernelGGL(weighted_walk_csr_kernel, dim3(blocks), dim3(256), lds, ctx->stream, d_indptr, d_indices, d_logs, n_rows, dim, direct_permille,
-                           plan, walk_a, gen->d_walk_c, reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, list_cap, d_out);
+        hipLaunchKernelGGL(weighted_walk_csr_kernel, dim3(blocks), dim3(256), lds, ctx->stream, d_indptr, d_indices, d_logs, n_rows, dim, direct_mode,
+                           plan, walk_a, gen->d_walk_c, reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, list_cap, d_out, d_gate);
         MHX_HIP_CHECK(hipGetLastError());
     }
     return MHX_OK;

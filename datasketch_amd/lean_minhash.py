@@ -135,3 +135,38 @@ def serialize_matrix(signatures: np.ndarray, seed: int, gpu_mode: str = "always"
     out[:, 8:12] = np.frombuffer(struct.pack("<i", k), dtype=np.uint8)
     out[:, 12:] = signatures.astype("<u4").view(np.uint8).reshape(n, 4 * k)
     return out
+
+
+_BIG = {">": True, "!": True, "<": False, "=": struct.pack("=I", 1) != struct.pack("<I", 1), "@": struct.pack("@I", 1) != struct.pack("<I", 1)}
+
+
+def deserialize_matrix(buf, num_perm: Optional[int] = None, byteorder: str = "@", gpu_mode: str = "always"):
+    """``LeanMinHash.deserialize`` (ref: datasketch/lean_minhash.py:177-214) of a buffer of N records laid back to back --
+    what :func:`serialize_matrix` writes, or N ``serialize`` calls as in the reference's docstring example -- without N
+    Python objects.  Returns ``(seeds int64[N], hashvalues uint64[N, K])``.  ``byteorder``: any of the reference's
+    (``@ = < > !``).  ``num_perm``: taken from the first record when not given; a record with another length field is a
+    ``ValueError`` (the reference would read a different number of values there and mis-frame everything behind it).
+    Runs on the device unless ``gpu_mode='disable'``."""
+    if byteorder not in _BIG:
+        raise struct.error("bad char in struct format")
+    raw = np.frombuffer(memoryview(buf), dtype=np.uint8) if not isinstance(buf, np.ndarray) else np.ascontiguousarray(buf).view(np.uint8).reshape(-1)
+    big = _BIG[byteorder]
+    if raw.size == 0:
+        return np.empty(0, dtype=np.int64), np.empty((0, int(num_perm or 0)), dtype=np.uint64)
+    if raw.size < 12:
+        raise struct.error("unpack_from requires a buffer of at least 12 bytes")
+    k = int(np.frombuffer(raw[8:12].tobytes(), dtype=">i4" if big else "<i4")[0]) if num_perm is None else int(num_perm)
+    rec = 12 + 4 * k
+    if k <= 0 or raw.size % rec:
+        raise ValueError("the buffer is not a whole number of %d-byte records (num_perm = %d)" % (rec, k))
+    if gpu_mode != "disable" and (gpu_mode == "always" or _native.gpu_detected()):
+        try:
+            return _native.context().lean_deserialize(raw, k, big)
+        except ValueError as e:
+            raise ValueError(str(e)) from None
+    rows = raw.reshape(-1, rec)
+    lengths = rows[:, 8:12].copy().view(">i4" if big else "<i4").reshape(-1)
+    if np.any(lengths != k):
+        raise ValueError("%d of %d records do not hold %d hash values (length field)" % (int(np.count_nonzero(lengths != k)), rows.shape[0], k))
+    seeds = rows[:, :8].copy().view(">i8" if big else "<i8").reshape(-1).astype(np.int64)
+    return seeds, rows[:, 12:].copy().view(">u4" if big else "<u4").astype(np.uint64)

@@ -366,21 +366,69 @@ class MinHash:
                 yield m._spawn(row.copy())
 
     @classmethod
-    def bulk_signatures(cls, b, out_dtype=np.uint64, **minhash_kwargs) -> np.ndarray:
+    def bulk_signatures(cls, b=None, out_dtype=np.uint64, packed=None, **minhash_kwargs) -> np.ndarray:
         """Not in the reference: the ``[N, K]`` signature matrix of a corpus, without creating N
         Python objects.  ``b`` is any iterable of token iterables, or -- with ``hashfunc=prehashed``
         -- a 2-D integer array (fixed-length sets; a uint32 array is uploaded as it is) or a
         ``(values, offsets)`` CSR pair of already hashed tokens.  ``out_dtype``: uint64 (the
-        reference's ``hashvalues`` type) or uint32 (values are < 2**32: half the bytes back)."""
+        reference's ``hashvalues`` type) or uint32 (values are < 2**32: half the bytes back).
+
+        ``packed=(buf, byte_offsets, set_offsets)`` instead of ``b``: byte tokens already packed back to back --
+        token ``i`` is ``buf[byte_offsets[i]:byte_offsets[i+1]]``, set ``j`` owns tokens ``set_offsets[j] ..
+        set_offsets[j+1]`` (what a tokenizer writing into one buffer produces; the layout of
+        ``mhx_minhash_bulk_bytes``).  No per-object packing on the host at all: with the default ``hashfunc``
+        (``sha1_hash32``, or ``sha1_hash64``) SHA-1 and MinHash both run on the device; any other ``hashfunc``, or
+        ``gpu_mode='disable'``, is applied per token on the host (ref: minhash.py:262-263)."""
         if np.dtype(out_dtype) not in (np.dtype(np.uint64), np.dtype(np.uint32)):
             raise ValueError("out_dtype must be uint64 or uint32")
+        if (b is None) == (packed is None):
+            raise ValueError("give the corpus either as b or as packed=(buf, byte_offsets, set_offsets)")
         m = cls(**minhash_kwargs)
         if np.dtype(out_dtype) == np.uint32 and not m.is_empty() and int(m.hashvalues.max()) > 0xFFFFFFFF:
             raise ValueError("initial hashvalues >= 2**32 do not fit uint32 signatures")
-        blocks = list(m._bulk_chunks(b, np.dtype(out_dtype)))
+        blocks = list(m._packed_chunks(packed, np.dtype(out_dtype)) if packed is not None else m._bulk_chunks(b, np.dtype(out_dtype)))
         if not blocks:
             return np.empty((0, len(m)), dtype=out_dtype)
         return blocks[0] if len(blocks) == 1 else np.concatenate(blocks, axis=0)
+
+    def _packed_chunks(self, packed, out_dtype=np.uint64) -> Generator[np.ndarray, None, None]:
+        """Signature blocks of a corpus of packed byte tokens, in chunks of whole sets (see :meth:`bulk_signatures`)."""
+        if not (isinstance(packed, tuple) and len(packed) == 3):
+            raise ValueError("packed is a (buf, byte_offsets, set_offsets) triple")
+        buf = np.frombuffer(memoryview(packed[0]), dtype=np.uint8) if not isinstance(packed[0], np.ndarray) else np.ascontiguousarray(packed[0]).view(np.uint8).reshape(-1)
+        byte_offsets = np.ascontiguousarray(packed[1], dtype=np.int64).reshape(-1)
+        set_offsets = np.ascontiguousarray(packed[2], dtype=np.int64).reshape(-1)
+        if byte_offsets.size < 1 or set_offsets.size < 1:
+            raise ValueError("byte_offsets has tokens + 1 entries and set_offsets sets + 1")
+        n_tokens, n_sets = byte_offsets.size - 1, set_offsets.size - 1
+        if byte_offsets[0] != 0 or byte_offsets[-1] > buf.size or np.any(np.diff(byte_offsets) < 0):
+            raise ValueError("byte_offsets must start at 0, never decrease and end inside buf")
+        if set_offsets[0] != 0 or set_offsets[-1] != n_tokens or np.any(np.diff(set_offsets) < 0):
+            raise ValueError("set_offsets must start at 0, never decrease and end at the number of tokens")
+        init = None if self.is_empty() else self.hashvalues
+        bits = 32 if self.hashfunc is sha1_hash32 else 64 if self.hashfunc is sha1_hash64 else 0
+        on_device = bits and self._use_gpu()
+        s = 0
+        while s < n_sets:
+            # whole sets, at most _BULK_CHUNK_SETS of them and about _BULK_CHUNK_TOKENS tokens (one set may exceed that alone)
+            e = min(n_sets, s + _BULK_CHUNK_SETS)
+            t0 = int(set_offsets[s])
+            if int(set_offsets[e]) - t0 > _BULK_CHUNK_TOKENS:
+                e = max(s + 1, int(np.searchsorted(set_offsets, t0 + _BULK_CHUNK_TOKENS, side="right")) - 1)
+            t1 = int(set_offsets[e])
+            b0 = int(byte_offsets[t0])
+            local_bytes = byte_offsets[t0: t1 + 1] - b0
+            local_sets = set_offsets[s: e + 1] - t0
+            piece = buf[b0: int(byte_offsets[t1])]
+            if on_device:
+                blk = _native.context().minhash_bulk_bytes(self.permutations, piece, local_bytes, local_sets, init, bits=bits)
+            else:
+                f = self.hashfunc
+                raw = piece.tobytes()
+                hv = _as_hash_array([f(raw[local_bytes[i]: local_bytes[i + 1]]) for i in range(t1 - t0)]).reshape(-1) if t1 > t0 else np.empty(0, dtype=np.uint64)
+                blk = self._signatures_csr(hv, local_sets, 0, e - s, init)
+            yield blk.astype(out_dtype, copy=False)
+            s = e
 
     # ------------------------------------------------------------------ pickling
     # State is plain numpy + the gpu_mode string: device handles live in the process-wide

@@ -114,6 +114,13 @@ MHX_API int mhx_ctx_counters(mhx_ctx *ctx, int enable, uint64_t out[MHX_NUM_COUN
  * repeated tokens.  Timings depend on it (so a benchmark may want to know, or to reset it), results never.  reset != 0 puts it
  * back to 0, the state of a fresh context.  mode may be NULL.  Blocking. */
 MHX_API int mhx_ctx_minhash_mode(mhx_ctx *ctx, int reset, int *mode);
+/* Diagnostics for parity audits: which sets of the LAST mhx_minhash_bulk_dev call on this context left the fast path.  The
+ * result of every set is exact whatever its flag says (ref: datasketch/minhash.py:293-297) -- the flag names the launch that
+ * produced it, so that a test can check exactly the sets the rare-event paths handled: flags[i] = 0 the first launch's proof
+ * held for set i, 1 = set i was done again by the second launch (tie-tolerant / dedup sieve), 2 = hashed pair by pair by the
+ * third.  n_sets must be the last call's; a call that kept no flags (one huge set split over waves, minhash.path != 0) is
+ * MHX_ERR_INVALID.  With more than 256 permutations (several passes over the sets) the flags are the last pass's.  Blocking. */
+MHX_API int mhx_ctx_minhash_flags(mhx_ctx *ctx, int64_t n_sets, uint8_t *flags);
 
 /* ---- device memory + events (so callers can keep corpora resident and time kernels) ------- */
 MHX_API int mhx_dev_alloc(mhx_ctx *ctx, size_t bytes, void **dptr);
@@ -422,6 +429,25 @@ MHX_API int mhx_lean_serialize_dev(mhx_ctx *ctx, const uint64_t *d_sig, int64_t 
                                    int32_t num_perm, int64_t seed, uint8_t *d_out);
 MHX_API int mhx_lean_serialize(mhx_ctx *ctx, const uint64_t *sig, int64_t n_sigs, int32_t num_perm,
                                int64_t seed, uint8_t *out);
+/* The same for a matrix of sig_dtype (MHX_U32: the compact form) in either byte order the reference's `byteorder` argument can ask
+ * for: MHX_LITTLE_ENDIAN is '<' (and '@' / '=' on this little-endian host), MHX_BIG_ENDIAN is '>' / '!' (network order). */
+#define MHX_LITTLE_ENDIAN 0
+#define MHX_BIG_ENDIAN 1
+MHX_API int mhx_lean_serialize_dev_typed(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_t n_sigs, int32_t num_perm,
+                                         int64_t seed, int byteorder, uint8_t *d_out);
+/* The inverse: LeanMinHash.deserialize of n records of 12 + 4*K bytes laid back to back (ref: datasketch/lean_minhash.py:177-214):
+ * d_sig [n, K] of sig_dtype receives the hash values, d_seeds (may be NULL) int64[n] each record's seed.  A record whose length
+ * field is not num_perm is counted in *d_bad (uint32 on the device, may be NULL; the caller zeroes it) -- the host entry point
+ * returns MHX_ERR_INVALID for such a buffer.  Records need 4-byte alignment. */
+MHX_API int mhx_lean_deserialize_dev(mhx_ctx *ctx, const uint8_t *d_records, int64_t n_sigs, int32_t num_perm, int byteorder,
+                                     int sig_dtype, void *d_sig, int64_t *d_seeds, uint32_t *d_bad);
+MHX_API int mhx_lean_deserialize(mhx_ctx *ctx, const uint8_t *records, int64_t n_sigs, int32_t num_perm, int byteorder,
+                                 uint64_t *sig, int64_t *seeds);
+/* The inverse of mhx_bbit_pack*: bBitMinHash.__setstate__ of every row (ref: datasketch/b_bit_minhash.py:103-125) --
+ * blocks [n, num_blocks] uint64 -> the b-bit values [n, num_perm] uint32 (what a restored bBitMinHash holds as hashvalues). */
+MHX_API int mhx_bbit_unpack_dev(mhx_ctx *ctx, const uint64_t *d_blocks, int64_t n_sigs, int32_t num_perm, int32_t b,
+                                uint32_t *d_out);
+MHX_API int mhx_bbit_unpack(mhx_ctx *ctx, const uint64_t *blocks, int64_t n_sigs, int32_t num_perm, int32_t b, uint32_t *out);
 
 /* ---- Multi-GPU: assemble the signature matrix (RCCL over xGMI) ----------------------------- */
 /* 128-byte RCCL unique id, created on rank 0 and distributed by the caller (env, file, socket). */

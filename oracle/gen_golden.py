@@ -194,6 +194,18 @@ def main():
     arrays["w2_in"] = x2
     arrays["w2_out"] = np.stack([r.hashvalues for r in g2.minhash_many(x2)])
 
+    # ---- 10b. the inverse wire formats as the reference itself reads them (round 6: bulk deserialize / unpack)
+    for bo, name in (("<", "le"), (">", "be"), ("@", "native"), ("!", "network")):
+        buf = bytearray(lm.bytesize(bo))
+        lm.serialize(buf, bo)
+        back = LeanMinHash.deserialize(buf, bo)
+        meta[f"lean_deserialize_{name}"] = {"bytes": bytes(buf).hex(), "seed": int(back.seed), "hashvalues": [int(v) for v in back.hashvalues]}
+    restored = {}
+    for b in (1, 2, 3, 7, 13, 32):
+        back = pickle.loads(pickle.dumps(bBitMinHash(m48, b)))   # bBitMinHash.__setstate__
+        restored[str(b)] = [int(v) for v in back.hashvalues]
+    meta["bbit_restored_k48"] = restored
+
     # ---- 11. pickles of the reference classes (cross-load check for our mirrors' state layout)
     meta["minhash_pickle_keys"] = sorted(MinHash(4, 1).__getstate__().keys())
 

@@ -271,6 +271,37 @@ def pack_and_lsh_cases(ctx):
         _done(f"lean serialize n={n} K={k}")
 
 
+def inverse_format_cases(ctx):
+    """Round 6: the inverse wire formats (mhx_bbit_unpack_dev, mhx_lean_deserialize_dev) and the typed / big-endian serialiser."""
+    lib = ctx.lib
+    rng = np.random.RandomState(606)
+    for n, k in ((1, 1), (3, 7), (65, 64), (33, 130), (257, 256)):
+        sig = rng.randint(0, 2**32, (n, k), dtype=np.uint64)
+        for b in (0, 1, 2, 3, 5, 8, 13, 16, 24, 32):
+            blocks = O.c_bbit_pack(sig, b)
+            d_blk, d_out = _dev(ctx, blocks), _alloc(ctx, n * k * 4)
+            check(lib.mhx_bbit_unpack_dev(ctx.handle, _p(d_blk), n, k, b, _p(d_out)))
+            _expect(d_out.download((n, k), np.uint32), (sig & np.uint64((1 << b) - 1)).astype(np.uint32), f"bbit unpack n={n} K={k} b={b}")
+            _done(f"bbit unpack n={n} K={k} b={b}")
+        for big in (0, 1):
+            for code, dt in ((MHX_U64, np.uint64), (MHX_U32, np.uint32)):
+                want = O.c_lean_serialize(sig, -77 - n)  # little-endian records
+                if big:
+                    w = want.reshape(n, -1).copy()
+                    w[:, :8] = w[:, 7::-1]
+                    w[:, 8:] = w[:, 8:].reshape(n, -1, 4)[:, :, ::-1].reshape(n, -1)
+                    want = w.reshape(want.shape)
+                d_sig, d_rec = _dev(ctx, sig.astype(dt)), _alloc(ctx, n * (12 + 4 * k))
+                check(lib.mhx_lean_serialize_dev_typed(ctx.handle, _p(d_sig), code, n, k, -77 - n, big, _p(d_rec)))
+                _expect(d_rec.download(want.shape, np.uint8), want, f"lean serialize typed n={n} K={k} big={big} code={code}")
+                d_back, d_seeds, d_bad = _alloc(ctx, n * k * np.dtype(dt).itemsize), _alloc(ctx, n * 8), _dev(ctx, np.zeros(1, dtype=np.uint32))
+                check(lib.mhx_lean_deserialize_dev(ctx.handle, _p(d_rec), n, k, big, code, _p(d_back), _p(d_seeds), _p(d_bad)))
+                _expect(d_back.download((n, k), dt), sig.astype(dt), f"lean deserialize n={n} K={k} big={big} code={code}")
+                _expect(d_seeds.download((n,), np.int64), np.full(n, -77 - n, dtype=np.int64), "lean deserialize seeds")
+                _expect(d_bad.download((1,), np.uint32), np.zeros(1, dtype=np.uint32), "lean deserialize bad count")
+                _done(f"lean round trip n={n} K={k} big={big} code={code}")
+
+
 def overread(ctx):
     """The positive control: mhx_minhash_merge_dev told that its inputs are one granule longer than they are."""
     granule, _ = _native.guard_alloc(int(sys.argv[1]))
@@ -295,6 +326,7 @@ def main():
     sha1_cases(ctx)
     weighted_cases(ctx)
     pack_and_lsh_cases(ctx)
+    inverse_format_cases(ctx)
     ctx.synchronize()
     _, live = _native.guard_alloc(align)
     if FAILED:

@@ -220,3 +220,96 @@ def test_two_rank_gloo_ragged_shards_and_the_by_band_exchange_equal_the_single_p
         b = sum(counts[:rank])
         tokens_per_rank.append(int(offsets[b + counts[rank]] - offsets[b]))
     assert abs(tokens_per_rank[0] - tokens_per_rank[1]) <= 400  # balanced by tokens, within one longest row
+
+
+# ---- the inverse wire formats and packed byte input, host (numpy) side; the device side is tests/test_gpu_round6.py ----
+def _golden():
+    import json
+
+    with open(os.path.join(ROOT, "tests", "golden", "golden.json")) as f:
+        return json.load(f), np.load(os.path.join(ROOT, "tests", "golden", "golden.npz"))
+
+
+def test_deserialize_matrix_reads_what_the_reference_wrote_in_every_byte_order():
+    """ref: lean_minhash.py:177-214 -- the records come from the reference's own serialize, the expected values from its
+    own deserialize (tests/golden, oracle/gen_golden.py section 10b)."""
+    import struct
+
+    from datasketch_amd import LeanMinHash
+    from datasketch_amd.lean_minhash import deserialize_matrix, serialize_matrix
+
+    meta, arrays = _golden()
+    for bo, name in (("<", "le"), (">", "be"), ("@", "native"), ("!", "network")):
+        g = meta[f"lean_deserialize_{name}"]
+        rec = bytes.fromhex(g["bytes"])
+        seeds, sig = deserialize_matrix(rec * 3, byteorder=bo, gpu_mode="disable")
+        assert seeds.tolist() == [g["seed"]] * 3 and sig.dtype == np.uint64
+        assert sig.tolist() == [g["hashvalues"]] * 3
+        one = LeanMinHash.deserialize(rec, bo)  # the per-object form agrees
+        assert one.seed == g["seed"] and one.hashvalues.tolist() == g["hashvalues"]
+    # round trip of a matrix, and the error cases
+    sig = np.random.RandomState(2).randint(0, 2**32, (17, 24), dtype=np.uint64)
+    raw = serialize_matrix(sig, 99, gpu_mode="disable")
+    seeds, back = deserialize_matrix(raw, gpu_mode="disable")
+    assert np.array_equal(back, sig) and np.all(seeds == 99)
+    assert np.array_equal(deserialize_matrix(raw, num_perm=24, byteorder="<", gpu_mode="disable")[1], sig)
+    bad = raw.copy()
+    bad[5, 8] ^= 1  # one record claims another length
+    with pytest.raises(ValueError):
+        deserialize_matrix(bad, gpu_mode="disable")
+    with pytest.raises(ValueError):
+        deserialize_matrix(raw.reshape(-1)[:-4], gpu_mode="disable")
+    with pytest.raises(struct.error):
+        deserialize_matrix(raw, byteorder="?", gpu_mode="disable")
+    assert deserialize_matrix(b"", num_perm=8, gpu_mode="disable")[1].shape == (0, 8)
+
+
+def test_unpack_matrix_restores_what_the_reference_restores():
+    """ref: b_bit_minhash.py:103-125 -- the packed states and the restored hashvalues both come from the reference."""
+    from datasketch_amd.b_bit_minhash import pack_matrix, unpack_matrix
+
+    meta, arrays = _golden()
+    for b, state in meta["bbit_states_k48"].items():
+        raw = bytes.fromhex(state)
+        blocks = np.frombuffer(raw[21:], dtype="<u8").reshape(1, -1)  # behind the 21-byte "<qBdi" header
+        got = unpack_matrix(blocks, 48, int(b), gpu_mode="disable")
+        assert got.dtype == np.uint32 and got[0].tolist() == meta["bbit_restored_k48"][b]
+    sig = np.random.RandomState(4).randint(0, 2**32, (9, 70), dtype=np.uint64)
+    for b in (0, 1, 2, 3, 4, 6, 8, 11, 16, 25, 32):
+        assert np.array_equal(unpack_matrix(pack_matrix(sig, b, gpu_mode="disable"), 70, b, gpu_mode="disable"), (sig & np.uint64((1 << b) - 1)).astype(np.uint32))
+    with pytest.raises(ValueError):
+        unpack_matrix(np.zeros((2, 3), dtype=np.uint64), 70, 8, gpu_mode="disable")
+    with pytest.raises(ValueError):
+        unpack_matrix(np.zeros((2, 3), dtype=np.uint64), 70, 33, gpu_mode="disable")
+
+
+def test_bulk_signatures_from_packed_byte_tokens_equals_the_per_object_corpus():
+    """packed=(buf, byte_offsets, set_offsets): the same signatures as the list-of-lists corpus (ref: minhash.py:491-522 with the
+    default hashfunc), on the host path here; chunk boundaries inside the corpus; empty sets and empty tokens."""
+    from datasketch_amd import MinHash, minhash as mh_mod, sha1_hash64
+
+    rng = np.random.RandomState(8)
+    sets = [[bytes(rng.randint(0, 256, rng.randint(0, 12), dtype=np.uint8)) for _ in range(rng.randint(0, 9))] for _ in range(40)]
+    sets[3], sets[-1] = [], []
+    flat = [t for s in sets for t in s]
+    buf = np.frombuffer(b"".join(flat), dtype=np.uint8)
+    byte_offsets = np.concatenate([[0], np.cumsum([len(t) for t in flat])]).astype(np.int64)
+    set_offsets = np.concatenate([[0], np.cumsum([len(s) for s in sets])]).astype(np.int64)
+    want = MinHash.bulk_signatures(sets, num_perm=16, seed=5, gpu_mode="disable")
+    got = MinHash.bulk_signatures(packed=(buf, byte_offsets, set_offsets), num_perm=16, seed=5, gpu_mode="disable")
+    assert np.array_equal(got, want)
+    old = mh_mod._BULK_CHUNK_SETS, mh_mod._BULK_CHUNK_TOKENS
+    try:
+        mh_mod._BULK_CHUNK_SETS, mh_mod._BULK_CHUNK_TOKENS = 7, 11  # many chunks, some cut by the token budget
+        assert np.array_equal(MinHash.bulk_signatures(packed=(bytes(buf), byte_offsets, set_offsets), num_perm=16, seed=5, gpu_mode="disable"), want)
+    finally:
+        mh_mod._BULK_CHUNK_SETS, mh_mod._BULK_CHUNK_TOKENS = old
+    want64 = MinHash.bulk_signatures(sets, num_perm=16, seed=5, hashfunc=sha1_hash64, gpu_mode="disable")
+    assert np.array_equal(MinHash.bulk_signatures(packed=(buf, byte_offsets, set_offsets), num_perm=16, seed=5, hashfunc=sha1_hash64, gpu_mode="disable"), want64)
+    assert MinHash.bulk_signatures(packed=(buf, byte_offsets, set_offsets), num_perm=16, seed=5, out_dtype=np.uint32, gpu_mode="disable").dtype == np.uint32
+    with pytest.raises(ValueError):
+        MinHash.bulk_signatures(sets, packed=(buf, byte_offsets, set_offsets), num_perm=16)
+    with pytest.raises(ValueError):
+        MinHash.bulk_signatures(packed=(buf, byte_offsets, set_offsets + 1), num_perm=16, gpu_mode="disable")
+    with pytest.raises(ValueError):
+        MinHash.bulk_signatures(packed=(buf[:-1], byte_offsets, set_offsets), num_perm=16, gpu_mode="disable")
