@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void gather_digests_kernel(const uint64_t *__r
 //     cache lines), counts them per bin in LDS (the top bin_bits of the digest), reserves a range in
 //     every bin's slab with one global atomic per (workgroup, bin) and writes (digest, row) there.
 //   pass 2 (lsh_bin_sort_kernel): one workgroup per (band, bin) loads the slab (about 2400 elements) into LDS, spreads
-//     it over 2048 buckets by the next 11 digest bits (one or two elements per bucket), ranks every element inside its
+//     it over 2^kSubBits = 1024 buckets by the next kSubBits = 10 digest bits (two or three elements per bucket), ranks every element inside its
 //     bucket by (digest, row) and writes it to its place in the output: band * n + the sizes of the band's bins before
 //     it + the bucket's start + the rank.  The order is (band, digest, row): exactly what the stable radix sort of rows in
 //     ascending order gives.
@@ -163,9 +163,14 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
                 dg[j] = band_digest_of<SigT>(sig, at, band, k, r, n);
             }
         }
+        // (round 6) the counting atomic RETURNS the element's rank inside its (team, bin) piece: the staging loop below no longer
+        // runs a second atomic per element, and the output loop reads one table word per element (base - lstart) instead of two --
+        // seven LDS operations per element where there were nine, five of them at random addresses instead of seven
+        // (profiles/r05_traffic_lsh_sort.json: 0.555 of this kernel's LDS cycles were bank conflicts of exactly those)
+        uint16_t rank[kScatterRows];
 #pragma unroll
         for (int j = 0; j < kScatterRows; ++j)
-            if (row0 + j * 256 + tid < count) atomicAdd(&hist[gbin_of(dg[j]) & (nb - 1)], 1u);
+            rank[j] = row0 + j * 256 + tid < count ? (uint16_t)atomicAdd(&hist[gbin_of(dg[j]) & (nb - 1)], 1u) : (uint16_t)0;
         __syncthreads();
         // per bin: a range of its slab (one global atomic) and the start of its elements in the team's staging area
         // (exclusive scan of the counts: thread t owns bins [t * per, t * per + per))
@@ -187,9 +192,8 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
                 const int t = tid * per + j;
                 if (j < per && t < nb) {
                     if (bases[j] + cnts[j] > cap) *overflow = 1u;
-                    base[t] = bases[j];
+                    base[t] = bases[j] - at;  // slab position of staged element i of this bin = base[bin] + i (mod 2^32)
                     lstart[t] = at;
-                    hist[t] = 0;
                     at += cnts[j];
                 }
             }
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
             const int64_t row = row0 + j * 256 + tid;
             if (row < count) {
                 const uint32_t bin = gbin_of(dg[j]) & (nb - 1);
-                const uint32_t lp = lstart[bin] + atomicAdd(&hist[bin], 1u);
+                const uint32_t lp = lstart[bin] + rank[j];
                 st_dig[lp] = dg[j];
                 if constexpr (kPairs) st_row[lp] = rw[j];
                 else st_row[lp] = (uint16_t)(j * 256 + tid);
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
         for (uint32_t i = tid; i < total; i += 256) {
             const uint64_t d = st_dig[i];
             const uint32_t bin = gbin_of(d) & (nb - 1);
-            const uint32_t pos = base[bin] + (i - lstart[bin]);
+            const uint32_t pos = base[bin] + i;
             if (pos < cap) {
                 const int64_t at = (out0 + bin) * cap + pos;
                 slab_dig[at] = d;
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32
         // in LDS -- one LDS copy of the bin, three workgroups per CU
         // (a thread's loads all go out before the first is waited for -- a thread behind the bin's end reads its last element again --
         // and the LDS atomics follow in a loop of their own: with the atomic next to its load the compiler waited for every load
-        // in turn, six memory latencies per bin and pass)
+        // in turn, kMine = kBinCap / kSortThreads = six memory latencies per bin and pass)
         constexpr int kMine = (kBinCap + kSortThreads - 1) / kSortThreads;
         const uint32_t last = count ? count - 1 : 0;
         {
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32
                 if (tid + u * kSortThreads < count) atomicAdd(&cnt[sub_of(d[u])], 1u);
         }
         __syncthreads();
-        // exclusive scan of the 2048 bucket sizes: a thread's 8 buckets, then the threads' sums
+        // exclusive scan of the kSub = 1024 bucket sizes: a thread's kPer = 2 buckets, then the threads' sums
         uint32_t mine[kPer], sum = 0;
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
@@ -821,7 +825,7 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     const int64_t nb = (int64_t)1 << bin_bits, bins = nb * bands;
     const int64_t big_bins = hi_bits ? ((int64_t)bands << hi_bits) : 0;
     const uint32_t cap0 = hi_bits ? (uint32_t)std::min<int64_t>(0xFFFFFFFFll, (n >> hi_bits) + (n >> hi_bits) / 32 + 4096) : 0;  // 3 % + 4096 over the mean (sigma = sqrt(mean))
-    const size_t cur_bytes = ((sizeof(uint32_t) * (size_t)(2 * bins + big_bins + 2)) + 255) & ~(size_t)255;  // cursor[bins] | overflow | cursor0[big_bins] | overflow0 | bin_start[bins]
+    const size_t cur_bytes = ((sizeof(uint32_t) * (size_t)(2 * bins + big_bins + 2)) + 255) & ~(size_t)255;  // cursor[bins] | overflow | cursor0[big_bins] | overflow0 | bin_start[bins]: 2 * bins + big_bins + 2 words (both overflow words counted)
     const size_t dig_bytes = sizeof(uint64_t) * (size_t)bins * kBinCap, row_bytes = sizeof(uint32_t) * (size_t)bins * kBinCap;
     const size_t dig0_bytes = ((sizeof(uint64_t) * (size_t)big_bins * cap0) + 255) & ~(size_t)255, row0_bytes = ((sizeof(uint32_t) * (size_t)big_bins * cap0) + 255) & ~(size_t)255;
     if (cur_bytes + dig_bytes + row_bytes + dig0_bytes + row0_bytes > (size_t)ctx->hbm_bytes / 4) return MHX_OK;
@@ -886,15 +890,25 @@ int launch_lsh_sort_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtype, int64_
         bool done = false;
         const void *d_in = d_sig;
         int in_dtype = sig_dtype;
-        if (sig_dtype == kSigDigests && bands >= 2 && bands <= 64 && (bands & (bands - 1)) == 0 &&
-            ctx->ensure_scratch(4, sizeof(uint64_t) * (size_t)n * (size_t)bands) == MHX_OK) {
+        // The band-major copy of the digests (8 bytes per key in scratch[4], kept until mhx_ctx_release_scratch) is optional: it counts against
+        // the same quarter of the device's memory as the bucketing's slabs (~30 bytes per key, launch_lsh_bucket_bands) -- 10M x 32: 2.5 of 12 GB --
+        // and when it does not fit, or cannot be had, the bucketing reads the caller's matrix as it is and the call's error string stays empty.
+        const size_t pre_bytes = sizeof(uint64_t) * (size_t)n * (size_t)bands;
+        const bool pre_fits = pre_bytes + 30 * (size_t)n * (size_t)bands <= (size_t)ctx->hbm_bytes / 4;
+        const auto pre_buffer = [&]() {
+            if (!pre_fits) return false;
+            if (ctx->ensure_scratch(4, pre_bytes) == MHX_OK) return true;
+            forgive();
+            return false;
+        };
+        if (sig_dtype == kSigDigests && bands >= 2 && bands <= 64 && (bands & (bands - 1)) == 0 && pre_buffer()) {
             // a row-major digest matrix is turned band-major first (see digests_to_band_major_kernel)
             const int64_t tiles = (n * bands + 2047) / 2048;
             hipLaunchKernelGGL(digests_to_band_major_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>(tiles, (int64_t)ctx->num_cus * 16))), dim3(256), 0, ctx->stream,
                                (const uint64_t *)d_sig, n, __builtin_ctz((unsigned)bands), (uint64_t *)ctx->scratch[4]);
             if (hipGetLastError() == hipSuccess) d_in = ctx->scratch[4], in_dtype = kSigDigestsBM;
         } else if ((sig_dtype == MHX_U32 || sig_dtype == MHX_U64) && ctx->opt_lsh_prehash != 1 && bands >= 2 && bands <= 64 && (bands & (bands - 1)) == 0 &&
-                   ctx->ensure_scratch(4, sizeof(uint64_t) * (size_t)n * (size_t)bands) == MHX_OK) {
+                   pre_buffer()) {
             // a signature matrix: its band digests first, band-major (band_digest_bm_kernel: one read of the matrix at the stream's rate), then the
             // bucketing of the digests -- hashing r values inside the scatter pass's load loop cost more than the extra 8 bytes per key written and
             // read again (1.25M x 256 uint32, 32 x 8: 0.90 ms against 0.31 + 0.48).  Option lsh.prehash 1: hash inside the scatter pass.

@@ -26,6 +26,8 @@ void set_error(const char *fmt, ...) {
     g_last_error = buf;
 }
 
+void forgive() { g_last_error.clear(); }
+
 int fail(int code, const char *fmt, ...) {
     char buf[1024];
     va_list ap;

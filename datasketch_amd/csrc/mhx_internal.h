@@ -18,6 +18,7 @@ namespace mhx {
 // thread-local last-error string (mhx_last_error)
 void set_error(const char *fmt, ...);
 int fail(int code, const char *fmt, ...);
+void forgive();  // a failure the caller tolerates (an optional buffer that could not be had): the message of a call that succeeds is empty
 
 #define MHX_HIP_CHECK(expr)                                                                      \
     do {                                                                                         \

@@ -1509,7 +1509,7 @@ __global__ __launch_bounds__(256, 4) void weighted_walk_dense_kernel(const float
 constexpr int kHandWords = 12;             // SPLIT 2: per stripe {ready, scanned, what the fetcher found, n_stored, n_list, flags, done[0 .. 5] (one per chunk of samples)}
 constexpr int kHandDone = 6;
 constexpr int kSplitHandWords2 = 128;      // ... eight stripes at most
-constexpr uint32_t kSpinLimit = 1u << 24;  // polls (each ~100 cycles) a wave waits for the other side before it traps
+constexpr uint32_t kSpinLimit = 1u << 24;  // polls (each ~100 cycles) after which a wait traps -- with option weighted.debug bit 3 only
 template <bool LOGS, int NV, bool PAIRS, int FETCH = 0, int SPLIT = 0>  // NV: 16-byte loads per lane that hold a row (dim <= 256 NV); PAIRS: two chunks of samples walked as one instruction stream
 __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_kernel(const float *__restrict__ x, int64_t n_rows, int32_t dim,
                                                                  const WalkPlan *__restrict__ plan, const float4 *__restrict__ walk_a,
@@ -1738,7 +1738,10 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
         uint32_t *hands = reinterpret_cast<uint32_t *>(lds + 5 * n_cc * wcached * kWave);
         const auto wait_at_least = [&](uint32_t *word, uint32_t want) {
             for (uint32_t polls = 0; __hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < want; ++polls) {
-                if (polls > kSpinLimit) __builtin_trap();
+                // (the hand-over cannot deadlock -- every counter has one writer and row i waits only for rows before it -- so a long wait is a
+                // stall, not a bug: a debugger, a serialising profiler, a preempted queue.  Production waits it out; only option weighted.debug
+                // bit 3 (8) turns the wait's limit into a trap, for work on the protocol itself.  ADVICE r5)
+                if (polls > kSpinLimit && (debug & 8) != 0) __builtin_trap();
                 __builtin_amdgcn_s_sleep(2);
             }
         };
@@ -1857,57 +1860,80 @@ __host__ __device__ __forceinline__ bool csr_row_is_walked(int64_t nnz, int32_t 
     return 74 * (int64_t)chunks * nnz * nnz > (7000 + 3 * (int64_t)dim) * nnz + (1800 + 920 * (int64_t)chunks) * dim;
 }
 
-// every stored entry of a CSR row with numpy's argmin (first minimum in storage order; the first NaN wins); entries come
-// through the scalar path, four table entries (one 16-byte load per lane each) are in flight.  A row whose logs are all
-// sane -- no NaN, no finite value beyond 2^80 -- takes t without the division (evaluate_guarded: 16 VALU instructions per
-// element where the division costs 27), with the strict "smaller" of a NaN-free row; any other row the general rule.
+// every stored entry of a CSR row with numpy's argmin (first minimum in storage order; the first NaN wins).  A row whose logs are all
+// sane -- no NaN, no finite value beyond 2^80 -- takes t without the division (evaluate_guarded: 16 VALU instructions per element where
+// the division costs 27), with the strict "smaller" of a NaN-free row; any other row the general rule (csr_row_general).
+//
+// Round 6: the loop was a chain of dependent memory round trips -- per four elements one scalar load of (column, log), then the four
+// table loads that need its answer, then the wait for those: ~25 latencies in a row for a row of 41 entries, which at eight waves per
+// SIMD is what the kernel's 0.30 ms per 80 000 rows was made of (VALU busy 0.66 but 0.61 of the wave cycles waiting).  Now a wave
+// takes 64 entries of the row with ONE coalesced vector load (lane u holds entry u; the same load serves the sanity test), hands
+// them to the whole wave by v_readlane, and keeps eight table entries in flight.  Groups are filled up with the block's last entry
+// (evaluated again: the strict "<" ignores it).
+__device__ __forceinline__ void csr_row_general(const int32_t MHX_CONST_AS *indices, const float MHX_CONST_AS *logs, int64_t beg, int64_t end,
+                                                const float4 *__restrict__ aos, int32_t s_pad, int32_t my, int64_t &k_out, int64_t &t_out) {
+    Best best;
+    best.ln_a = 0.0f, best.t = 0.0f, best.k = -1;
+    for (int64_t j = beg; j < end; ++j) {
+        const int32_t c = indices[j];
+        consider(best, logs[j], entry_of(aos[(int64_t)c * s_pad + my]), c);
+    }
+    k_out = best.k, t_out = (int64_t)best.t;
+}
+
+template <int G>
+__device__ __forceinline__ void csr_group(int32_t c_v, float l_v, int u0, int last, const float4 *__restrict__ aos_my, int32_t s_pad,
+                                          float &best_a, float &best_t, int32_t &best_c) {
+    int32_t c[G];
+    float4 e[G];
+    float l[G], t[G], a[G];
+    bool open = false;
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+        const int at = u0 + u < last ? u0 + u : last;  // (uniform)
+        c[u] = __builtin_amdgcn_readlane(c_v, at);
+        l[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(l_v), at));
+        e[u] = aos_my[(int64_t)c[u] * s_pad];
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u) open |= evaluate_guarded<false>(l[u], e[u], t[u], a[u]);
+    if (__builtin_expect(__any(open), 0)) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) evaluate<false>(l[u], entry_of(e[u]), t[u], a[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < G; ++u)
+        if (a[u] < best_a) best_a = a[u], best_t = t[u], best_c = c[u];
+}
+
+// WIDE: eight table entries in flight (the entry-by-entry kernel: 70 VGPRs); the walk kernel, where this is the rare way out of a row,
+// keeps four (eight there cost it 87 VGPRs and three of its eight workgroups per CU: walked rows 0.14 -> 0.33 ms per 20 000)
+template <bool WIDE>
 __device__ __forceinline__ void csr_row_by_entry(const int32_t MHX_CONST_AS *indices, const float MHX_CONST_AS *logs,
-                                                 const float *__restrict__ logs_vec, int64_t beg, int64_t end,
+                                                 const int32_t *__restrict__ indices_vec, const float *__restrict__ logs_vec, int64_t beg, int64_t end,
                                                  const float4 *__restrict__ aos, int32_t s_pad, int32_t my, int64_t &k_out, int64_t &t_out) {
     const int lane = my & (kWave - 1);
-    bool sane = true;
-    for (int64_t j = beg + lane; j < end; j += kWave) {
-        const float m = fabsf(logs_vec[j]);
-        sane &= m <= 0x1p80f || m == __builtin_inff();
-    }
-    if (!__all(sane)) {
-        Best best;
-        best.ln_a = 0.0f, best.t = 0.0f, best.k = -1;
-        for (int64_t j = beg; j < end; ++j) {
-            const int32_t c = indices[j];
-            consider(best, logs[j], entry_of(aos[(int64_t)c * s_pad + my]), c);
+    const float4 *aos_my = aos + my;
+    float best_a = __builtin_inff(), best_t = 0.0f;
+    int32_t best_c = 0;
+    for (int64_t base = beg; base < end; base += kWave) {
+        const int cnt = (int)(end - base < kWave ? end - base : kWave);  // (uniform)
+        const int mine = lane < cnt ? lane : cnt - 1;
+        const int32_t c_v = indices_vec[base + mine];
+        const float l_v = logs_vec[base + mine];
+        const float m = fabsf(l_v);
+        if (!__all(m <= 0x1p80f || m == __builtin_inff())) {  // a NaN or a huge log somewhere in the row: all of it by the general rule
+            csr_row_general(indices, logs, beg, end, aos, s_pad, my, k_out, t_out);
+            return;
         }
-        k_out = best.k, t_out = (int64_t)best.t;
+        int u0 = 0;
+        if constexpr (WIDE)
+            for (; cnt - u0 > 4; u0 += 8) csr_group<8>(c_v, l_v, u0, cnt - 1, aos_my, s_pad, best_a, best_t, best_c);
+        for (; u0 < cnt; u0 += 4) csr_group<4>(c_v, l_v, u0, cnt - 1, aos_my, s_pad, best_a, best_t, best_c);
+    }
+    if (__builtin_expect(__any(!(best_a < __builtin_inff())), 0)) {  // nothing but +inf (stored zeros): numpy's argmin is the first entry, with its own t
+        csr_row_general(indices, logs, beg, end, aos, s_pad, my, k_out, t_out);
         return;
-    }
-    float best_a, best_t;
-    int32_t best_c = indices[beg];
-    evaluate<false>(logs[beg], entry_of(aos[(int64_t)best_c * s_pad + my]), best_t, best_a);
-    int64_t j = beg + 1;
-    for (; j + 4 <= end; j += 4) {
-        int32_t c[4];
-        float4 e[4];
-        float l[4], t[4], a[4];
-        bool open = false;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) c[u] = indices[j + u], l[u] = logs[j + u], e[u] = aos[(int64_t)c[u] * s_pad + my];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) open |= evaluate_guarded<false>(l[u], e[u], t[u], a[u]);
-        if (__builtin_expect(__any(open), 0)) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) evaluate<false>(l[u], entry_of(e[u]), t[u], a[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (a[u] < best_a) best_a = a[u], best_t = t[u], best_c = c[u];
-    }
-    for (; j < end; ++j) {
-        const int32_t c = indices[j];
-        const float l = logs[j];
-        const float4 e = aos[(int64_t)c * s_pad + my];
-        float t, a;
-        if (__builtin_expect(__any(evaluate_guarded<false>(l, e, t, a)), 0)) evaluate<false>(l, entry_of(e), t, a);
-        if (a < best_a) best_a = a, best_t = t, best_c = c;
     }
     k_out = best_c, t_out = (int64_t)best_t;
 }
@@ -1939,7 +1965,7 @@ __global__ __launch_bounds__(256) void weighted_csr_direct_kernel(const int64_t 
             continue;
         }
         int64_t k = 0, t = 0;
-        if (end > beg) csr_row_by_entry(indices, logs, logs_, beg, end, aos, s_pad, my, k, t);
+        if (end > beg) csr_row_by_entry<true>(indices, logs, indices_, logs_, beg, end, aos, s_pad, my, k, t);
         if (my < sample_size) {
             int64_t *o = out + (row * sample_size + my) * 2;
             o[0] = k;
@@ -1950,7 +1976,7 @@ __global__ __launch_bounds__(256) void weighted_csr_direct_kernel(const int64_t 
     if (n_walked && left && lane == 0) atomicAdd(n_walked, left);
 }
 
-__global__ __launch_bounds__(256) void weighted_walk_csr_kernel(const int64_t *__restrict__ indptr_, const int32_t *__restrict__ indices_,
+__global__ __launch_bounds__(256, 8) void weighted_walk_csr_kernel(const int64_t *__restrict__ indptr_, const int32_t *__restrict__ indices_,
                                                                 const float *__restrict__ logs_, int64_t n_rows, int32_t dim,
                                                                 int32_t direct_permille, const WalkPlan *__restrict__ plan,
                                                                 const float4 *__restrict__ walk_a, const uint32_t *__restrict__ walk_c,
@@ -2007,14 +2033,18 @@ __global__ __launch_bounds__(256) void weighted_walk_csr_kernel(const int64_t *_
             const int32_t my = ch * kWave + lane;
             int64_t k_out = 0, t_out = 0;
             if (by_entry) {
-                csr_row_by_entry((const int32_t MHX_CONST_AS *)indices_, (const float MHX_CONST_AS *)logs_, logs_, beg, end, aos, s_pad, my, k_out, t_out);
+                csr_row_by_entry<false>((const int32_t MHX_CONST_AS *)indices_, (const float MHX_CONST_AS *)logs_, indices_, logs_, beg, end, aos, s_pad, my, k_out, t_out);
             } else {
                 const Held held = walk_row(row, list, n_out, false, dim, ch, my, sample_size, walk_a, walk_c, aos, s_pad,
                                            ch < n_cc ? s_cache_a + ch * kWalkCached * kWave : nullptr,
                                            ch < n_cc ? s_cache_c + ch * kWalkCached * kWave : nullptr, 0, 1);
                 k_out = held.c, t_out = (int64_t)held.t;
-                if (my < sample_size && k_out == 0xFFFFFFFFll)  // the walk met nothing (stored zeros only)
-                    csr_row_by_entry((const int32_t MHX_CONST_AS *)indices_, (const float MHX_CONST_AS *)logs_, logs_, beg, end, aos, s_pad, my, k_out, t_out);
+                const bool nothing = my < sample_size && k_out == 0xFFFFFFFFll;  // the walk met nothing (stored zeros only)
+                if (__any(nothing)) {  // (the whole wave goes: csr_row_by_entry hands entries around with v_readlane)
+                    int64_t k2 = 0, t2 = 0;
+                    csr_row_by_entry<false>((const int32_t MHX_CONST_AS *)indices_, (const float MHX_CONST_AS *)logs_, indices_, logs_, beg, end, aos, s_pad, my, k2, t2);
+                    if (nothing) k_out = k2, t_out = t2;
+                }
             }
             if (my < sample_size) {
                 int64_t *o = out + (d * sample_size + my) * 2;

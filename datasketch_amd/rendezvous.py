@@ -108,6 +108,16 @@ def _publish_dir() -> str:
     return path
 
 
+def _socket_is_dead(sock) -> bool:
+    """True when the peer has closed this connection (EOF or an error on a non-blocking peek); pending data or silence = alive."""
+    try:
+        return sock.recv(1, socket.MSG_PEEK | socket.MSG_DONTWAIT) == b""
+    except (BlockingIOError, InterruptedError):
+        return False
+    except OSError:
+        return True
+
+
 class Group:
     """``world`` processes, this one being ``rank``.  Collectives: :meth:`allgather`,
     :meth:`broadcast`, :meth:`barrier`, :meth:`allreduce_max`.
@@ -177,14 +187,18 @@ class Group:
                 peer, hello = _recv_frame(conn, _HELLO_MAX)
                 if not (0 < peer < self.world) or not hmac.compare_digest(hello, want):
                     raise ConnectionError("unexpected rendezvous peer")
+                old = self._peers[peer]
+                if old is not None and not (want and _socket_is_dead(old)):
+                    # a hello for a rank that is registered already.  Its first ACK may have reached it too late (it waits
+                    # min(timeout, 10 s) while rank 0 reads silent connections at 1 s each): it closed that socket and came
+                    # again, and the new connection replaces the dead one -- but ONLY when this group has a nonce (so that the
+                    # hello proves membership; without one any local process could evict a live peer by claiming its rank) and
+                    # the registered socket really is dead (the peer closed it: EOF or an error on a peek).  ADVICE r5.
+                    raise ConnectionError("rank already registered")
                 conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
                 conn.settimeout(timeout)
                 _send_frame(conn, 0, _ACK)  # the joiner waits for this: a rank that was dropped must not believe it has joined
-                old = self._peers[peer]
                 if old is not None:
-                    # a valid hello from a rank that is registered already: its first ACK reached it too late (it waits
-                    # min(timeout, 10 s) while rank 0 reads silent connections at 1 s each), so it closed that socket and
-                    # came again -- the new connection replaces the dead one instead of being turned away for good
                     try:
                         old.close()
                     except OSError:
@@ -195,7 +209,7 @@ class Group:
             except (OSError, struct.error):
                 conn.close()
 
-    def _join(self, host, port, timeout, publish, nonce):
+    def _join(self, host, port, timeout, publish, nonce):  # noqa: C901
         deadline = time.time() + timeout
         last: Optional[Exception] = None
         while True:

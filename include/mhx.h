@@ -92,7 +92,8 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * instead of walked, default 100), ("weighted.split", 0 auto: the waves of a workgroup that share 64 samples split the list of a
  * dense row that is evaluated entry by entry, 1 = one wave per 64 samples), ("weighted.tail", profiling: 1 .. 5 force the share of a call's logs that
  * counts as "above the cut" to 0.5, 1, 2, 4, 8 %; 0 = the cheapest by the plan's estimate), ("weighted.debug", profiling only: 1 = stage and scan the rows without walking them,
- * 2 = skip the scan, 4 = (fetcher / walker kernel) every stripe keeps its first row: the walkers alone; results are meaningless),
+ * 2 = skip the scan, 4 = (fetcher / walker kernel) every stripe keeps its first row: the walkers alone; results are meaningless;
+ * 8 = (fetcher / walker kernel, results unaffected) a hand-over wait that outlasts 2^24 polls traps instead of waiting on),
  * ("host.chunk_bytes", see
  * mhx_minhash_bulk), ("lsh.sort_bits", bits of (band, digest) mhx_lsh_sort_bands hands to the radix sort,
  * 0 = chosen from n; the order is exact for any value, fewer bits leave more to the clean-up pass),

@@ -49,7 +49,7 @@ def main():
         idx = dist.lsh_index_sharded(ctx, d_sig.ptr, _native.MHX_U32, n_local, k, bands, r, counts, group, b=1, transport=transport)
         ctx.synchronize()
         shard = idx.digests
-        arrays = {"blocks": idx.blocks.download((n_local, k // 64), np.uint64), "digests": shard.to_host()}
+        arrays = {"blocks": idx.blocks.download((n_local, -(-k // 64)), np.uint64), "digests": shard.to_host()}
         if idx.sorted_digests is not None:
             arrays["sorted_digests"], arrays["sorted_rows"] = idx.to_host()
         rec = {"rank": group.rank, "world": group.world, "counts": counts, "transport": shard.transport, "fused": bool(idx.fused),

@@ -152,7 +152,8 @@ def test_cpu_baseline_times_the_real_reference_when_it_is_named(monkeypatch):
     a, b = O.np_init_permutations(16, 1)
     monkeypatch.delenv("DATASKETCH_REFERENCE", raising=False)
     port = bench.cpu_baseline(tokens, a, b, 2000, 16, 64, None, seed=1)
-    assert port["kind"] == "port" and port["reference_over_port_time"] == 1.21 and "2026-09-22" in port["reference_over_port_measured"]
+    assert port["kind"] == "port" and "reference_over_port_time" not in port  # no scaled claim without the reference
+    assert os.path.exists(os.path.join(root, port["reference_over_port_file"]))
     if not os.path.isdir("/root/reference/datasketch"):
         pytest.skip("the reference is not on this box")
     monkeypatch.setenv("DATASKETCH_REFERENCE", "/root/reference")

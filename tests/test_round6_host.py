@@ -313,3 +313,41 @@ def test_bulk_signatures_from_packed_byte_tokens_equals_the_per_object_corpus():
         MinHash.bulk_signatures(packed=(buf, byte_offsets, set_offsets + 1), num_perm=16, gpu_mode="disable")
     with pytest.raises(ValueError):
         MinHash.bulk_signatures(packed=(buf[:-1], byte_offsets, set_offsets), num_perm=16, gpu_mode="disable")
+
+
+def test_a_second_hello_cannot_evict_a_live_rank_and_needs_a_nonce_to_replace_a_dead_one():
+    """rank 0 replaces a registered rank's socket only when the hello carried the group's nonce AND the registered
+    socket is dead.  An impostor claiming rank 1 while the real rank 1 is connected is turned away (nonce or not), and the group works."""
+    import struct
+    import time
+
+    for nonce in ("n6", None):
+        port = _free_port()
+        res = {}
+
+        def run(rank, delay=0.0):
+            time.sleep(delay)
+            try:
+                with rendezvous.Group(rank, 3, "127.0.0.1", port, timeout=30, nonce=nonce) as g:
+                    res[rank] = g.allgather(bytes([rank]))
+            except Exception as e:  # noqa: BLE001
+                res[rank] = e
+
+        threads = [threading.Thread(target=run, args=(0,)), threading.Thread(target=run, args=(1, 0.1))]
+        for t in threads:
+            t.start()
+        time.sleep(0.6)  # rank 1 is registered and alive, rank 2 still missing
+        c = socket.create_connection(("127.0.0.1", port), timeout=2.0)
+        c.sendall(struct.pack("<4sIQ", b"MHXR", 1, len(nonce or "")) + (nonce or "").encode())
+        c.settimeout(3.0)
+        try:
+            got = c.recv(64)
+        except OSError:
+            got = b""
+        assert got == b"", "the impostor was acknowledged"  # dropped: EOF, no ACK
+        c.close()
+        t2 = threading.Thread(target=run, args=(2,))
+        t2.start()
+        for t in threads + [t2]:
+            t.join(40)
+        assert all(res.get(r) == [b"\x00", b"\x01", b"\x02"] for r in range(3)), (nonce, res)

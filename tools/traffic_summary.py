@@ -65,7 +65,13 @@ def main():
                  "valu_issue_frac": 4 * c["SQ_INSTS_VALU"] / (1024 * cycles),
                  "valu_issue_frac_formula": "4 cycles x SQ_INSTS_VALU / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCD instances): the share of "
                                             "SIMD issue cycles the launch's VALU instructions need at their minimum of 4 cycles each"}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from benchmarks.common import kernel_stamp
+
     print(json.dumps({
+        "stamp": dict(kernel_stamp(), git_commit=os.environ.get("MHX_GIT_COMMIT"),
+                      note="the tree the counters were taken on (the GPU box has no .git: MHX_GIT_COMMIT is passed in by tools/round6_refresh.sh); "
+                           "bench.py replays these figures only for a tree with the same kernel_source_sha256"),
         "kernel": "minhash_bulk_kernel<2, uint64, uint64, MODE_SIEVE, SHAPE_PLAIN_FIXED_ROWS> (1M sets x 256 tokens, K=128)",
         "source": "rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum / TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum, own passes (tools/traffic.sh), mean of 4 dispatches",
         "byte_formula": "reads 32*RDREQ_32B + 64*RDREQ_64B + 128*(RDREQ - RDREQ_32B - RDREQ_64B); writes 64*WRREQ_64B + 32*(WRREQ - WRREQ_64B)",
