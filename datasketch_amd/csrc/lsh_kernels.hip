@@ -146,6 +146,10 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
         __syncthreads();
         // the element's bin inside the band (top hi + lo digest bits) and inside this source unit (the low lo bits of that)
         const auto gbin_of = [&](uint64_t d) { return tot_bits ? (uint32_t)(d >> (64 - tot_bits)) : 0u; };
+        // (Round 6, measured and dropped: the counting atomic returning the element's rank, so that the staging loop needs no second atomic and
+        // the output loop one table word instead of two -- seven LDS operations per element instead of nine, five at random addresses instead
+        // of seven.  Same box, interleaved: 0.495 / 0.498 ms against 0.491 / 0.451 for 40M keys.  The LDS bank conflicts the counters show
+        // (0.555 of the LDS cycles) are not what the pass waits for.)
         // All of the thread's loads go out before any of them is waited for: a thread behind the unit's end reads the unit's last
         // element again (nothing is predicated), and the histogram's LDS atomics come in a loop of their own.  (Until round 5 the
         // atomic sat next to its load inside `if (row < count)`: the compiler put an s_waitcnt vmcnt(0) between every load and its
@@ -163,14 +167,9 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
                 dg[j] = band_digest_of<SigT>(sig, at, band, k, r, n);
             }
         }
-        // (round 6) the counting atomic RETURNS the element's rank inside its (team, bin) piece: the staging loop below no longer
-        // runs a second atomic per element, and the output loop reads one table word per element (base - lstart) instead of two --
-        // seven LDS operations per element where there were nine, five of them at random addresses instead of seven
-        // (profiles/r05_traffic_lsh_sort.json: 0.555 of this kernel's LDS cycles were bank conflicts of exactly those)
-        uint16_t rank[kScatterRows];
 #pragma unroll
         for (int j = 0; j < kScatterRows; ++j)
-            rank[j] = row0 + j * 256 + tid < count ? (uint16_t)atomicAdd(&hist[gbin_of(dg[j]) & (nb - 1)], 1u) : (uint16_t)0;
+            if (row0 + j * 256 + tid < count) atomicAdd(&hist[gbin_of(dg[j]) & (nb - 1)], 1u);
         __syncthreads();
         // per bin: a range of its slab (one global atomic) and the start of its elements in the team's staging area
         // (exclusive scan of the counts: thread t owns bins [t * per, t * per + per))
@@ -192,8 +191,9 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
                 const int t = tid * per + j;
                 if (j < per && t < nb) {
                     if (bases[j] + cnts[j] > cap) *overflow = 1u;
-                    base[t] = bases[j] - at;  // slab position of staged element i of this bin = base[bin] + i (mod 2^32)
+                    base[t] = bases[j];
                     lstart[t] = at;
+                    hist[t] = 0;
                     at += cnts[j];
                 }
             }
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
             const int64_t row = row0 + j * 256 + tid;
             if (row < count) {
                 const uint32_t bin = gbin_of(dg[j]) & (nb - 1);
-                const uint32_t lp = lstart[bin] + rank[j];
+                const uint32_t lp = lstart[bin] + atomicAdd(&hist[bin], 1u);
                 st_dig[lp] = dg[j];
                 if constexpr (kPairs) st_row[lp] = rw[j];
                 else st_row[lp] = (uint16_t)(j * 256 + tid);
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
         for (uint32_t i = tid; i < total; i += 256) {
             const uint64_t d = st_dig[i];
             const uint32_t bin = gbin_of(d) & (nb - 1);
-            const uint32_t pos = base[bin] + i;
+            const uint32_t pos = base[bin] + (i - lstart[bin]);
             if (pos < cap) {
                 const int64_t at = (out0 + bin) * cap + pos;
                 slab_dig[at] = d;

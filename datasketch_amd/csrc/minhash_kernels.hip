@@ -1334,8 +1334,7 @@ __global__ __launch_bounds__(256) void minhash_packed_kernel(const BulkArgs args
             int max_rows = 0;
 #pragma unroll
             for (int j = 0; j < G; ++j) max_rows = max(max_rows, __builtin_amdgcn_readlane(nrows, j * KP));
-#pragma unroll 2
-            for (int r = 0; r < max_rows; ++r) {
+            for (int r = 0; r < max_rows; ++r) {  // (a "#pragma unroll 2" stood here until round 6: the optimizer never applied it -- 28 warnings per build, the same code)
                 const uint32_t *rowp = my_tile + r * STRIDE;
                 uint32_t row[P];
 #pragma unroll

@@ -1849,15 +1849,15 @@ __global__ __launch_bounds__(SPLIT != 0 ? 1024 : 512) void weighted_walk_wave_ke
 // 64 samples, four table entries in flight); a row that stores many is spread out in LDS (-inf where nothing is stored)
 // and walked like a dense row (weighted_walk_csr_kernel: one workgroup per row).  The two kernels share the rows out by
 // the same test on the row's length.
-// `mode` > 0: option weighted.direct, a fixed share of the columns in per mille (A/B runs); 0: by cost.  Measured on an MI355X over
-// densities 0.02 .. 0.5 of (1024 columns, 64 samples), (4096, 128), (1024, 256) -- profiles/r06_sweep_weighted_csr.txt --, per
-// 20 000 rows: entry by entry 0.74 us x stored entries x chunks of 64 samples; walked (0.07 + 3e-5 dim) ms for clearing and
-// spreading the row + (0.018 + 0.0092 chunks) ms / density for the positions a walk passes before it meets stored columns.  The
-// fixed 10 % of rounds 3-5 sat on the crossover of (4096, 128) only: 1024 columns x 64 samples at 10 % ran 0.30 ms where entry by
-// entry takes 0.115.  Only speed depends on the choice: both kernels produce the reference's (k, t) for any row.
+// `mode` > 0: option weighted.direct, a fixed share of the columns in per mille (A/B runs); 0: by cost.  Measured on an MI355X with this
+// round's kernels over densities 0.02 .. 0.5 of (1024 columns, 64 samples), (4096, 128), (1024, 256) -- profiles/r06_sweep_weighted_csr.txt --,
+// in microseconds per 20 000 rows: entry by entry 0.70 x stored entries x chunks of 64 samples; walked (39 + 0.011 dim + 20 chunks) for
+// clearing and spreading the row + (3 + 13.7 chunks + 0.003 dim) x dim / stored for the positions a walk passes before it meets stored
+// columns + 0.017 chunks x stored.  The fixed 10 % of rounds 3-5 sat on the crossover of (4096, 128) only: 1024 columns x 64 samples at
+// 10 % ran 0.30 ms where entry by entry now takes 0.08.  Only speed depends on the choice: both kernels produce the reference's (k, t).
 __host__ __device__ __forceinline__ bool csr_row_is_walked(int64_t nnz, int32_t dim, int32_t chunks, int32_t mode) {
     if (mode > 0) return nnz * 1000 > (int64_t)mode * dim;
-    return 74 * (int64_t)chunks * nnz * nnz > (7000 + 3 * (int64_t)dim) * nnz + (1800 + 920 * (int64_t)chunks) * dim;
+    return 683 * (int64_t)chunks * nnz * nnz > (39000 + 11 * (int64_t)dim + 20000 * (int64_t)chunks) * nnz + (3000 + 13700 * (int64_t)chunks + 3 * (int64_t)dim) * dim;
 }
 
 // every stored entry of a CSR row with numpy's argmin (first minimum in storage order; the first NaN wins).  A row whose logs are all
@@ -1945,7 +1945,7 @@ __global__ __launch_bounds__(256) void weighted_csr_direct_kernel(const int64_t 
                                                                   const float *__restrict__ logs_, int64_t n_rows, int32_t dim,
                                                                   int32_t direct_permille, const float4 *__restrict__ aos,
                                                                   int32_t sample_size, int32_t s_pad, int64_t *__restrict__ out,
-                                                                  uint8_t *__restrict__ nonempty, unsigned int *__restrict__ n_walked) {
+                                                                  uint8_t *__restrict__ nonempty) {
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int waves_per_block = blockDim.x >> 6;
@@ -1955,15 +1955,11 @@ __global__ __launch_bounds__(256) void weighted_csr_direct_kernel(const int64_t 
     const int64_t MHX_CONST_AS *indptr = (const int64_t MHX_CONST_AS *)indptr_;
     const int32_t MHX_CONST_AS *indices = (const int32_t MHX_CONST_AS *)indices_;
     const float MHX_CONST_AS *logs = (const float MHX_CONST_AS *)logs_;
-    unsigned int left = 0;  // rows this wave leaves to the walk kernel (counted once per row: by chunk 0)
     for (int64_t row = (int64_t)(blockIdx.x / chunks) * waves_per_block + wave; row < n_rows;
          row += (int64_t)(gridDim.x / chunks) * waves_per_block) {
         const int64_t beg = indptr[row], end = indptr[row + 1];
         if (ch == 0 && lane == 0) nonempty[row] = end > beg ? 1 : 0;
-        if (direct_permille >= 0 && csr_row_is_walked(end - beg, dim, (int32_t)chunks, direct_permille)) {  // the walk kernel's row
-            left += ch == 0 ? 1u : 0u;
-            continue;
-        }
+        if (direct_permille >= 0 && csr_row_is_walked(end - beg, dim, (int32_t)chunks, direct_permille)) continue;  // the walk kernel's row
         int64_t k = 0, t = 0;
         if (end > beg) csr_row_by_entry<true>(indices, logs, indices_, logs_, beg, end, aos, s_pad, my, k, t);
         if (my < sample_size) {
@@ -1972,8 +1968,19 @@ __global__ __launch_bounds__(256) void weighted_csr_direct_kernel(const int64_t 
             o[1] = t;
         }
     }
-    // the plan and walk launches behind this one do nothing at all when no row is theirs (a corpus of short rows: 15 % of the call)
-    if (n_walked && left && lane == 0) atomicAdd(n_walked, left);
+}
+
+// Is any row of the call long enough to be walked?  *gate = 1 if so (the caller zeroes it).  The plan and walk launches read the word
+// and return at once when it is 0: on a corpus of short rows they were 15 % of the call.  A pass of its own over the row pointers
+// (8 bytes per row, a few microseconds) with one store per workgroup that found one: letting the entry-by-entry kernel's 16 384 waves
+// report what they skipped -- an atomic each, or even a plain store each, on one word -- serialised in the memory system for 0.19 ms
+// and more (profiles/r06_ab_weighted_csr.txt).
+__global__ __launch_bounds__(256) void csr_any_walked_kernel(const int64_t *__restrict__ indptr, int64_t n_rows, int32_t dim, int32_t chunks,
+                                                             int32_t mode, unsigned int *__restrict__ gate) {
+    bool any = false;
+    for (int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; row < n_rows; row += (int64_t)gridDim.x * blockDim.x)
+        any |= csr_row_is_walked(indptr[row + 1] - indptr[row], dim, chunks, mode);
+    if (__syncthreads_or(any) && threadIdx.x == 0) *gate = 1u;
 }
 
 __global__ __launch_bounds__(256, 8) void weighted_walk_csr_kernel(const int64_t *__restrict__ indptr_, const int32_t *__restrict__ indices_,
@@ -2294,19 +2301,22 @@ static int launch_weighted_csr_walk(mhx_wgen *gen, const int64_t *d_indptr, cons
     float4 *walk_a = reinterpret_cast<float4 *>(gen->d_walk_a);
     const int64_t chunks = gen->s_pad / kWave;
     const bool any_walk = csr_row_is_walked(std::min<int64_t>(nnz, dim), dim, (int32_t)chunks, direct_mode);  // the longest row there can be
-    // The entry-by-entry launch goes first and counts the rows it leaves to the walk (d_work word 12); the plan and walk launches
-    // read the count and return at once when it is 0.  The two-launch plan (dim > 8192) has no gate: it always runs.
+    // A short pass over the row pointers says whether any row is walked at all (d_work word 12); the plan and walk launches read the
+    // word and return at once when it is 0.  The two-launch plan (dim > 8192) has no gate: it always runs.
     unsigned int *d_gate = nullptr;
     if (any_walk) {
         if (int rc = ctx->ensure_work()) return rc;
         d_gate = ctx->d_work + 12;
         MHX_HIP_CHECK(hipMemsetAsync(d_gate, 0, sizeof(unsigned int), ctx->stream));
+        hipLaunchKernelGGL(csr_any_walked_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((n_rows + 1023) / 1024, 256))), dim3(256), 0, ctx->stream,
+                           d_indptr, n_rows, dim, (int32_t)chunks, direct_mode, d_gate);
+        MHX_HIP_CHECK(hipGetLastError());
     }
     const int64_t want = (n_rows + 3) / 4;
     const int64_t groups = std::max<int64_t>(1, std::min<int64_t>(want, (int64_t)ctx->num_cus * (ctx->opt_blocks_per_cu > 0 ? ctx->opt_blocks_per_cu : 16) / chunks));
     hipLaunchKernelGGL(weighted_csr_direct_kernel, dim3((unsigned)(groups * chunks)), dim3(256), 0,
                        ctx->stream, d_indptr, d_indices, d_logs, n_rows, dim, any_walk ? direct_mode : -1,
-                       reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, d_out, d_nonempty, d_gate);
+                       reinterpret_cast<const float4 *>(gen->d_aos), gen->sample_size, gen->s_pad, d_out, d_nonempty);
     MHX_HIP_CHECK(hipGetLastError());
     if (any_walk) {
         const int32_t seg = (int32_t)std::min<int64_t>(nnz, 1024);

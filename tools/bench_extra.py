@@ -199,6 +199,33 @@ def sha1(ctx):
         print(json.dumps({"name": f"bulk_signatures on byte tokens, default hashfunc, gpu_mode={mode}", "sets": len(sets),
                           "tokens_per_set": 100, "seconds": round(dt, 3), "sets_per_s": len(sets) / dt,
                           "checksum": int(sig.sum() % (1 << 61))}), flush=True)
+    # the same corpus already packed (what a tokenizer writing into one buffer hands over): MinHash.bulk_signatures(packed=...), round 6
+    flat = [t for s_ in sets for t in s_]
+    pbuf = np.frombuffer(b"".join(flat), dtype=np.uint8)
+    pboff = np.concatenate([[0], np.cumsum([len(t) for t in flat])]).astype(np.int64)
+    psoff = np.arange(len(sets) + 1, dtype=np.int64) * 100
+    want = sig
+    for rep in range(2):
+        t0 = time.perf_counter()
+        sig = MinHash.bulk_signatures(packed=(pbuf, pboff, psoff), num_perm=128, seed=1, gpu_mode="always")
+        dt = time.perf_counter() - t0
+    assert np.array_equal(sig, want)
+    print(json.dumps({"name": "bulk_signatures(packed=...) on the same byte tokens, gpu_mode=always (second call)", "sets": len(sets), "tokens_per_set": 100,
+                      "seconds": round(dt, 4), "sets_per_s": len(sets) / dt, "tokens_per_s": len(flat) / dt}), flush=True)
+    # a corpus large enough for the link to matter: 1M sets x 100 tokens of 3..12 bytes, packed
+    n_sets, per = 1_000_000, 100
+    lens = rng.randint(3, 13, size=n_sets * per).astype(np.int64)
+    boff = np.zeros(n_sets * per + 1, dtype=np.int64)
+    np.cumsum(lens, out=boff[1:])
+    big = rng.randint(0, 256, int(boff[-1]), dtype=np.uint8)
+    soff = np.arange(n_sets + 1, dtype=np.int64) * per
+    for rep in range(2):
+        t0 = time.perf_counter()
+        sig = MinHash.bulk_signatures(packed=(big, boff, soff), num_perm=128, seed=1, gpu_mode="always", out_dtype=np.uint32)
+        dt = time.perf_counter() - t0
+    print(json.dumps({"name": "bulk_signatures(packed=...) 1M sets x 100 byte tokens (3..12 bytes), uint32 out, host numpy in -> host numpy out (second call)",
+                      "sets": n_sets, "seconds": round(dt, 3), "sets_per_s": n_sets / dt, "tokens_per_s": n_sets * per / dt,
+                      "bytes_over_pcie": int(big.size + boff.nbytes + soff.nbytes + sig.nbytes)}), flush=True)
 
 
 def reference_gpu_benchmark(ctx):
