@@ -109,12 +109,8 @@ __device__ __forceinline__ uint32_t bin_of(uint64_t digest, int bin_bits) { retu
 // the band is the top hi + lo digest bits, of which the low lo bits index the team's histogram.
 struct SlabPairs {};  // source of level 1: src_dig / src_row slabs of src_cap elements per unit, src_cursor[unit] of them filled
 
-// sources read with unit stride: a workgroup is one team (nothing to share between bands) and its items are software-pipelined
-template <typename SigT>
-constexpr bool kUnitStrideSource = std::is_same<SigT, SlabPairs>::value || std::is_same<SigT, Digest64BM>::value;
-
 template <typename SigT, int kScatterRows>
-__global__ __launch_bounds__(kUnitStrideSource<SigT> ? 256 : 1024) void lsh_bin_scatter_kernel(const SigT *__restrict__ sig, int32_t k, int32_t r, int64_t n, int32_t units,
+__global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__restrict__ sig, int32_t k, int32_t r, int64_t n, int32_t units,
                                                                int hi_bits, int lo_bits, int band_share, uint32_t cap,
                                                                uint32_t *__restrict__ cursor, uint64_t *__restrict__ slab_dig,
                                                                uint32_t *__restrict__ slab_row, uint32_t *__restrict__ overflow,
@@ -139,48 +135,13 @@ __global__ __launch_bounds__(kUnitStrideSource<SigT> ? 256 : 1024) void lsh_bin_
     // band groups that share 128-byte input lines of a ROW-major digest matrix to one XCD -- reads 1.30 GB -> 0.32 GB, but 16
     // bands' slabs per XCD no longer merge: writes 0.62 -> 1.02 GB in 32-byte requests, 447 -> 493 us,
     // profiles/r05_pmc_scatter_work_orders.txt.  The band-major input (Digest64BM) keeps both properties.)
-    // Round 6: a workgroup's items are software-pipelined where the source is read with unit stride (band-major digests, the big bins of
-    // level 0): the NEXT item's elements are requested while this one's are counted, grouped and written, so that of an item's three round
-    // trips to memory (its loads, the cursor atomics, the drain of its stores) the first is off the critical path.  At three one-team
-    // workgroups per CU (LDS) nothing else hides it.
-    constexpr bool kAhead = kUnitStrideSource<SigT>;
-    const auto item_unit = [&](int64_t item) { return (int)(item % groups) * band_share + team; };
-    const auto item_count = [&](int unit) { return kPairs ? (int64_t)min(src_cursor[unit], src_cap) : n; };
-    uint64_t dg[kScatterRows];
-    uint32_t rw[kPairs ? kScatterRows : 1];
-    // a thread behind the unit's end reads the unit's last element again (nothing is predicated)
-    const auto fetch = [&](int64_t item, uint64_t (&d)[kScatterRows], uint32_t (&w)[kPairs ? kScatterRows : 1]) {
-        const int unit = item_unit(item);
-        const int64_t count = item_count(unit), row0 = item / groups * kChunk;
-        if (kPairs && row0 >= count) return;
-        const int64_t src0 = kPairs ? (int64_t)unit * src_cap : 0;
-#pragma unroll
-        for (int j = 0; j < kScatterRows; ++j) {
-            const int64_t row = row0 + j * 256 + tid;
-            const int64_t at = row < count ? row : count - 1;  // (count > 0 here)
-            if constexpr (kPairs) {
-                d[j] = src_dig[src0 + at];
-                w[j] = src_row[src0 + at];
-            } else {
-                d[j] = band_digest_of<SigT>(sig, at, unit, k, r, n);
-            }
-        }
-    };
-    if (kAhead && (int64_t)blockIdx.x < chunks * groups) fetch(blockIdx.x, dg, rw);
     for (int64_t item = blockIdx.x; item < chunks * groups; item += gridDim.x) {
-        const int unit = item_unit(item);
+        const int unit = (int)(item % groups) * band_share + team;
         const int64_t row0 = item / groups * kChunk;
-        const int64_t count = item_count(unit);
-        const bool empty = kPairs && row0 >= count;  // (band_share is 1 for pair sources: workgroup-uniform)
+        const int64_t count = kPairs ? (int64_t)min(src_cursor[unit], src_cap) : n;
+        if (kPairs && row0 >= count) continue;  // (band_share is 1 for pair sources: workgroup-uniform)
         const int band = kPairs ? unit >> hi_bits : unit;
-        if (!kAhead) fetch(item, dg, rw);
-        uint64_t dg_next[kAhead ? kScatterRows : 1];
-        uint32_t rw_next[kPairs ? kScatterRows : 1];
-        const bool more = kAhead && item + gridDim.x < chunks * groups;
-        if (empty) {
-            if (more) fetch(item + gridDim.x, dg, rw);
-            continue;
-        }
+        const int64_t src0 = kPairs ? (int64_t)unit * src_cap : 0;
         for (int t = tid; t < nb; t += 256) hist[t] = 0;
         __syncthreads();
         // the element's bin inside the band (top hi + lo digest bits) and inside this source unit (the low lo bits of that)
@@ -193,6 +154,19 @@ __global__ __launch_bounds__(kUnitStrideSource<SigT> ? 256 : 1024) void lsh_bin_
         // element again (nothing is predicated), and the histogram's LDS atomics come in a loop of their own.  (Until round 5 the
         // atomic sat next to its load inside `if (row < count)`: the compiler put an s_waitcnt vmcnt(0) between every load and its
         // atomic -- sixteen memory latencies in a row per chunk, which is what the pass's 24 us per chunk were made of.)
+        uint64_t dg[kScatterRows];
+        uint32_t rw[kPairs ? kScatterRows : 1];
+#pragma unroll
+        for (int j = 0; j < kScatterRows; ++j) {
+            const int64_t row = row0 + j * 256 + tid;
+            const int64_t at = row < count ? row : count - 1;  // (count > 0 here)
+            if constexpr (kPairs) {
+                dg[j] = src_dig[src0 + at];
+                rw[j] = src_row[src0 + at];
+            } else {
+                dg[j] = band_digest_of<SigT>(sig, at, band, k, r, n);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < kScatterRows; ++j)
             if (row0 + j * 256 + tid < count) atomicAdd(&hist[gbin_of(dg[j]) & (nb - 1)], 1u);
@@ -209,9 +183,6 @@ __global__ __launch_bounds__(kUnitStrideSource<SigT> ? 256 : 1024) void lsh_bin_
                 cnts[j] = j < per && t < nb ? hist[t] : 0u;
                 bases[j] = cnts[j] ? atomicAdd(&cursor[out0 + t], cnts[j]) : 0u;
                 sum += cnts[j];
-            }
-            if constexpr (kAhead) {  // behind the cursor atomics: their answers are not held up by these loads
-                if (more) fetch(item + gridDim.x, dg_next, rw_next);
             }
             const uint32_t incl = block_inclusive_scan(sum, scan_tmp, tid);
             uint32_t at = incl - sum;
@@ -250,15 +221,6 @@ __global__ __launch_bounds__(kUnitStrideSource<SigT> ? 256 : 1024) void lsh_bin_
                 const int64_t at = (out0 + bin) * cap + pos;
                 slab_dig[at] = d;
                 slab_row[at] = kPairs ? (uint32_t)st_row[i] : (uint32_t)(row0 + st_row[i]);
-            }
-        }
-        if constexpr (kAhead) {
-            if (more) {
-#pragma unroll
-                for (int j = 0; j < kScatterRows; ++j) {
-                    dg[j] = dg_next[j];
-                    if constexpr (kPairs) rw[j] = rw_next[j];
-                }
             }
         }
         __syncthreads();
