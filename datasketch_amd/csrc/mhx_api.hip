@@ -378,6 +378,7 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "weighted.kernel")) ctx->opt_weighted_kernel = value;
     else if (!strcmp(key, "weighted.plan")) ctx->opt_weighted_plan = value;
     else if (!strcmp(key, "weighted.rescue")) ctx->opt_weighted_rescue = value;
+    else if (!strcmp(key, "weighted.min_dim")) ctx->opt_weighted_min_dim = value;
     else if (!strcmp(key, "host.chunk_bytes")) ctx->opt_host_chunk_bytes = value;
     else if (!strcmp(key, "lsh.sort_bits")) ctx->opt_lsh_sort_bits = value;
     else if (!strcmp(key, "lsh.gather")) ctx->opt_lsh_gather = value;

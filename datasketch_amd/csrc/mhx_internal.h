@@ -79,6 +79,7 @@ struct mhx_ctx {
     int64_t opt_minhash_prefetch = 1; // warm L2 with the next set's tokens (vector load per set): 1 auto (CSR, or fixed length < 256), 0 never, 2 always
     int64_t opt_minhash_alias = -1; // profiling only: >= 0 makes set i read the tokens of set (i & mask)
     int64_t opt_weighted_path = 0;  // 0 auto (dense rows: bound-ordered walk; CSR: reciprocal-multiply quotient + row blocks), 1 IEEE division for every element, 2 every element evaluated (dense rows compacted to CSR: the round-2 path)
+    int64_t opt_weighted_min_dim = 0; // dense walk: rows of at least this many columns (a multiple of 4, <= 4096) go to the wave / fetcher-walker kernels; 0 auto
     int64_t opt_weighted_rescue = 0; // dense walk, one wave per row: a walk's last lanes get the whole wave each (walk_rescue) when at most this many are left; 0 auto (8), < 0 never
     int64_t opt_weighted_plan = 0;   // walk plan + tables: 0 = one launch (every workgroup plans, then sorts its sample's list if need be), 1 = round 3's two launches
     int64_t opt_weighted_kernel = 0; // dense walk: 0 auto (one wave per row where the shape allows, two chunks of samples walked as one stream), 1 = one workgroup per row always, 2 = one wave per row, chunk after chunk

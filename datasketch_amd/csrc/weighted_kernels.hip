@@ -2148,7 +2148,8 @@ static int launch_weighted_dense_walk(mhx_wgen *gen, const float *d_x, int value
         const size_t stripe_bytes = (sizeof(float) * (size_t)((dim + 3) & ~3) + sizeof(uint16_t) * (size_t)((list_cap_w + 7) & ~7) + 15) & ~(size_t)15;
         const int64_t fit = ((int64_t)ctx->lds_per_block - (int64_t)cache_bytes - 64) / (int64_t)stripe_bytes;
         const int waves = (int)std::min<int64_t>(8, fit);
-        const bool shape_ok = (dim & 3) == 0 && (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 && dim >= 1024 && dim <= 4096;
+        const int32_t min_dim_w = ctx->opt_weighted_min_dim > 0 ? (int32_t)ctx->opt_weighted_min_dim : 4;  // (until round 6: 1024 -- rows of 64 .. 1000 columns x 64 .. 256 samples run 1.5 - 1.75 x faster here than one workgroup per row, profiles/r06_ab_weighted_small_dims.txt)
+        const bool shape_ok = (dim & 3) == 0 && (reinterpret_cast<uintptr_t>(d_x) & 15) == 0 && dim >= min_dim_w && dim <= 4096;
         if (shape_ok && waves >= 4 && ctx->opt_weighted_kernel != 1) {  // (weighted.debug 1 / 2: this kernel's phases alone, profiling)
             const size_t lds = cache_bytes + stripe_bytes * (size_t)waves;
             const int64_t groups = (n_rows + waves - 1) / waves;

@@ -84,6 +84,7 @@ def main():
         ctx.set_option("weighted.plan", int(opts.get("plan", 0)))
         ctx.set_option("weighted.rescue", int(opts.get("rescue", 0)))
         ctx.set_option("weighted.refill", int(opts.get("refill", 0)))
+        ctx.set_option("weighted.min_dim", int(opts.get("min_dim", 0)))
 
         def call():
             if args.csr:
