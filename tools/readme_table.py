@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""tools/readme_table.py -- README.md's "Measured" table, generated from profiles/r05_bench.json (the headline bench line with
-its extra configs) and profiles/r05_bench_n{2,8}_host.json (ranks sharing one GPU over the host-staged transport).
+"""tools/readme_table.py -- README.md's "Measured" table, generated from profiles/r06_bench.json (the headline bench line with
+its extra configs) and profiles/r06_bench_n{2,8}_host.json (ranks sharing one GPU over the host-staged transport).
 
     python tools/readme_table.py            # rewrites the block between the markers in README.md
     python tools/readme_table.py --print    # the block on stdout"""
@@ -25,17 +25,19 @@ def row(what, shape, ms, frac, note=""):
 
 
 def main():
-    d = load("r05_bench.json")
+    d = load("r06_bench.json")
     if d is None:
-        raise SystemExit("profiles/r05_bench.json is missing")
+        raise SystemExit("profiles/r06_bench.json is missing")
     e, r, cpu = d["extra"], d["roofline"], d["cpu_baseline"]
     # (files written before the values-in figure became config 4's primary one keep it under kernel_device_log)
     c4v = e["c4"].get("kernel_device_log") or e["c4"]["kernel"]
     c4l = e["c4"].get("kernel_logs_in") or e["c4"]["kernel"]
     lines = [BEGIN,
-             f"Measured on one MI355X (`profiles/r05_bench.json`: `python bench.py`, every launch timed with HIP events behind a clock warm-up; "
+             f"Measured on one MI355X (`profiles/r06_bench.json`: `python bench.py`, every launch timed with HIP events behind a clock warm-up; "
              f"`frac` = algorithmic bytes / time against 8 TB/s).  Headline: **{d['value']:.3g} signatures/s** ({d['ms_per_step']:.2f} ms per 10^6 sets, "
-             f"traffic {r['traffic'] / r['algorithmic_bytes_per_launch']:.2f}x algorithmic, VALU issue {r['valu_issue_frac']:.2f}); the numpy path "
+             
+             + (f"traffic {r['traffic'] / r['algorithmic_bytes_per_launch']:.2f}x algorithmic, VALU issue {r['valu_issue_frac']:.2f}" if r.get("traffic") else
+                "counters not replayed: taken on another tree") + "); the numpy path "
              f"({cpu['kind']}) does {cpu['single_core_value']:.3g}/s per core, {cpu['value']:.3g}/s on {cpu['cores']} cores of the box's {cpu['cpu_model']}; "
              f"host numpy in -> host numpy out (PCIe included) {d['pcie_inclusive_value']:.2g}/s, {d['pcie_inclusive_u32_value']:.2g}/s with uint32 tokens and signatures.",
              "",
@@ -53,6 +55,13 @@ def main():
                  f"every element evaluated: {e['c4']['kernel_every_element']['kernel_ms']:.1f} ms; from Python, bit-exact mode: {e['c4']['from_python_parity_mode']['seconds'] * 1e3:.0f} ms"),
              row("config 4, logs precomputed and resident", "100k x 4096, S=128", c4l["kernel_ms"], c4l["frac"]),
              ]
+    if "fused_band_major_uint64_in" in e["c5"]:
+        u = e["c5"]["fused_band_major_uint64_in"]
+        lines.append(row("config 5 shard from uint64 signatures (the reference's width: 2 336 B per signature)", "1.25M x 256", u["kernel_ms"], u["frac"]))
+    if "c4_sparse" in e:
+        k = e["c4_sparse"]["kernel"]
+        lines.append(row("config 4, the 1 %-dense CSR variant (entry by entry)", "100k rows x 41 of 4096, S=128", k["kernel_ms"], k["frac"],
+                         f"bound by the table's way from the L2 ({k['table_GBps_from_l2'] / 1e3:.0f} TB/s of 16-byte entries), not by HBM"))
     if "c3_full" in e:
         f3, f5 = e["c3_full"], e["c5_full"]
         lines += [row("**config 3 at its stated size**: signatures", "10M x 256 (2.56e9 tokens), K=256", f3["signatures"]["kernel_ms"], f3["signatures"]["frac"]),
@@ -62,11 +71,15 @@ def main():
                   row("**config 5 at its stated size**: blocks + digests, one read", "10M x 256", f5["fused"]["kernel_ms"], f5["fused"]["frac"],
                       f"two kernels: {f5['two_kernels_ms']:.2f} ms")]
     for n in (2, 8):
-        m = load(f"r05_bench_n{n}_host.json")
+        m = load(f"r06_bench_n{n}_host.json")
         if m and "extra" in m and "c3_sharded" in m["extra"] and "ms" in m["extra"]["c3_sharded"]:
             c = m["extra"]["c3_sharded"]
             lines.append(f"| config 3 across {n} ranks SHARING this one GPU (plumbing, not a scaling number) | {c['rows_total']} rows, transport `{c['allgather']['transport']}` | "
                          f"{c['pipeline_ms']:.3g} | — | signatures {c['ms']['signatures']:.1f} + all-gather {c['ms']['allgather']:.0f} + digests {c['ms']['band_digests']:.2f} + bucketing {c['ms']['bucketing']:.2f} |")
+            bb = c.get("by_band")
+            if bb and "exchange" in bb:
+                lines.append(f"| ... the same index through the by-band digest exchange | {bb['exchange']['bytes_received_per_gpu'] / 1e9:.2f} GB received per rank instead of "
+                             f"{c['allgather']['bytes_received_per_gpu'] / 1e9:.2f} GB | {bb['pipeline_ms']:.3g} | — | exchange {bb['ms']['exchange']:.0f} ms on the same host-staged transport |")
     lines += ["", "No multi-GPU node has been available: the RCCL all-gather has run with one rank only (`DESIGN.md` section 6).", END]
     block = "\n".join(lines)
     if "--print" in sys.argv:
