@@ -205,32 +205,45 @@ def extra_configs(ctx, tokens, d_tok, seed, only):
 # ------------------------------------------------------------------------------------------------
 
 
-def full_corpus(ctx, n, t, shards=8, piece=50_000, sample=4096):
+def full_corpus(ctx, n, t, shards=8, piece=50_000, sample=4096, blocks=(0, 0)):
     """Config 3's corpus, resident in HBM: shard q = RandomState(42 + q).randint(0, 2**32, (rows_q, t), uint64) (SURVEY.md
     section 8d), drawn by one host thread per shard (numpy releases the GIL inside the draw) in pieces of 50k sets that
     go up as they are made -- 20.5 GB on the device, 100 MB per thread on the host.  Returns the device buffer, `sample`
-    row numbers spread over the whole corpus and their tokens (what the oracle will be given)."""
+    row numbers spread over the whole corpus and their tokens (what the oracle will be given) -- and, with blocks = (count,
+    length), the first rows and the tokens of `count` runs of `length` consecutive sets spread over the corpus (a
+    million rows of config 3 against the oracle, not four thousand; runs, so that their signatures come back in `count` copies)."""
     from concurrent.futures import ThreadPoolExecutor
 
     from datasketch_amd.dist import shard_rows
 
     d_tok = ctx.alloc(n * t * 8)
     rows = np.unique(np.concatenate([np.linspace(0, n - 1, sample).astype(np.int64), [0, n - 1]]))
+    count, length = blocks
+    length = min(length, n)
+    starts = np.unique(np.linspace(0, n - length, count).astype(np.int64)) if count and length else np.empty(0, dtype=np.int64)
+    starts = starts[np.concatenate([[True], np.diff(starts) >= length])] if starts.size else starts  # (no overlapping runs on a small corpus)
+    run_rows = (starts[:, None] + np.arange(length, dtype=np.int64)[None, :]).reshape(-1)
 
     def make(q):
         b, e = shard_rows(n, shards, q)
         rng = np.random.RandomState(42 + q)
-        kept = []
+        kept, kept_runs = [], []
         for lo in range(b, e, piece):
             m = min(piece, e - lo)
             part = rng.randint(0, 2**32, size=(m, t), dtype=np.uint64)
             sel = rows[(rows >= lo) & (rows < lo + m)]
             kept.append(part[sel - lo].copy())
+            sel = run_rows[(run_rows >= lo) & (run_rows < lo + m)]
+            kept_runs.append(part[sel - lo].copy())
             d_tok.upload(part, offset=lo * t * 8)
-        return np.concatenate(kept) if kept else np.empty((0, t), dtype=np.uint64)
+        none = np.empty((0, t), dtype=np.uint64)
+        return (np.concatenate(kept) if kept else none), (np.concatenate(kept_runs) if kept_runs else none)
 
     with ThreadPoolExecutor(max(1, min(shards, _usable_cores()))) as pool:
-        sample_tokens = np.concatenate(list(pool.map(make, range(shards))))
+        made = list(pool.map(make, range(shards)))
+    sample_tokens = np.concatenate([m[0] for m in made])
+    if count and length:
+        return d_tok, rows, sample_tokens, (starts, length, np.concatenate([m[1] for m in made]))
     return d_tok, rows, sample_tokens
 
 
@@ -247,7 +260,8 @@ def extra_full(ctx, n, seed, checks="sample", t=256, k=256, bands=32, r=8):
 
     lib = ctx.lib
     t0 = time.perf_counter()
-    d_tok, rows, tok = full_corpus(ctx, n, t)
+    n_runs = 250 if checks == "all" else 25  # x 4 000 consecutive sets: 1 000 000 rows ("all": the GPU test) or 100 000 (every bench run) against the oracle
+    d_tok, rows, tok, (run_starts, run_len, run_tok) = full_corpus(ctx, n, t, blocks=(n_runs, 4000))
     gen_s = time.perf_counter() - t0
     perms = MinHash(num_perm=k, seed=seed, hashfunc=lambda x: x).permutations
     nb = k // 64
@@ -264,6 +278,15 @@ def extra_full(ctx, n, seed, checks="sample", t=256, k=256, bands=32, r=8):
     want = O.c_minhash_bulk_dense(tok, a, b)
     if not np.array_equal(_download_rows(d_sig, rows, k, np.uint32).astype(np.uint64), want):
         raise SystemExit("PARITY FAILURE (extra.c3_full): signatures differ from the oracle")
+    # ... and a million rows of them (runs of consecutive sets spread over the corpus): the C oracle on every host thread
+    w0 = time.perf_counter()
+    want_runs = O.c_minhash_bulk_dense_parallel(run_tok, a, b)
+    for i, st in enumerate(run_starts):
+        got = d_sig.download((run_len, k), np.uint32, offset=int(st) * k * 4)
+        if not np.array_equal(got.astype(np.uint64), want_runs[i * run_len: (i + 1) * run_len]):
+            raise SystemExit(f"PARITY FAILURE (extra.c3_full): signatures of rows {int(st)} .. {int(st) + run_len} differ from the oracle")
+    runs_checked, runs_s = int(len(run_starts) * run_len), time.perf_counter() - w0
+    del want_runs, run_tok
     want_dig = lsh_bulk.band_digests(want, bands, r, gpu_mode="disable")  # FNV-1a-64 of the reference's key bytes (lsh.py:537-538), numpy
     for i in range(8):
         keys = O.c_band_keys(want[i: i + 1], bands, r)
@@ -305,7 +328,9 @@ def extra_full(ctx, n, seed, checks="sample", t=256, k=256, bands=32, r=8):
         "lsh_sort_digests": dict(_roof(n * (8 * bands + 12 * bands), ms_sort), keys_per_s=n * bands / (ms_sort * 1e-3)),
         "pipeline_ms": ms_sig + ms_dig + ms_sort,
         "corpus_seconds_on_host": gen_s,
-        "parity": f"{len(rows)} rows spread over the corpus: signatures vs the C oracle, {bands} digests each vs FNV-1a-64 of the reference's key bytes; "
+        "signature_rows_vs_oracle": runs_checked + len(rows),
+        "parity": f"{runs_checked} rows in {len(run_starts)} runs of {run_len} consecutive sets spread over the corpus: signatures vs the C oracle ({runs_s:.1f} s on the host's threads); "
+                  f"{len(rows)} rows spread over the corpus: signatures vs the C oracle, {bands} digests each vs FNV-1a-64 of the reference's key bytes; "
                   f"sorted bands {check_bands if checks != 'all' else 'all'}: ascending, equal to the digest column gathered by the sorted rows, rows ascending "
                   f"inside every bucket, a permutation" + ("; all bands equal to the stable radix sort's" if radix is not None else ""),
     }
