@@ -277,13 +277,16 @@ __global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32
         // in turn, kMine = kBinCap / kSortThreads = six memory latencies per bin and pass)
         constexpr int kMine = (kBinCap + kSortThreads - 1) / kSortThreads;
         const uint32_t last = count ? count - 1 : 0;
+        uint64_t d[kMine];
+        uint32_t rw[kMine];
         {
-            uint64_t d[kMine];
 #pragma unroll
             for (int u = 0; u < kMine; ++u) {
                 const uint32_t i = tid + u * kSortThreads;
                 d[u] = slab_dig[slab + (i < count ? i : last)];
             }
+#pragma unroll
+            for (int u = 0; u < kMine; ++u) rw[u] = slab_row[slab + (tid + u * kSortThreads < count ? tid + u * kSortThreads : last)];  // (needed behind the scan: on their way meanwhile)
 #pragma unroll
             for (int u = 0; u < kMine; ++u)
                 if (tid + u * kSortThreads < count) atomicAdd(&cnt[sub_of(d[u])], 1u);
@@ -306,14 +309,6 @@ __global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32
         }
         __syncthreads();
         {
-            uint64_t d[kMine];
-            uint32_t rw[kMine];
-#pragma unroll
-            for (int u = 0; u < kMine; ++u) {
-                const uint32_t i = tid + u * kSortThreads;
-                d[u] = slab_dig[slab + (i < count ? i : last)];
-                rw[u] = slab_row[slab + (i < count ? i : last)];
-            }
 #pragma unroll
             for (int u = 0; u < kMine; ++u)
                 if (tid + u * kSortThreads < count) {
