@@ -109,7 +109,7 @@ __device__ __forceinline__ uint32_t bin_of(uint64_t digest, int bin_bits) { retu
 // the band is the top hi + lo digest bits, of which the low lo bits index the team's histogram.
 struct SlabPairs {};  // source of level 1: src_dig / src_row slabs of src_cap elements per unit, src_cursor[unit] of them filled
 
-template <typename SigT, int kScatterRows>
+template <typename SigT, int kScatterRows, int T = 256>  // T: threads of a team (1024 for unit-stride sources since round 6: see launch_scatter_rows)
 __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__restrict__ sig, int32_t k, int32_t r, int64_t n, int32_t units,
                                                                int hi_bits, int lo_bits, int band_share, uint32_t cap,
                                                                uint32_t *__restrict__ cursor, uint64_t *__restrict__ slab_dig,
@@ -118,10 +118,10 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
                                                                const uint32_t *__restrict__ src_cursor, uint32_t src_cap) {
     constexpr bool kPairs = std::is_same<SigT, SlabPairs>::value;
     using RowT = typename std::conditional<kPairs, uint32_t, uint16_t>::type;  // staged per element: the row itself, or row - row0
-    constexpr int kChunk = 256 * kScatterRows;
+    constexpr int kChunk = T * kScatterRows;
     extern __shared__ uint64_t scatter_lds[];  // per team: st_dig[kChunk] | hist[nb] | base[nb] | lstart[nb] | st_row RowT[kChunk] | scan_tmp[4]
-    const int nb = 1 << lo_bits, team = threadIdx.x >> 8, tid = threadIdx.x & 255;
-    const size_t team_words = kChunk + (3 * (size_t)nb * 4 + kChunk * sizeof(RowT) + 16 + 7) / 8;
+    const int nb = 1 << lo_bits, team = threadIdx.x / T, tid = threadIdx.x % T;
+    const size_t team_words = kChunk + (3 * (size_t)nb * 4 + kChunk * sizeof(RowT) + 32 + 7) / 8;
     uint64_t *st_dig = scatter_lds + team * team_words;  // the chunk's elements grouped by bin before they go out
     uint32_t *hist = reinterpret_cast<uint32_t *>(st_dig + kChunk), *base = hist + nb, *lstart = base + nb;
     RowT *st_row = reinterpret_cast<RowT *>(lstart + nb);
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
         if (kPairs && row0 >= count) continue;  // (band_share is 1 for pair sources: workgroup-uniform)
         const int band = kPairs ? unit >> hi_bits : unit;
         const int64_t src0 = kPairs ? (int64_t)unit * src_cap : 0;
-        for (int t = tid; t < nb; t += 256) hist[t] = 0;
+        for (int t = tid; t < nb; t += T) hist[t] = 0;
         __syncthreads();
         // the element's bin inside the band (top hi + lo digest bits) and inside this source unit (the low lo bits of that)
         const auto gbin_of = [&](uint64_t d) { return tot_bits ? (uint32_t)(d >> (64 - tot_bits)) : 0u; };
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
         uint32_t rw[kPairs ? kScatterRows : 1];
 #pragma unroll
         for (int j = 0; j < kScatterRows; ++j) {
-            const int64_t row = row0 + j * 256 + tid;
+            const int64_t row = row0 + j * T + tid;
             const int64_t at = row < count ? row : count - 1;  // (count > 0 here)
             if constexpr (kPairs) {
                 dg[j] = src_dig[src0 + at];
@@ -169,13 +169,13 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
         }
 #pragma unroll
         for (int j = 0; j < kScatterRows; ++j)
-            if (row0 + j * 256 + tid < count) atomicAdd(&hist[gbin_of(dg[j]) & (nb - 1)], 1u);
+            if (row0 + j * T + tid < count) atomicAdd(&hist[gbin_of(dg[j]) & (nb - 1)], 1u);
         __syncthreads();
         // per bin: a range of its slab (one global atomic) and the start of its elements in the team's staging area
         // (exclusive scan of the counts: thread t owns bins [t * per, t * per + per))
         const int64_t out0 = ((int64_t)band << tot_bits) + (kPairs ? (int64_t)(unit & ((1 << hi_bits) - 1)) << lo_bits : 0);  // the unit's first output bin
         {
-            const int per = (nb + 255) / 256;  // (<= kMaxBinsPerThread)
+            const int per = (nb + T - 1) / T;  // (<= kMaxBinsPerThread)
             uint32_t cnts[kMaxBinsPerThread], bases[kMaxBinsPerThread], sum = 0;
 #pragma unroll
             for (int j = 0; j < kMaxBinsPerThread; ++j) {  // the thread's returning atomics go out back to back: one round trip to the L2, not `per`
@@ -201,19 +201,19 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < kScatterRows; ++j) {
-            const int64_t row = row0 + j * 256 + tid;
+            const int64_t row = row0 + j * T + tid;
             if (row < count) {
                 const uint32_t bin = gbin_of(dg[j]) & (nb - 1);
                 const uint32_t lp = lstart[bin] + atomicAdd(&hist[bin], 1u);
                 st_dig[lp] = dg[j];
                 if constexpr (kPairs) st_row[lp] = rw[j];
-                else st_row[lp] = (uint16_t)(j * 256 + tid);
+                else st_row[lp] = (uint16_t)(j * T + tid);
             }
         }
         __syncthreads();
         // out: consecutive threads carry consecutive elements of a bin -- every (team, bin) piece is one contiguous run
         const uint32_t total = (uint32_t)min((int64_t)kChunk, count - row0);
-        for (uint32_t i = tid; i < total; i += 256) {
+        for (uint32_t i = tid; i < total; i += T) {
             const uint64_t d = st_dig[i];
             const uint32_t bin = gbin_of(d) & (nb - 1);
             const uint32_t pos = base[bin] + (i - lstart[bin]);
@@ -770,9 +770,9 @@ __global__ __launch_bounds__(256) void digests_to_band_major_kernel(const uint64
 }
 
 // one scatter pass (see lsh_bin_scatter_kernel); returns false when the launch is refused
-static size_t scatter_team_bytes(int lo_bits, bool pairs, int rows) {
-    const size_t nb = (size_t)1 << lo_bits, chunk = 256 * (size_t)rows;
-    return 8 * chunk + 8 * ((3 * nb * 4 + chunk * (pairs ? 4 : 2) + 16 + 7) / 8);
+static size_t scatter_team_bytes(int lo_bits, bool pairs, int rows, int team = 256) {
+    const size_t nb = (size_t)1 << lo_bits, chunk = (size_t)team * (size_t)rows;
+    return 8 * chunk + 8 * ((3 * nb * 4 + chunk * (pairs ? 4 : 2) + 32 + 7) / 8);
 }
 
 template <typename SigT, int ROWS>
@@ -781,6 +781,25 @@ static bool launch_scatter_rows(mhx_ctx *ctx, const SigT *d_sig, int32_t k, int3
                                 const uint32_t *d_src_row, const uint32_t *d_src_cursor, uint32_t src_cap) {
     constexpr bool kPairs = std::is_same<SigT, SlabPairs>::value;
     const int64_t span = kPairs ? (int64_t)src_cap : n;
+    if constexpr (ROWS == 16 && (kPairs || std::is_same<SigT, Digest64BM>::value)) {
+        // Round 6: a unit-stride source is taken by ONE team of 1024 threads x 8 rows per workgroup (92 KB of LDS: one workgroup, sixteen waves
+        // per CU) instead of three teams of 256 x 16 -- 8192 rows per (team, bin) histogram: half the returning cursor atomics (one per
+        // (team, bin): 5M instead of 10M for 40M keys) and runs of eight elements instead of four for the L2 to merge into lines.  Same box,
+        // interleaved (tools/ab_option.py lsh.team): 40M keys 0.472 -> 0.441 ms, 320M keys 5.08 -> 4.87 ms; 512 x 16: 0.457 / 4.99, 768 x 16:
+        // 0.470 / 5.04, 1024 x 12: 0.445 / 4.89, 1024 x 14: 0.443 / 5.19, 512 x 24 rows: 0.54 / 7.4 (profiles/r06_ab_scatter_team.txt).
+        // Option lsh.team 256: the teams of 256.
+        constexpr int TT = 1024, RR = 8;
+        const size_t lds2 = scatter_team_bytes(lo_bits, kPairs, RR, TT);
+        const int64_t items2 = (span + TT * RR - 1) / (TT * RR) * units;
+        // (fewer than eight items per CU -- 200k rows x 32 bands: 0.101 against 0.095 ms -- leave the single workgroup per CU short of work: teams of 256)
+        if (band_share == 1 && ctx->opt_lsh_team != 256 && lds2 <= (size_t)ctx->lds_per_block && (items2 >= 8 * (int64_t)ctx->num_cus || ctx->opt_lsh_team == 1024)) {
+            const int64_t per_cu2 = std::max<int64_t>(1, (int64_t)((size_t)ctx->lds_per_block / (lds2 + 64)));
+            const unsigned grid2 = (unsigned)std::max<int64_t>(1, std::min<int64_t>(items2, (int64_t)ctx->num_cus * per_cu2 * 2));
+            hipLaunchKernelGGL((lsh_bin_scatter_kernel<SigT, RR, TT>), dim3(grid2), dim3(TT), lds2, ctx->stream, d_sig, k, r, n, units, hi_bits, lo_bits, 1, cap,
+                               d_cursor, d_slab_dig, d_slab_row, d_overflow, d_src_dig, d_src_row, d_src_cursor, src_cap);
+            return hipGetLastError() == hipSuccess;
+        }
+    }
     const int64_t items = (span + 256 * ROWS - 1) / (256 * ROWS) * (units / band_share);
     const size_t lds = scatter_team_bytes(lo_bits, kPairs, ROWS) * band_share;
     const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(32 / (4 * band_share), (int64_t)((size_t)ctx->lds_per_block / (lds + 64))));
