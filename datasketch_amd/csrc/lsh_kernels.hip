@@ -232,7 +232,7 @@ __device__ __forceinline__ bool pair_less(uint64_t da, uint32_t ra, uint64_t db,
 // where every bin's elements go in the output: the sizes of the band's bins before it (one workgroup per band; a bin holds at
 // most kBinCap elements).  Computed once here: lsh_bin_sort_kernel used to sum the band's cursors in every workgroup -- a loop of
 // dependent loads (eight L2 round trips per thread at 4096 bins) and a 512-thread tree reduction, nine barriers per bin.
-__global__ __launch_bounds__(256) void lsh_bin_offsets_kernel(const uint32_t *__restrict__ cursor, int bin_bits, uint32_t *__restrict__ bin_start) {
+__global__ __launch_bounds__(256) void lsh_bin_offsets_kernel(const uint32_t *__restrict__ cursor, int bin_bits, uint32_t bin_cap, uint32_t *__restrict__ bin_start) {
     __shared__ uint32_t scan_tmp[4];
     const int nb = 1 << bin_bits, tid = threadIdx.x;
     const uint32_t *cur = cursor + (int64_t)blockIdx.x * nb;
@@ -241,24 +241,33 @@ __global__ __launch_bounds__(256) void lsh_bin_offsets_kernel(const uint32_t *__
     uint32_t sum = 0;
     for (int j = 0; j < per; ++j) {
         const int t = tid * per + j;
-        if (t < nb) sum += min(cur[t], (uint32_t)kBinCap);
+        if (t < nb) sum += min(cur[t], bin_cap);
     }
     uint32_t at = block_inclusive_scan(sum, scan_tmp, tid) - sum;
     for (int j = 0; j < per; ++j) {
         const int t = tid * per + j;
         if (t < nb) {
             dst[t] = at;
-            at += min(cur[t], (uint32_t)kBinCap);
+            at += min(cur[t], bin_cap);
         }
     }
 }
 
+// Round 6: the pass is a template over (capacity, sub-bucket bits, threads).  <3072, 10, 512> is the pass of rounds 3-5 (bins of ~2 400 elements,
+// three workgroups per CU).  <kBigBinCap, 12, 1024> finishes bins of ~10 000 elements -- the whole LDS of a CU, one workgroup of sixteen waves -- so that
+// between 2.6M and 10.5M rows per band ONE scatter level into 1024 big bins is enough: two passes over the keys instead of three (10M x 32: see
+// launch_lsh_bucket_bands).  The bucket starts are 16-bit there (a bin holds fewer than 65 536 elements) to fit 4096 buckets beside the bin.
+constexpr int kBigBinCap = 11264, kBigSubBits = 12, kBigSortThreads = 1024;
+template <int kBinCap, int kSubBits, int kSortThreads>
 __global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32_t *__restrict__ cursor, const uint32_t *__restrict__ bin_start,
                                                            const uint64_t *__restrict__ slab_dig, const uint32_t *__restrict__ slab_row, int64_t n,
                                                            int32_t bands, int bin_bits, uint64_t *__restrict__ out_dig, uint32_t *__restrict__ out_row) {
+    using StartT = typename std::conditional<(kBinCap > 4096), uint16_t, uint32_t>::type;
+    static_assert(kBinCap < 65536, "16-bit bucket starts");
     __shared__ uint64_t dig[kBinCap];
     __shared__ uint32_t row[kBinCap];
-    __shared__ uint32_t cnt[1 << kSubBits], start[1 << kSubBits];
+    __shared__ uint32_t cnt[1 << kSubBits];
+    __shared__ StartT start[1 << kSubBits];
     __shared__ uint32_t scan_tmp[kSortThreads / 64];
     const int nb = 1 << bin_bits, tid = threadIdx.x;
     constexpr int kSub = 1 << kSubBits, kPer = kSub / kSortThreads;
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32
         uint32_t at = incl - sum;
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
-            start[tid * kPer + j] = at;
+            start[tid * kPer + j] = (StartT)at;
             cnt[tid * kPer + j] = 0;
             at += mine[j];
         }
@@ -834,13 +843,19 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     int bin_bits = 0;
     while (bin_bits < kMaxBinBits && (n >> bin_bits) > 2500) ++bin_bits;  // about 1250 .. 2500 elements per bin (kBinCap: 3072)
     if ((n >> bin_bits) > 2500) return MHX_OK;                            // more than 41 million rows: the radix sort
+    // Round 6: between 2.56M and 10.2M rows ONE scatter level into 2^10 big bins of up to kBigBinCap elements, finished by the bin pass's
+    // <kBigBinCap, 12, 1024> form (a CU's whole LDS): two passes over the keys instead of three.  Option lsh.bigbins: 1 = never, 2 = from 4 bins on (tests).
+    const bool big = ctx->opt_lsh_bigbins != 1 && ctx->opt_lsh_levels != 2 &&
+                     ((bin_bits > kOneLevelBits && (n >> kOneLevelBits) <= (kBigBinCap * 10) / 11) || (ctx->opt_lsh_bigbins == 2 && bin_bits >= 2));
+    if (big) bin_bits = ctx->opt_lsh_bigbins == 2 && bin_bits <= kOneLevelBits ? bin_bits - 2 : kOneLevelBits;
+    const int32_t bin_cap = big ? kBigBinCap : kBinCap;
     // beyond 2^10 bins: two scatter levels of about half the bits each (see the kernel)
     const int hi_bits = bin_bits > kOneLevelBits || (ctx->opt_lsh_levels == 2 && bin_bits >= 2) ? bin_bits / 2 : 0, lo_bits = bin_bits - hi_bits;  // (option lsh.levels = 2: two levels at any size, for the tests)
     const int64_t nb = (int64_t)1 << bin_bits, bins = nb * bands;
     const int64_t big_bins = hi_bits ? ((int64_t)bands << hi_bits) : 0;
     const uint32_t cap0 = hi_bits ? (uint32_t)std::min<int64_t>(0xFFFFFFFFll, (n >> hi_bits) + (n >> hi_bits) / 32 + 4096) : 0;  // 3 % + 4096 over the mean (sigma = sqrt(mean))
     const size_t cur_bytes = ((sizeof(uint32_t) * (size_t)(2 * bins + big_bins + 2)) + 255) & ~(size_t)255;  // cursor[bins] | overflow | cursor0[big_bins] | overflow0 | bin_start[bins]: 2 * bins + big_bins + 2 words (both overflow words counted)
-    const size_t dig_bytes = sizeof(uint64_t) * (size_t)bins * kBinCap, row_bytes = sizeof(uint32_t) * (size_t)bins * kBinCap;
+    const size_t dig_bytes = sizeof(uint64_t) * (size_t)bins * bin_cap, row_bytes = sizeof(uint32_t) * (size_t)bins * bin_cap;
     const size_t dig0_bytes = ((sizeof(uint64_t) * (size_t)big_bins * cap0) + 255) & ~(size_t)255, row0_bytes = ((sizeof(uint32_t) * (size_t)big_bins * cap0) + 255) & ~(size_t)255;
     if (cur_bytes + dig_bytes + row_bytes + dig0_bytes + row0_bytes > (size_t)ctx->hbm_bytes / 4) return MHX_OK;
     // bands whose r values of a row share a 128-byte line go to one workgroup (at most four) -- as far as the teams'
@@ -870,7 +885,7 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     uint32_t *cur_a = hi_bits ? d_cursor0 : d_cursor, *ovf_a = hi_bits ? d_overflow0 : d_overflow;
     uint64_t *dig_a = hi_bits ? d_slab0_dig : d_slab_dig;
     uint32_t *row_a = hi_bits ? d_slab0_row : d_slab_row;
-    const uint32_t cap_a = hi_bits ? cap0 : (uint32_t)kBinCap;
+    const uint32_t cap_a = hi_bits ? cap0 : (uint32_t)bin_cap;
     bool ok;
 #define MHX_SCATTER_A(T) ok = launch_scatter<T>(ctx, (const T *)d_sig, k, r, n, bands, 0, first_bits, band_share, cap_a, cur_a, dig_a, row_a, ovf_a, nullptr, nullptr, nullptr, 0)
     if (sig_dtype == kSigDigestsBM) MHX_SCATTER_A(Digest64BM);
@@ -889,9 +904,13 @@ static int launch_lsh_bucket_bands(mhx_ctx *ctx, const void *d_sig, int sig_dtyp
     if (hi_bits) MHX_HIP_CHECK(hipMemcpyAsync(&overflow[1], d_overflow0, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     MHX_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     if (overflow[0] || overflow[1]) return MHX_OK;
-    hipLaunchKernelGGL(lsh_bin_offsets_kernel, dim3((unsigned)bands), dim3(256), 0, ctx->stream, d_cursor, bin_bits, d_bin_start);
-    hipLaunchKernelGGL(lsh_bin_sort_kernel, dim3((unsigned)std::min<int64_t>(bins, (int64_t)ctx->num_cus * 96)), dim3(kSortThreads), 0, ctx->stream, d_cursor,
-                       d_bin_start, d_slab_dig, d_slab_row, n, bands, bin_bits, d_sorted_digests, d_sorted_rows);
+    hipLaunchKernelGGL(lsh_bin_offsets_kernel, dim3((unsigned)bands), dim3(256), 0, ctx->stream, d_cursor, bin_bits, (uint32_t)bin_cap, d_bin_start);
+    if (big)
+        hipLaunchKernelGGL((lsh_bin_sort_kernel<kBigBinCap, kBigSubBits, kBigSortThreads>), dim3((unsigned)std::min<int64_t>(bins, (int64_t)ctx->num_cus * 32)), dim3(kBigSortThreads), 0,
+                           ctx->stream, d_cursor, d_bin_start, d_slab_dig, d_slab_row, n, bands, bin_bits, d_sorted_digests, d_sorted_rows);
+    else
+        hipLaunchKernelGGL((lsh_bin_sort_kernel<kBinCap, kSubBits, kSortThreads>), dim3((unsigned)std::min<int64_t>(bins, (int64_t)ctx->num_cus * 96)), dim3(kSortThreads), 0, ctx->stream,
+                           d_cursor, d_bin_start, d_slab_dig, d_slab_row, n, bands, bin_bits, d_sorted_digests, d_sorted_rows);
     MHX_HIP_CHECK(hipGetLastError());
     *done = true;
     return MHX_OK;

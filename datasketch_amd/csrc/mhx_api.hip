@@ -386,6 +386,7 @@ int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value) {
     else if (!strcmp(key, "lsh.levels")) ctx->opt_lsh_levels = value;
     else if (!strcmp(key, "lsh.chunk")) ctx->opt_lsh_chunk = value;
     else if (!strcmp(key, "lsh.team")) ctx->opt_lsh_team = value;
+    else if (!strcmp(key, "lsh.bigbins")) ctx->opt_lsh_bigbins = value;
     else if (!strcmp(key, "pack.fused")) ctx->opt_pack_fused = value;
     else if (!strcmp(key, "weighted.refill")) ctx->opt_weighted_refill = value;
     else if (!strcmp(key, "lsh.prehash")) ctx->opt_lsh_prehash = value;

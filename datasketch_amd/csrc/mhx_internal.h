@@ -92,6 +92,7 @@ struct mhx_ctx {
     int64_t opt_lsh_sort_bits = 0;  // mhx_lsh_sort_bands: bits of (band, digest) the radix sort orders by; 0 = from n
     int64_t opt_lsh_prehash = 0;    // mhx_lsh_sort_bands on a signature matrix: 0 auto (band digests first, then the bucketing), 1 = hash inside the scatter pass (A/B)
     int64_t opt_lsh_chunk = 0;      // bucketing: rows per thread of a scatter pass over a unit-stride source: 0 auto (16), 8 = eight (A/B)
+    int64_t opt_lsh_bigbins = 0;    // bucketing: 0 auto (2.56M .. 10.2M rows: one scatter level into 1024 big bins + the big bin pass), 1 never, 2 whenever there are at least 4 bins (tests)
     int64_t opt_lsh_team = 0;       // bucketing, unit-stride sources: 0 auto (one team of 1024 threads x 8 rows per workgroup), 256 = teams of 256 x 16 (until round 6; A/B, tests)
     int64_t opt_lsh_levels = 0;     // bucketing: 0 auto (two scatter levels beyond 2^10 bins per band), 2 = two levels whenever there are at least 4 bins
     int64_t opt_pack_fused = 0;     // mhx_bbit_pack_band_digests_dev: 0 auto (one read of the matrix where the shape allows), 1 = always the two kernels

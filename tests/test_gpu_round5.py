@@ -108,7 +108,12 @@ def test_bucketing_passes_in_both_layouts_equal_numpy_and_the_radix_sort(ctx, n)
     d_sd, d_sr = ctx.alloc(max(1, n * bands * 8)), ctx.alloc(max(1, n * bands * 4))
     res = {}
     for name, opts in (("lds", {}), ("two_levels", {"lsh.levels": 2}), ("radix", {"lsh.sort": 1}), ("band_major_two_levels", {"lsh.levels": 2}),
-                       ("band_major", {}), ("band_major_radix", {"lsh.sort": 1}), ("band_major_gather", {"lsh.sort": 1, "lsh.gather": 1})):
+                       ("band_major", {}), ("band_major_radix", {"lsh.sort": 1}), ("band_major_gather", {"lsh.sort": 1, "lsh.gather": 1}),
+                       # round 6: bins of up to 11 264 elements finished by the big form of the bin pass (auto between 2.56M and 10.2M rows: the 3M-row
+                       # case takes it by itself, lsh.bigbins = 1 is the three passes there; 2 forces it from 4 bins on), teams of 256 / 1024 threads
+                       ("big_bins", {"lsh.bigbins": 2}), ("band_major_big_bins", {"lsh.bigbins": 2}), ("band_major_never_big", {"lsh.bigbins": 1}),
+                       ("band_major_teams_256", {"lsh.team": 256}), ("band_major_teams_1024", {"lsh.team": 1024}),
+                       ("band_major_teams_1024_two_levels", {"lsh.team": 1024, "lsh.levels": 2})):
         for key, v in opts.items():
             ctx.set_option(key, v)
         try:
@@ -125,7 +130,7 @@ def test_bucketing_passes_in_both_layouts_equal_numpy_and_the_radix_sort(ctx, n)
         order = np.lexsort((np.arange(n), dig[:, j]))
         assert np.array_equal(res["lds"][1][j], order.astype(np.uint32)), j
         assert np.array_equal(res["lds"][0][j], dig[order, j]), j
-    for name in ("two_levels", "radix", "band_major", "band_major_two_levels", "band_major_radix", "band_major_gather"):
+    for name in res:
         assert np.array_equal(res[name][0], res["lds"][0]) and np.array_equal(res[name][1], res["lds"][1]), name
 
 
