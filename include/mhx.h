@@ -81,8 +81,8 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * permutations per lane, lane groups share a last slot that holds at most 32 permutations -- num_perm 129..160, 193..224 --, 1 = off),
  * ("minhash.adapt", 0 auto: the context remembers on the device whether the last call's sets mostly defeated the one-candidate proof and
  * starts the next call with the tie-tolerant one, 1 = off),
- * ("weighted.kernel", 0 auto: dense rows of 1024..4096 columns with 65..256 or 321..384 samples through the fetcher / walker kernel, other dense rows of 1024..4096
- * columns through the one-wave-per-row kernel, 1 = the workgroup-per-row kernel, 2 = one wave per row, sample chunks one after the other),
+ * ("weighted.kernel", 0 auto: dense rows of up to 4096 columns (a multiple of 4) with 65..256 or 321..384 samples through the fetcher / walker kernel, other dense rows
+ * of that width through the one-wave-per-row kernel, 1 = the workgroup-per-row kernel, 2 = one wave per row, sample chunks one after the other),
  * ("weighted.refill", 0 auto; 13 = auto without the fetcher / walker split, 5 / 6 / 8 / 9 = the split with other stripe counts and cached list positions,
  * 1 = round 4's plain loads behind the walk, 2 / 3 = the one-wave-per-row kernel's fetch modes; A/B), ("weighted.plan", 1 = plan and tables in two launches), ("weighted.rescue", n: a walk's last n lanes
  * are taken over by the whole wave, 0 auto = 8, < 0 never),
@@ -100,8 +100,14 @@ MHX_API int mhx_ctx_device_info(mhx_ctx *ctx, char *name, int name_len, int *cus
  * ("lsh.gather", 1 = gather the full digests after the sort instead of letting them ride through it),
  * ("lsh.prehash", mhx_lsh_sort_bands on a signature matrix: 0 auto = band digests first (one pass at the stream's rate), then the bucketing; 1 = hash inside
  * the bucketing's first pass),
- * ("lsh.sort", 0 auto: mhx_lsh_sort_bands buckets the bands in two passes and falls back to the radix sort when a bin
- * overflows or n > 12M, 1 = radix sort always). */
+ * ("lsh.team", bucketing over unit-stride sources: 0 auto = one team of 1024 threads x 8 rows per workgroup from eight items per CU on,
+ * 256 = teams of 256 threads x 16 rows (until round 6), 1024 = the one team at any size),
+ * ("lsh.bigbins", 0 auto: between 2.56M and 10.2M rows one scatter level into 1024 bins of up to 11 264 elements and the bin pass's big form
+ * (two passes over the keys instead of three), 1 = never, 2 = from 4 bins on (tests)),
+ * ("weighted.min_dim", dense rows at least this wide -- a multiple of 4, up to 4096 columns -- go to the one-wave-per-row / fetcher-walker kernels:
+ * 0 auto = 4, 1024 = the rule until round 6),
+ * ("lsh.sort", 0 auto: mhx_lsh_sort_bands buckets the bands in two passes (three beyond 10.2M rows) and falls back to the radix sort when a bin
+ * overflows or n > 41M, 1 = radix sort always). */
 MHX_API int mhx_ctx_set_option(mhx_ctx *ctx, const char *key, int64_t value);
 /* Kernel event counters since the last call (synchronises the stream, then resets them):
  *   out[0] sets the sieve launch left to the full launch (failed proof, or skipped by the back-off),
