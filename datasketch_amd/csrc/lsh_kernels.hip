@@ -69,6 +69,9 @@ __global__ __launch_bounds__(256) void gather_digests_kernel(const uint64_t *__r
 //     ascending order gives.
 // A bin can hold kBinCap elements; one that would overflow (a corpus of near-identical signatures) raises a flag that the
 // host reads after pass 1, and the call falls back to the radix sort.
+// Round 6: over unit-stride sources (band-major digests, big bins) pass 1 runs as one team of 1024 threads x 8 rows per workgroup
+// (launch_scatter_rows), and between 2.56M and 10.2M rows pass 1 stops at 1024 bins per band which pass 2 finishes in its big form
+// (bins of up to kBigBinCap = 11 264 elements in a CU's whole LDS): two passes over the keys where rounds 4-5 made three.
 constexpr int kBinCap = 3072;
 constexpr int kScatterRowsDefault = 8;   // rows per thread of pass 1 (2048 per team: 26 KB of LDS, six one-team workgroups per CU)
 constexpr int kSubBits = 10;  // (11 until round 5: 8 KB less LDS puts three workgroups on a CU instead of two, 0.45 -> 0.35 ms for 40M keys; 9 bits and a fourth workgroup gain nothing)
@@ -279,11 +282,11 @@ __global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32
         __syncthreads();
         const int64_t slab = item * kBinCap;
         const auto sub_of = [&](uint64_t d) { return (uint32_t)((bin_bits ? d << bin_bits : d) >> (64 - kSubBits)); };
-        // the slab is read twice (the second time from the L2): bucket sizes first, then every element to its bucket's range
-        // in LDS -- one LDS copy of the bin, three workgroups per CU
+        // bucket sizes first, then every element to its bucket's range in LDS -- one LDS copy of the bin, three workgroups per CU; a thread's
+        // elements stay in its registers across the scan (until round 6 they came from the L2 a second time: -1.5 %)
         // (a thread's loads all go out before the first is waited for -- a thread behind the bin's end reads its last element again --
         // and the LDS atomics follow in a loop of their own: with the atomic next to its load the compiler waited for every load
-        // in turn, kMine = kBinCap / kSortThreads = six memory latencies per bin and pass)
+        // in turn, kMine = kBinCap / kSortThreads = six (big form: eleven) memory latencies per bin and pass)
         constexpr int kMine = (kBinCap + kSortThreads - 1) / kSortThreads;
         const uint32_t last = count ? count - 1 : 0;
         uint64_t d[kMine];
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(kSortThreads) void lsh_bin_sort_kernel(const uint32
                 if (tid + u * kSortThreads < count) atomicAdd(&cnt[sub_of(d[u])], 1u);
         }
         __syncthreads();
-        // exclusive scan of the kSub = 1024 bucket sizes: a thread's kPer = 2 buckets, then the threads' sums
+        // exclusive scan of the kSub bucket sizes (1024, or 4096 in the big form): a thread's kPer buckets (2 / 4), then the threads' sums
         uint32_t mine[kPer], sum = 0;
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
