@@ -170,9 +170,12 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
                 dg[j] = band_digest_of<SigT>(sig, at, band, k, r, n);
             }
         }
+        uint16_t rank[kScatterRows];  // (T >= 1024 only) the element's rank inside its (team, bin) piece: what the counting atomic returns
 #pragma unroll
-        for (int j = 0; j < kScatterRows; ++j)
-            if (row0 + j * T + tid < count) atomicAdd(&hist[gbin_of(dg[j]) & (nb - 1)], 1u);
+        for (int j = 0; j < kScatterRows; ++j) {
+            if constexpr (T >= 1024) rank[j] = row0 + j * T + tid < count ? (uint16_t)atomicAdd(&hist[gbin_of(dg[j]) & (nb - 1)], 1u) : (uint16_t)0;
+            else if (row0 + j * T + tid < count) atomicAdd(&hist[gbin_of(dg[j]) & (nb - 1)], 1u);
+        }
         __syncthreads();
         // per bin: a range of its slab (one global atomic) and the start of its elements in the team's staging area
         // (exclusive scan of the counts: thread t owns bins [t * per, t * per + per))
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
                 const int t = tid * per + j;
                 if (j < per && t < nb) {
                     if (bases[j] + cnts[j] > cap) *overflow = 1u;
-                    base[t] = bases[j];
+                    base[t] = T >= 1024 ? bases[j] - at : bases[j];  // (T >= 1024: slab position of staged element i of this bin = base[bin] + i, mod 2^32)
                     lstart[t] = at;
                     hist[t] = 0;
                     at += cnts[j];
@@ -207,7 +210,9 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
             const int64_t row = row0 + j * T + tid;
             if (row < count) {
                 const uint32_t bin = gbin_of(dg[j]) & (nb - 1);
-                const uint32_t lp = lstart[bin] + atomicAdd(&hist[bin], 1u);
+                uint32_t lp;
+                if constexpr (T >= 1024) lp = lstart[bin] + rank[j];
+                else lp = lstart[bin] + atomicAdd(&hist[bin], 1u);
                 st_dig[lp] = dg[j];
                 if constexpr (kPairs) st_row[lp] = rw[j];
                 else st_row[lp] = (uint16_t)(j * T + tid);
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
         for (uint32_t i = tid; i < total; i += T) {
             const uint64_t d = st_dig[i];
             const uint32_t bin = gbin_of(d) & (nb - 1);
-            const uint32_t pos = base[bin] + (i - lstart[bin]);
+            const uint32_t pos = T >= 1024 ? base[bin] + i : base[bin] + (i - lstart[bin]);
             if (pos < cap) {
                 const int64_t at = (out0 + bin) * cap + pos;
                 slab_dig[at] = d;
