@@ -378,6 +378,21 @@ def main():
             if rank == 0:
                 print(json.dumps(out), flush=True)
             os._exit(0)
+        except (Exception, SystemExit) as e:
+            # anything else that goes wrong in the exchange phases -- an MhxError out of RCCL, a PARITY FAILURE of the sharded chain on this
+            # rank -- is reported IN the line, loudly, instead of taking the complete headline measurement above down with it; the peers this
+            # rank leaves inside a collective are released by their own watchdogs
+            import traceback
+
+            traceback.print_exc()
+            where = "allgather" if "allgather" not in out else None
+            if where:
+                out["allgather"] = {"error": repr(e)}
+            else:
+                out.setdefault("extra", {})["c3_sharded"] = {"error": repr(e), "rank": rank}
+            if rank == 0:
+                print(json.dumps(out), flush=True)
+            os._exit(0)  # (a non-zero status would make the launcher kill rank 0 before its watchdog prints the line; the traceback is on stderr)
         dog.cancel()
 
     if rank == 0 and world == 1:
