@@ -122,9 +122,9 @@ __global__ __launch_bounds__(1024) void lsh_bin_scatter_kernel(const SigT *__res
     constexpr bool kPairs = std::is_same<SigT, SlabPairs>::value;
     using RowT = typename std::conditional<kPairs, uint32_t, uint16_t>::type;  // staged per element: the row itself, or row - row0
     constexpr int kChunk = T * kScatterRows;
-    extern __shared__ uint64_t scatter_lds[];  // per team: st_dig[kChunk] | hist[nb] | base[nb] | lstart[nb] | st_row RowT[kChunk] | scan_tmp[4]
+    extern __shared__ uint64_t scatter_lds[];  // per team: st_dig[kChunk] | hist[nb] | base[nb] | lstart[nb] | st_row RowT[kChunk] | scan_tmp[16]
     const int nb = 1 << lo_bits, team = threadIdx.x / T, tid = threadIdx.x % T;
-    const size_t team_words = kChunk + (3 * (size_t)nb * 4 + kChunk * sizeof(RowT) + 32 + 7) / 8;
+    const size_t team_words = kChunk + (3 * (size_t)nb * 4 + kChunk * sizeof(RowT) + 64 + 7) / 8;  // (+ 64: scan_tmp, a word per wave of the team -- sixteen at T = 1024)
     uint64_t *st_dig = scatter_lds + team * team_words;  // the chunk's elements grouped by bin before they go out
     uint32_t *hist = reinterpret_cast<uint32_t *>(st_dig + kChunk), *base = hist + nb, *lstart = base + nb;
     RowT *st_row = reinterpret_cast<RowT *>(lstart + nb);
@@ -789,7 +789,7 @@ __global__ __launch_bounds__(256) void digests_to_band_major_kernel(const uint64
 // one scatter pass (see lsh_bin_scatter_kernel); returns false when the launch is refused
 static size_t scatter_team_bytes(int lo_bits, bool pairs, int rows, int team = 256) {
     const size_t nb = (size_t)1 << lo_bits, chunk = (size_t)team * (size_t)rows;
-    return 8 * chunk + 8 * ((3 * nb * 4 + chunk * (pairs ? 4 : 2) + 32 + 7) / 8);
+    return 8 * chunk + 8 * ((3 * nb * 4 + chunk * (pairs ? 4 : 2) + 64 + 7) / 8);
 }
 
 template <typename SigT, int ROWS>
