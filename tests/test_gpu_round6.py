@@ -373,3 +373,27 @@ def test_weighted_csr_rows_on_both_sides_of_the_cost_crossover_equal_the_oracle(
         out, ne = g.minhash_many_arrays(csr)
         wo, wn = O.c_weighted_minhash_many(csr.indptr, csr.indices, csr.data, g.rs, g.ln_cs, g.betas)
         assert np.array_equal(ne, wn) and np.array_equal(out, wo)
+
+
+# ------------------------------------------------------------------ bucketing: the big bins' range of sizes
+@pytest.mark.parametrize("n", [2_560_001, 10_480_000, 10_490_000])
+def test_big_bin_bucketing_at_the_ends_of_its_range(ctx, n):
+    """Round 6: between 2.56M and 10.2M rows a band is spread over 1024 bins of up to 11 264 elements and finished by the big form of the bin pass
+    (launch_lsh_bucket_bands); just above 2^10 x 2500 rows, at the last size that still takes it ((n >> 10) <= 10 240) and just beyond (three passes
+    again) the sorted bands must be numpy's stable order, with a cluster of equal digests inside one bin's capacity."""
+    bands = 2
+    rng = np.random.RandomState(n % 1000)
+    dig = rng.randint(0, 2**63, (bands, n), dtype=np.int64).astype(np.uint64) * np.uint64(2) + rng.randint(0, 2, (bands, n)).astype(np.uint64)
+    dig[1, rng.randint(0, n, 5000)] = dig[1, 7]  # a bucket of ~5 000 equal digests: ranked inside one sub-bucket by the row
+    d_dig = ctx.to_device(dig)
+    d_sd, d_sr = ctx.alloc(n * bands * 8), ctx.alloc(n * bands * 4)
+    _native.check(ctx.lib.mhx_lsh_sort_digests_layout_dev(ctx.handle, d_dig.ptr, n, bands, _native.BAND_MAJOR, d_sd.ptr, d_sr.ptr))
+    ctx.synchronize()
+    sd, sr = d_sd.download((bands, n), np.uint64), d_sr.download((bands, n), np.uint32)
+    for j in range(bands):
+        order = np.argsort(dig[j], kind="stable")
+        assert np.array_equal(sr[j], order.astype(np.uint32)), j
+        assert np.array_equal(sd[j], dig[j][order]), j
+    for d in (d_dig, d_sd, d_sr):
+        d.free()
+    ctx.release_scratch()
